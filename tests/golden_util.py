@@ -1,0 +1,47 @@
+"""Shared helpers: load a golden case, regenerate its synthetic inputs, run the oracle."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from jperceiver_amd import synthetic as syn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    meta = ast.literal_eval(str(g["meta"]))
+    return g, meta
+
+
+def case_inputs(meta):
+    B, HW, FR = meta["B"], meta["HW"], meta["FR"]
+    inp = syn.make_batch(B, HW, HW, FR, meta["occ"], tuple(meta["full_hw"]), meta["split"], seed=meta["seed"])
+    masks = syn.make_dropout_masks(B, HW, HW, seed=meta["seed"])
+    noise = syn.make_automask_noise(B, HW, HW, 4, len(FR) - 1, seed=meta["seed"])
+    return inp, masks, noise
+
+
+def oracle_opt(meta):
+    from oracle import jp_oracle as J
+    return J.default_opt(frame_ids=meta["FR"], imgs_per_gpu=meta["B"], height=meta["HW"], width=meta["HW"],
+                         occ_map_size=meta["occ"], type=meta["type"], split=meta["split"],
+                         loss_weightS=20, loss2_weightS=20)
+
+
+def run_oracle(meta, backward=True):
+    from oracle import jp_oracle as J
+    opt = oracle_opt(meta)
+    shapes = J.state_shapes(meta["occ"])
+    tmpl = {n: torch.empty(s, dtype=torch.long if n.endswith("num_batches_tracked") else torch.float32)
+            for n, s in shapes.items()}
+    state = syn.synth_state_dict(tmpl, seed=0)
+    P, Bf = J.make_params(shapes, state)
+    inp, masks, noise = case_inputs(meta)
+    out, L = J.forward(P, Bf, opt, inp, True, masks, noise)
+    total = J.total_loss(L)
+    if backward:
+        total.backward()
+    return dict(P=P, Bf=Bf, out=out, L=L, total=total, opt=opt, inp=inp)

@@ -1,0 +1,94 @@
+"""Pin the oracle (oracle/jp_oracle.py) against golden vectors produced by the imported
+reference (tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.golden_util import load_case, run_oracle
+from oracle import jp_oracle as J
+
+
+def pool_to(t, n=16):
+    t = t.detach().float()
+    return F.adaptive_avg_pool2d(t, (min(n, t.shape[-2]), min(n, t.shape[-1]))).numpy()
+
+
+@pytest.mark.parametrize("case", ["argo_both_256_b2", "argo_both_512_b2", "argo_both_1024_b1"])
+def test_full_step_matches_reference(case):
+    g, meta = load_case(case)
+    r = run_oracle(meta)
+    L, out, P, Bf = r["L"], r["out"], r["P"], r["Bf"]
+    for k, v in L.items():
+        ref = float(g["loss/" + repr(k)])
+        assert float(v) == pytest.approx(ref, rel=2e-5, abs=1e-7), k
+    assert float(r["total"]) == pytest.approx(float(g["loss/total"]), rel=2e-5)
+    for f in meta["FR"][1:]:
+        np.testing.assert_allclose(out[("cam_T_cam", 0, f)].detach().numpy(), g[f"cam_T_cam/{f}"], atol=1e-6)
+    for s in range(4):
+        np.testing.assert_allclose(pool_to(out[("disp", 0, s)]), g[f"disp{s}/pool"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out[("disp", 0, s)].detach().numpy()[:, :, :8, :8], g[f"disp{s}/first"], rtol=1e-4, atol=1e-6)
+        hist = np.bincount(out[("min_index", s)].reshape(-1).numpy(), minlength=4)
+        assert np.abs(hist - g[f"min_index{s}/hist"]).sum() <= 4
+        for f in meta["FR"][1:]:
+            np.testing.assert_allclose(pool_to(out[("color", f, s)]), g[f"color{f}_{s}/pool"], rtol=1e-4, atol=1e-5)
+    for k in ("topview", "transform_topview", "topviewB", "transform_topviewB"):
+        np.testing.assert_allclose(pool_to(out[k]), g[k + "/pool"], rtol=1e-3, atol=1e-4)
+    for k in ("features", "featuresB", "retransform_features", "cv_attn_road", "cm_attn_car", "origin_features"):
+        np.testing.assert_allclose(out[k].detach().numpy(), g["feat/" + k], rtol=1e-3, atol=1e-4)
+    # gradients
+    none_ref = {k[len("gradnone/"):] for k in g.files if k.startswith("gradnone/")}
+    none_got = {n for n, p in P.items() if p.grad is None}
+    assert none_got == none_ref
+    mods = {}
+    for n, p in P.items():
+        if p.grad is None:
+            continue
+        gn = float(p.grad.double().pow(2).sum()) ** 0.5
+        # conv biases feeding a BatchNorm have an analytically-zero gradient: pure rounding noise,
+        # so the absolute floor scales with the owning module's gradient norm
+        floor = 1e-6 * float(g["gradnorm_module/" + n.split(".")[0]])
+        assert gn == pytest.approx(float(g["gradnorm/" + n]), rel=2e-3, abs=floor), n
+        np.testing.assert_allclose(p.grad.reshape(-1)[:4].numpy(), g["gradprobe/" + n], rtol=5e-3,
+                                   atol=floor + 1e-4 * float(g["gradnorm/" + n]))
+    # BN buffers incl. the double update of the duplicated layout call
+    for k in g.files:
+        if k.startswith("nbt/"):
+            assert int(Bf[k[4:]]) == int(g[k]), k
+        if k.startswith("buf/"):
+            np.testing.assert_allclose(Bf[k[4:]].numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+def test_unit_vectors():
+    g = np.load(__import__("os").path.join(__import__("tests.golden_util").golden_util.GOLDEN, "unit_vectors.npz"))
+    from jperceiver_amd import synthetic as syn
+    x = torch.from_numpy(syn.hash_uniform(7, "ssim_x", (2, 3, 16, 16)))
+    y = 0.7 * x + 0.3 * torch.from_numpy(syn.hash_uniform(7, "ssim_y", (2, 3, 16, 16)))
+    np.testing.assert_allclose(J.ssim(x, y).numpy(), g["ssim/out"], atol=1e-6)
+    vec = torch.from_numpy((syn.hash_uniform(7, "aa", (8, 1, 3)) - 0.5) * 0.2)
+    vec[0] = 0
+    tr = torch.from_numpy((syn.hash_uniform(7, "tr", (8, 1, 3)) - 0.5))
+    np.testing.assert_allclose(J.rot_from_axisangle(vec).numpy(), g["pose/rot"], atol=1e-7)
+    np.testing.assert_allclose(J.transformation_from_parameters(vec, tr, False).numpy(), g["pose/M"], atol=1e-7)
+    np.testing.assert_allclose(J.transformation_from_parameters(vec, tr, True).numpy(), g["pose/Minv"], atol=1e-7)
+    n = 48
+    masks = np.zeros((5, 2, n, n), np.float32)
+    yy, xx = np.mgrid[:n, :n]
+    masks[1, 1] = ((yy - 20) ** 2 + (xx - 25) ** 2 < 100)
+    r2 = (yy - 24) ** 2 + (xx - 24) ** 2
+    masks[2, 1] = (r2 < 300) & (r2 > 90)
+    masks[3, 1, 10, 30] = 1
+    masks[4, 1] = 1
+    masks[:, 0] = 1 - masks[:, 1]
+    np.testing.assert_array_equal(J.compute_sdf(masks), g["sdf/out"])
+    logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
+    gt = torch.from_numpy(masks[:, 1]).long()
+    assert float(J.iou_loss(logits, gt)) == pytest.approx(float(g["loss/iou"]), rel=1e-6)
+    assert float(J.bd_loss(logits, gt)) == pytest.approx(float(g["loss/bd"]), rel=1e-6)
+    Bn, H, W = 2, 12, 20
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(Bn, 1, 1)
+    invK = torch.linalg.pinv(K)
+    depth = 1.0 / (0.01 + 9.99 * torch.from_numpy(syn.hash_uniform(7, "d", (Bn, 1, H, W))))
+    T = J.transformation_from_parameters(vec[1:3], tr[1:3] * 0.3, False)
+    grid = J.project(J.backproject(depth, invK), K, T, H, W)
+    np.testing.assert_allclose(grid.numpy(), g["warp/grid"], rtol=1e-5, atol=1e-5)

@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference)
+on CPU in the build container.  Never runs on the GPU box; no reference source is copied —
+this file only stubs the third-party packages the reference imports but the image lacks
+(cv2, imageio, pykitti, skimage, torchvision, torchgeometry) and feeds it
+the deterministic synthetic weights/inputs of jperceiver_amd/synthetic.py.
+
+Usage:  python tools/make_golden.py [case ...]     (default: all cases)
+"""
+import importlib.util
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import scipy.ndimage as ndi
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jperceiver_amd import synthetic as syn  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------ reference import harness
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, file):
+    spec = importlib.util.spec_from_file_location(name, file)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def import_reference():
+    np.bool = bool                                   # boundary_loss.py:137 (numpy>=1.24)
+    torch.Tensor.cuda = lambda self, *a, **k: self   # hard .cuda() calls all over net.py/layers.py
+    nn.Module.cuda = lambda self, *a, **k: self
+    _stub("imageio"); _stub("pykitti"); _stub("cv2")
+
+    def find_boundaries(img, mode="inner"):          # skimage rule, connectivity=1
+        img = np.asarray(img).astype(np.uint8)
+        fp = ndi.generate_binary_structure(2, 1)
+        b = ndi.grey_dilation(img, footprint=fp) != ndi.grey_erosion(img, footprint=fp)
+        return b & (img != 0)
+    sk = _stub("skimage")
+    sk.segmentation = _stub("skimage.segmentation", find_boundaries=find_boundaries)
+    base = REF + "/mono/model/mono_baseline"
+    _pkg("mono", REF + "/mono"); _pkg("mono.model", REF + "/mono/model"); _pkg("mono.model.mono_baseline", base)
+    _load("mono.model.registry", REF + "/mono/model/registry.py")
+    res = _load("mono.model.mono_baseline.resnet", base + "/resnet.py")
+    tv = _stub("torchvision")
+    tvm = _stub("torchvision.models", ResNet=res.ResNet, resnet18=lambda pretrained=False: res.resnet18(),
+                resnet34=None, resnet50=None, resnet101=None, resnet152=None)
+    tvm.resnet = types.SimpleNamespace(BasicBlock=res.BasicBlock, Bottleneck=res.Bottleneck, model_urls={})
+
+    def rotate(x, angle):
+        assert angle == 270
+        return torch.rot90(x, k=3, dims=(-2, -1))
+    tv.models = tvm
+    tv.transforms = _stub("torchvision.transforms", functional=types.SimpleNamespace(rotate=rotate))
+
+    def transform_points(T, pts):                    # torchgeometry 0.1.2 semantics
+        ph = F.pad(pts, (0, 1), value=1.0)
+        out = torch.matmul(T.unsqueeze(1), ph.unsqueeze(-1)).squeeze(-1)
+        return out[..., :-1] / out[..., -1:]
+
+    def npix(h, w):
+        return torch.tensor([[2.0 / (w - 1), 0, -1], [0, 2.0 / (h - 1), -1], [0, 0, 1.0]]).unsqueeze(0)
+
+    def warp_perspective(src, M, dsize):
+        B, C, H, W = src.shape
+        h, w = dsize
+        sntd = torch.inverse(npix(h, w) @ M @ torch.inverse(npix(H, W)))
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")
+        grid = torch.stack([xs, ys], -1).view(1, -1, 2).expand(B, -1, -1)
+        return F.grid_sample(src, transform_points(sntd, grid).view(B, h, w, 2), mode="bilinear", padding_mode="zeros")
+    _stub("torchgeometry"); _stub("torchgeometry.core")
+    _stub("torchgeometry.core.imgwarp", warp_perspective=warp_perspective)
+    _stub("torchgeometry.core.transformations", transform_points=transform_points)
+    return _load("mono.model.mono_baseline.net", base + "/net.py")
+
+
+class Opt(dict):
+    __getattr__ = dict.__getitem__
+
+
+class FixedDropout(nn.Module):
+    """stands in for DepthDecoder.do (depth_decoder.py:13,52-53): x * keep * 1/(1-p)."""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.i = masks, 0
+
+    def forward(self, x):
+        m = self.masks[self.i % len(self.masks)]
+        self.i += 1
+        return x * m * 2.0
+
+
+# ------------------------------------------------------------------ helpers
+def crc(t):
+    return zlib.crc32(np.ascontiguousarray(t.detach().numpy()).tobytes()) & 0xFFFFFFFF
+
+
+def pool_to(t, n=16):
+    """adaptive-average to at most n x n (size-independent fingerprint of a map)."""
+    t = t.detach().float()
+    return F.adaptive_avg_pool2d(t, (min(n, t.shape[-2]), min(n, t.shape[-1]))).numpy()
+
+
+def run_case(net, name, HW, B, FR, ty, split, full_hw, seed=1):
+    occ = HW // 4
+    opt = Opt(depth_num_layers=18, pose_num_layers=18, frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW,
+              scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0, depth_pretrained_path=None,
+              pose_pretrained_path=None, automask=True, disp_norm=True, smoothness_weight=1e-3,
+              scale_weight=0.1, dynamic_weight=15., static_weight=5., occ_map_size=occ, num_class=2,
+              loss_type="iou", loss_weight=20, loss_weightS=20, loss2_type="boundary", loss2_weight=20,
+              loss2_weightS=20, type=ty, loss_sum=3, split=split)
+    torch.manual_seed(0)
+    model = net.Baseline(opt)
+    sd = syn.synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    inp = syn.make_batch(B, HW, HW, FR, occ, full_hw, split, seed=seed)
+    m4, m3 = syn.make_dropout_masks(B, HW, HW, seed=seed)
+    model.DepthDecoder.do = FixedDropout([m4, m3])
+    noise = syn.make_automask_noise(B, HW, HW, 4, len(FR) - 1, seed=seed)
+    flat = [n.clone() for per_scale in noise for n in per_scale]
+    it = iter(flat)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    # capture the scale label the reference computes (it is an *input* of the parity-checked step)
+    cap = {}
+    orig = model.get_scale_label_both
+
+    def grab(inputs, o):
+        cap["scale_label"] = orig(inputs, o)
+        return cap["scale_label"]
+    model.get_scale_label_both = grab
+    try:
+        out, losses = model({k: v.clone() for k, v in inp.items()})
+    finally:
+        torch.randn = real_randn
+    total = sum(v.mean() for v in losses.values())
+    total.backward()
+
+    g = {}
+    for k, v in losses.items():
+        g["loss/" + repr(k)] = np.float64(v.detach().double().item())
+    g["loss/total"] = np.float64(total.detach().double().item())
+    for f in FR[1:]:
+        g[f"cam_T_cam/{f}"] = out[("cam_T_cam", 0, f)].detach().numpy()
+    for s in range(4):
+        d = out[("disp", 0, s)]
+        g[f"disp{s}/pool"] = pool_to(d)
+        g[f"disp{s}/mean"] = np.float64(d.double().mean().item())
+        g[f"disp{s}/first"] = d.detach().numpy()[:, :, :8, :8].copy()
+        g[f"min_index{s}/hist"] = np.bincount(out[("min_index", s)].reshape(-1).numpy(), minlength=4)
+        for f in FR[1:]:
+            g[f"color{f}_{s}/pool"] = pool_to(out[("color", f, s)])
+    for k in ("topview", "transform_topview", "topviewB", "transform_topviewB"):
+        g[k + "/pool"] = pool_to(out[k])
+        g[k + "/first"] = out[k].detach().numpy()[:, :, :8, :8].copy()
+    for k in ("features", "featuresB", "retransform_features", "retransform_featuresB",
+              "transform_feature_road", "transform_feature_car", "cv_attn_road", "cm_attn_road",
+              "cv_attn_car", "cm_attn_car", "origin_features"):
+        g["feat/" + k] = out[k].detach().numpy()
+    g["scale_label/pool"] = pool_to(cap["scale_label"], 32)
+    g["scale_label/nnz"] = np.int64((cap["scale_label"] > 0).sum().item())
+    # gradients: L2 norm per top-level module, per parameter, and a few probed entries
+    mods = {}
+    for n, p in model.named_parameters():
+        top = n.split(".")[0]
+        if p.grad is None:
+            g["gradnone/" + n] = np.int64(1)
+            continue
+        gn = float(p.grad.double().pow(2).sum())
+        mods[top] = mods.get(top, 0.0) + gn
+        g["gradnorm/" + n] = np.float64(np.sqrt(gn))
+        g["gradprobe/" + n] = p.grad.reshape(-1)[:4].detach().numpy().copy()
+    for top, v in mods.items():
+        g["gradnorm_module/" + top] = np.float64(np.sqrt(v))
+    # BN buffer side effects (N4)
+    for n, b in model.named_buffers():
+        if n.endswith("num_batches_tracked"):
+            g["nbt/" + n] = np.int64(b.item())
+    for n in ("DepthEncoder.encoder.bn1.running_mean", "LayoutEncoder.resnet_encoder.encoder.bn1.running_mean",
+              "LayoutDecoder.decoder.1.running_var", "LayoutDecoderB.decoder.1.running_var",
+              "PoseEncoder.encoder.bn1.running_var"):
+        g["buf/" + n] = dict(model.named_buffers())[n].detach().numpy().copy()
+    meta = dict(HW=HW, B=B, FR=FR, type=ty, split=split, full_hw=list(full_hw), seed=seed, occ=occ)
+    g["meta"] = np.array(repr(meta))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
+    print(name, "total loss", g["loss/total"], "keys", len(g))
+    return model, inp, out, losses, cap
+
+
+def unit_vectors(net):
+    """Small op-level known-answer vectors straight from the reference's layers/losses."""
+    layers = sys.modules["mono.model.mono_baseline.layers"]
+    bl = sys.modules["mono.model.mono_baseline.boundary_loss"]
+    dl = sys.modules["mono.model.mono_baseline.dice_loss"]
+    g = {}
+    x = torch.from_numpy(syn.hash_uniform(7, "ssim_x", (2, 3, 16, 16)))
+    y = torch.from_numpy(syn.hash_uniform(7, "ssim_y", (2, 3, 16, 16)))
+    y = 0.7 * x + 0.3 * y
+    g["ssim/out"] = layers.SSIM()(x, y).numpy()
+    # rot_from_axisangle / transformation_from_parameters on 8 vectors incl. zero (net.py:704-756)
+    vec = torch.from_numpy((syn.hash_uniform(7, "aa", (8, 1, 3)) - 0.5) * 0.2)
+    vec[0] = 0
+    tr = torch.from_numpy((syn.hash_uniform(7, "tr", (8, 1, 3)) - 0.5))
+    B = net.Baseline
+    dummy = types.SimpleNamespace()
+    for nm in ("rot_from_axisangle", "get_translation_matrix", "transformation_from_parameters"):
+        setattr(dummy, nm, types.MethodType(getattr(B, nm), dummy))
+    g["pose/rot"] = dummy.rot_from_axisangle(vec).numpy()
+    g["pose/M"] = dummy.transformation_from_parameters(vec, tr, invert=False).numpy()
+    g["pose/Minv"] = dummy.transformation_from_parameters(vec, tr, invert=True).numpy()
+    # SDF on hand-made masks: empty / blob / ring / single pixel / full (boundary_loss.py:121-147)
+    n = 48
+    masks = np.zeros((5, 2, n, n), np.float32)
+    yy, xx = np.mgrid[:n, :n]
+    masks[1, 1] = ((yy - 20) ** 2 + (xx - 25) ** 2 < 100)
+    r2 = (yy - 24) ** 2 + (xx - 24) ** 2
+    masks[2, 1] = (r2 < 300) & (r2 > 90)
+    masks[3, 1, 10, 30] = 1
+    masks[4, 1] = 1
+    masks[:, 0] = 1 - masks[:, 1]
+    g["sdf/out"] = bl.compute_sdf(masks, masks.shape)
+    # IoU / BD / CE losses on random logits vs a blob label (dice_loss.py:293-331, boundary_loss.py:150-192)
+    logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
+    gt = torch.from_numpy(masks[:, 1]).long()
+    g["loss/iou"] = np.float64(dl.IoULoss(apply_nonlin=lambda t: F.softmax(t, 1))(logits, gt).item())
+    g["loss/bd"] = np.float64(bl.BDLoss()(logits, gt).item())
+    g["loss/ce"] = np.float64(nn.CrossEntropyLoss(weight=torch.tensor([1.0, 5.0]))(logits, gt).item())
+    # Backproject / Project / grid_sample (layers.py:41-82, net.py:690-702) on a tiny case
+    Bn, H, W = 2, 12, 20
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(Bn, 1, 1)
+    invK = torch.linalg.pinv(K)
+    depth = 1.0 / (0.01 + 9.99 * torch.from_numpy(syn.hash_uniform(7, "d", (Bn, 1, H, W))))
+    T = dummy.transformation_from_parameters(vec[1:3], tr[1:3] * 0.3, invert=False)
+    cam = layers.Backproject(Bn, H, W)(depth, invK)
+    pix = layers.Project(Bn, H, W)(cam, K, T)
+    img = torch.from_numpy(syn.hash_uniform(7, "img", (Bn, 3, H, W)))
+    g["warp/grid"] = pix.numpy()
+    g["warp/out"] = F.grid_sample(img, pix, padding_mode="border").numpy()
+    np.savez_compressed(os.path.join(OUT, "unit_vectors.npz"), **g)
+    print("unit_vectors keys", len(g))
+
+
+CASES = {
+    # name: (HW, B, frames, type, split, full-res frame (shrunk), seed)
+    "argo_both_256_b2": (256, 2, [0, -1, 1], "Argo_both", "argo", (257, 308), 1),
+    "argo_both_512_b2": (512, 2, [0, -1, 1], "Argo_both", "argo", (514, 616), 2),
+    "argo_both_1024_b1": (1024, 1, [0, -1], "Argo_both", "argo", (514, 616), 3),
+}
+
+if __name__ == "__main__":
+    net = import_reference()
+    want = sys.argv[1:] or (["unit"] + list(CASES))
+    for c in want:
+        if c == "unit":
+            unit_vectors(net)
+        else:
+            run_case(net, c, *CASES[c][:6], seed=CASES[c][6])
