@@ -1,0 +1,254 @@
+// Train-mode BatchNorm2d (+ fused residual add and ReLU) forward/backward and the per-channel
+// reductions they need.  Replaces nn.BatchNorm2d at resnet.py:21-24,41-45,92 and
+// layout_model.py:146,152 (batch statistics, biased var for normalisation, unbiased var into
+// running_var with momentum 0.1, eps 1e-5).  All kernels are HBM-bound streaming passes:
+// NCHW fp32, one (channel, slice) per workgroup, float4 loads when HW % 4 == 0.
+#include "jp_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int TPB = 256;
+
+// grid (C, S): partial sum / sum of squares of channel c over a slice of the N*HW elements,
+// fp32 per-thread accumulation over short runs, double for the block and cross-block combination.
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums,
+                                                       int C, int HW, int CH, int chunk) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
+    const int beg = ck * chunk, end = min(HW, beg + chunk);
+    const float* xp = x + ((size_t)n * C + c) * HW;
+    double s = 0.0, q = 0.0;
+    float fs = 0.f, fq = 0.f;
+    int run = 0;
+    for (int i = beg + threadIdx.x; i < end; i += TPB) {
+        const float v = xp[i];
+        fs += v;
+        fq += v * v;
+        if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+    }
+    s += fs; q += fq;
+    s = jp_block_sum_d(s, sm);
+    q = jp_block_sum_d(q, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], s);
+        atomicAdd(&sums[2 * c + 1], q);
+    }
+}
+
+// C threads: mean / invstd and running-stat momentum update (applied n_updates times: the
+// reference evaluates the layout branch twice per iteration).
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, int C, double count, float momentum, float eps,
+                                   int n_updates) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const float unb = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+        float rm = running_mean[c], rv = running_var[c];
+        for (int i = 0; i < n_updates; ++i) {
+            rm = (1.f - momentum) * rm + momentum * (float)m;
+            rv = (1.f - momentum) * rv + momentum * unb;
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
+// y = relu?( (x-mean)*invstd*gamma + beta (+ residual) )
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       int C, int HW, int relu) {
+    const int nc = blockIdx.y;  // n*C + c
+    const int c = nc % C;
+    const float sc = invstd[c] * gamma[c];
+    const float sh = beta[c] - mean[c] * sc;
+    const size_t base = (size_t)nc * HW;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+        float v = x[base + i] * sc + sh;
+        if (residual) v += residual[base + i];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[base + i] = v;
+    }
+}
+
+// eval mode: y = relu?( (x-running_mean)/sqrt(running_var+eps)*gamma + beta (+ residual) )
+__global__ __launch_bounds__(TPB) void bn_eval_kernel(const float* __restrict__ x, const float* __restrict__ rm,
+                                                      const float* __restrict__ rv, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ residual, float* __restrict__ y,
+                                                      int C, int HW, float eps, int relu) {
+    const int nc = blockIdx.y;
+    const int c = nc % C;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    const float sh = beta[c] - rm[c] * sc;
+    const size_t base = (size_t)nc * HW;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+        float v = x[base + i] * sc + sh;
+        if (residual) v += residual[base + i];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[base + i] = v;
+    }
+}
+
+// backward reduction: per channel sum(dyr), sum(dyr * xhat) with dyr = dy * (y > 0) when relu
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            double* __restrict__ sums, int C, int HW, int CH,
+                                                            int chunk, int relu) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
+    const int beg = ck * chunk, end = min(HW, beg + chunk);
+    const size_t base = ((size_t)n * C + c) * HW;
+    const float mu = mean[c], is = invstd[c];
+    double s = 0.0, q = 0.0;
+    float fs = 0.f, fq = 0.f;
+    int run = 0;
+    for (int i = beg + threadIdx.x; i < end; i += TPB) {
+        const size_t o = base + i;
+        float g = dy[o];
+        if (relu && !(y[o] > 0.f)) g = 0.f;
+        fs += g;
+        fq += g * (x[o] - mu) * is;
+        if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+    }
+    s += fs; q += fq;
+    s = jp_block_sum_d(s, sm);
+    q = jp_block_sum_d(q, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], s);
+        atomicAdd(&sums[2 * c + 1], q);
+    }
+}
+
+// dx = gamma*invstd * (dyr - sum_dy/cnt - xhat*sum_dy_xhat/cnt);  dres = dyr;  dgamma/dbeta by block (0,c-row 0)
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, float* __restrict__ dx,
+                                                           float* __restrict__ dres, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int C, int HW, double count,
+                                                           int relu, int acc_param_grads) {
+    const int nc = blockIdx.y;
+    const int c = nc % C;
+    const float mu = mean[c], is = invstd[c], g = gamma[c];
+    const float k1 = (float)(sums[2 * c] / count), k2 = (float)(sums[2 * c + 1] / count);
+    if (nc < C && blockIdx.x == 0 && threadIdx.x == 0) {  // image 0 owns the parameter gradients
+        const float dg = (float)sums[2 * c + 1], db = (float)sums[2 * c];
+        dgamma[c] = acc_param_grads ? dgamma[c] + dg : dg;
+        dbeta[c] = acc_param_grads ? dbeta[c] + db : db;
+    }
+    const size_t base = (size_t)nc * HW;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+        float d = dy[base + i];
+        if (relu && !(y[base + i] > 0.f)) d = 0.f;
+        if (dres) dres[base + i] = d;
+        const float xh = (x[base + i] - mu) * is;
+        dx[base + i] = g * is * (d - k1 - xh * k2);
+    }
+}
+
+// generic per-channel sum over (N, HW): out[c] (+)= sum  — conv bias gradients
+__global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int C, int HW, int CH, int chunk) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
+    const int beg = ck * chunk, end = min(HW, beg + chunk);
+    const float* xp = x + ((size_t)n * C + c) * HW;
+    double s = 0.0;
+    float fs = 0.f;
+    int run = 0;
+    for (int i = beg + threadIdx.x; i < end; i += TPB) {
+        fs += xp[i];
+        if (++run == 32) { s += fs; fs = 0.f; run = 0; }
+    }
+    s += fs;
+    s = jp_block_sum_d(s, sm);
+    if (threadIdx.x == 0) atomicAdd(&out[c], (float)s);
+}
+
+// chunks per image so that ~2k workgroups stream the tensor, each at least 2048 elements
+void chunking(int N, int C, int HW, int* CH, int* chunk) {
+    int ch = std::max(1, 2048 / std::max(1, N * C));
+    ch = std::min(ch, std::max(1, HW / 2048));
+    *chunk = (HW + ch - 1) / ch;
+    *CH = (HW + *chunk - 1) / *chunk;
+}
+
+}  // namespace
+
+// ws: 2*C doubles of caller-owned scratch (zeroed here).  Saves mean/invstd for backward.
+extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                               float* y, float* running_mean, float* running_var, float* save_mean,
+                               float* save_invstd, double* ws, int N, int C, int HW, float momentum, float eps,
+                               int relu, int n_updates, void* stream) {
+    JP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
+    JP_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn_train_fwd: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    JP_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
+    int CH, chunk;
+    chunking(N, C, HW, &CH, &chunk);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(jp_cdiv(C, 64)), dim3(64), 0, st, ws, save_mean, save_invstd,
+                       running_mean, running_var, C, (double)N * HW, momentum, eps, n_updates);
+    const int gx = std::min(jp_cdiv(HW, TPB), 64);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, save_mean, save_invstd, gamma, beta,
+                       residual, y, C, HW, relu);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                               const float* save_mean, const float* save_invstd, float* dx, float* dres,
+                               float* dgamma, float* dbeta, double* ws, int N, int C, int HW, int relu,
+                               int acc_param_grads, void* stream) {
+    JP_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
+    JP_CHECK_ARG(!relu || y, "bn_train_bwd: relu needs the forward output");
+    hipStream_t st = (hipStream_t)stream;
+    JP_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
+    int CH, chunk;
+    chunking(N, C, HW, &CH, &chunk);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, ws, C,
+                       HW, CH, chunk, relu);
+    const int gx = std::min(jp_cdiv(HW, TPB), 64);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, gamma,
+                       ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
+    JP_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "channel_sum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) JP_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, st));
+    int CH, chunk;
+    chunking(N, C, HW, &CH, &chunk);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, out, C, HW, CH, chunk);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                              const float* running_var, const float* residual, float* y, int N, int C, int HW,
+                              float eps, int relu, void* stream) {
+    JP_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && N > 0 && C > 0 && HW > 0, "bn_eval_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = std::min(jp_cdiv(HW, TPB), 64);
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, running_mean, running_var, gamma, beta,
+                       residual, y, C, HW, eps, relu);
+    JP_LAUNCH_CHECK();
+}

@@ -1,0 +1,124 @@
+// One LDS-staged fp32-MFMA implicit-GEMM engine for gfx950:  C[m][n] (+)= sum_k A(m,k) * B(k,n)
+// with pluggable gather-loaders for A and B and a pluggable epilogue.  conv2d forward, dgrad and
+// wgrad, 1x1 convs and the dense layers are all instances of this kernel (conv.hip).
+//
+// Geometry: 256 threads = 4 wave64.  Every wave owns a 64x64 output tile as 2x2
+// v_mfma_f32_32x32x2_f32 accumulators (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak, guide
+// cdna_hip_programming.md §3).  Block tile = (64*WM) x (64*WN), WM*WN == 4.  The K loop is chunked
+// by KC; each chunk is gathered global->registers (prefetched one chunk ahead, so the loads fly
+// under the previous chunk's MFMAs), stored to LDS as As[k][m] / Bs[k][n] (row pad 1 -> both the
+// lane-along-k and lane-along-mn store patterns and the MFMA fragment reads are bank-conflict
+// free) and consumed with one ds_read_b32 per operand per MFMA.
+#pragma once
+#include "jp_common.h"
+
+typedef float jp_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi>
+__global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi epi, int M, int N, int K,
+                                                      int k_per_split) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int NA = BM * KC / 256, NB = BN * KC / 256;  // elements per thread per chunk
+    __shared__ float As[KC * LDA];
+    __shared__ float Bs[KC * LDB];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    // ---- loader thread mappings
+    // ALONG_K  : lanes run along k (kk = t % KC), mn = t / KC + (256/KC) * r
+    // ALONG_MN : lanes run along m/n (mn = t % B), kk = t / B + (256/B) * r      (B <= 256)
+    constexpr int A_ROWS = ALoad::ALONG_K ? (256 / KC) : (256 / BM);
+    constexpr int B_ROWS = BLoad::ALONG_K ? (256 / KC) : (256 / BN);
+    const int a_fix_l = ALoad::ALONG_K ? (t % KC) : (t % BM);
+    const int a_var_l = ALoad::ALONG_K ? (t / KC) : (t / BM);
+    const int b_fix_l = BLoad::ALONG_K ? (t % KC) : (t % BN);
+    const int b_var_l = BLoad::ALONG_K ? (t / KC) : (t / BN);
+    // loader state lives in registers (the functors themselves are read-only kernel arguments)
+    typename ALoad::St sa = al.fix(ALoad::ALONG_K ? 0 : m0 + a_fix_l);
+    typename BLoad::St sb = bl.fix(BLoad::ALONG_K ? 0 : n0 + b_fix_l);
+
+    float ra[NA], rb[NB];
+    auto gload = [&](int kc) {
+        if (ALoad::ALONG_K) {
+            sa = al.fix(kc + a_fix_l);
+#pragma unroll
+            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, m0 + a_var_l + A_ROWS * r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, kc + a_var_l + A_ROWS * r);
+        }
+        if (BLoad::ALONG_K) {
+            sb = bl.fix(kc + b_fix_l);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, n0 + b_var_l + B_ROWS * r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, kc + b_var_l + B_ROWS * r);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            if (ALoad::ALONG_K) As[a_fix_l * LDA + a_var_l + A_ROWS * r] = ra[r];
+            else As[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            if (BLoad::ALONG_K) Bs[b_fix_l * LDB + b_var_l + B_ROWS * r] = rb[r];
+            else Bs[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = rb[r];
+        }
+    };
+
+    jp_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const float* ap = As + lhi * LDA + wm * 64 + l31;
+    const float* bp = Bs + lhi * LDB + wn * 64 + l31;
+
+    if (kbeg < kend) gload(kbeg);
+    for (int kc = kbeg; kc < kend; kc += KC) {
+        lstore();
+        __syncthreads();
+        if (kc + KC < kend) gload(kc + KC);  // in flight during the MFMAs below
+#pragma unroll 4
+        for (int kk = 0; kk < KC; kk += 2) {
+            const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
+            const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= N) continue;
+        const typename Epi::St se = epi.col(n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < M) epi.put(se, m, acc[i][j][r]);
+            }
+        }
+    }
+}

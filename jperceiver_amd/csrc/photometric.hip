@@ -1,0 +1,559 @@
+// The CGT view-synthesis + photometric loss path of the JPerceiver train step, forward and backward:
+//   pose      : Rodrigues + (T*R | R^T*T(-t)) + P = K*T        (net.py:704-756, layers.py:74)
+//   cgt warp  : bilinear-up(disp) -> depth -> backproject -> project -> grid_sample(bilinear, border,
+//               align_corners=False)                           (net.py:690-702, layers.py:57-61,73-82)
+//   ssim + l1 : 0.85*mean_c SSIM + 0.15*mean_c sqrt((t-p)^2+1e-6)  (layers.py:97-107, net.py:84-92)
+//   min-reproj: min/argmin over identity(+noise) and warped candidates, mean  (net.py:159-175)
+// All HBM-bound.  SSIM forward does its 3x3 window sums in registers: a wave owns a 64-pixel-wide
+// column strip, horizontal taps come from neighbouring lanes (DPP/ds_bpermute wave shuffles), the
+// vertical taps from a 3-row sliding window, so every pixel is read once (+2/ROWS halo rows).
+#include "jp_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr float SSIM_C1 = 0.0001f, SSIM_C2 = 0.0009f;
+
+// ------------------------------------------------------------------------------ pose
+__device__ void rodrigues(const float v[3], float R[9]) {
+    const float th = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float inv = 1.f / (th + 1e-7f);
+    const float x = v[0] * inv, y = v[1] * inv, z = v[2] * inv;
+    const float ca = cosf(th), sa = sinf(th), C = 1.f - ca;
+    R[0] = x * x * C + ca;     R[1] = x * y * C - z * sa; R[2] = z * x * C + y * sa;
+    R[3] = x * y * C + z * sa; R[4] = y * y * C + ca;     R[5] = y * z * C - x * sa;
+    R[6] = z * x * C - y * sa; R[7] = y * z * C + x * sa; R[8] = z * z * C + ca;
+}
+
+// one thread per batch element.  aa/tr: (B,3).  T: (B,4,4) cam_T_cam.  P: (B,3,4) = (K*T)[:3]
+__global__ void pose_fwd_kernel(const float* __restrict__ aa, const float* __restrict__ tr,
+                                const float* __restrict__ K, float* __restrict__ T, float* __restrict__ P, int B,
+                                int invert) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float v[3] = {aa[3 * b], aa[3 * b + 1], aa[3 * b + 2]};
+    float t[3] = {tr[3 * b], tr[3 * b + 1], tr[3 * b + 2]};
+    float R[9], M[16];
+    rodrigues(v, R);
+    for (int i = 0; i < 16; ++i) M[i] = 0.f;
+    M[15] = 1.f;
+    if (!invert) {  // M = T(t) * R
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) M[4 * i + j] = R[3 * i + j];
+            M[4 * i + 3] = t[i];
+        }
+    } else {        // M = R^T * T(-t)
+        for (int i = 0; i < 3; ++i) {
+            float s = 0.f;
+            for (int j = 0; j < 3; ++j) {
+                M[4 * i + j] = R[3 * j + i];
+                s += R[3 * j + i] * (-t[j]);
+            }
+            M[4 * i + 3] = s;
+        }
+    }
+    for (int i = 0; i < 16; ++i) T[16 * b + i] = M[i];
+    const float* Kb = K + 16 * b;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s += Kb[4 * i + k] * M[4 * k + j];
+            P[12 * b + 4 * i + j] = s;
+        }
+}
+
+// dP (B,3,4) as doubles accumulated by the warp backward -> d axisangle, d translation
+__global__ void pose_bwd_kernel(const double* __restrict__ dP, const float* __restrict__ aa,
+                                const float* __restrict__ tr, const float* __restrict__ K, float* __restrict__ daa,
+                                float* __restrict__ dtr, int B, int invert, int accumulate) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* Kb = K + 16 * b;
+    float dM[12];  // rows 0..2 of K[:3,:]^T dP  (row 3 of M is constant)
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int i = 0; i < 3; ++i) s += Kb[4 * i + k] * (float)dP[12 * b + 4 * i + j];
+            dM[4 * k + j] = s;
+        }
+    float v[3] = {aa[3 * b], aa[3 * b + 1], aa[3 * b + 2]};
+    float t[3] = {tr[3 * b], tr[3 * b + 1], tr[3 * b + 2]};
+    float R[9], G[9], dt[3];
+    rodrigues(v, R);
+    if (!invert) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) G[3 * i + j] = dM[4 * i + j];
+            dt[i] = dM[4 * i + 3];
+        }
+    } else {
+        const float g3[3] = {dM[3], dM[7], dM[11]};
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.f;
+            for (int i = 0; i < 3; ++i) {
+                G[3 * j + i] = dM[4 * i + j] - g3[i] * t[j];
+                s += R[3 * j + i] * g3[i];
+            }
+            dt[j] = -s;
+        }
+    }
+    const float th = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float inv = 1.f / (th + 1e-7f);
+    const float a[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+    const float ca = cosf(th), sa = sinf(th), C = 1.f - ca;
+    float aGa = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) aGa += a[i] * G[3 * i + j] * a[j];
+    const float dca = G[0] + G[4] + G[8] - aGa;
+    const float dsa = -a[2] * G[1] + a[1] * G[2] + a[2] * G[3] - a[0] * G[5] - a[1] * G[6] + a[0] * G[7];
+    float da[3] = {sa * (-G[5] + G[7]), sa * (G[2] - G[6]), sa * (-G[1] + G[3])};
+    for (int i = 0; i < 3; ++i) {
+        float s = 0.f;
+        for (int j = 0; j < 3; ++j) s += (G[3 * i + j] + G[3 * j + i]) * a[j];
+        da[i] += C * s;
+    }
+    float dth = -sa * dca + ca * dsa;
+    dth -= (da[0] * v[0] + da[1] * v[1] + da[2] * v[2]) * inv * inv;
+    for (int i = 0; i < 3; ++i) {
+        float g = da[i] * inv + (th > 0.f ? dth * v[i] / th : 0.f);
+        daa[3 * b + i] = accumulate ? daa[3 * b + i] + g : g;
+        dtr[3 * b + i] = accumulate ? dtr[3 * b + i] + dt[i] : dt[i];
+    }
+}
+
+// ------------------------------------------------------------------------------ CGT warp
+__device__ __forceinline__ void bil_src(int o, float scale, int in, int& i0, int& i1, float& w1) {
+    float src = ((float)o + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+
+struct WarpGeo {   // per-pixel forward geometry, recomputed identically in backward
+    float depth, rx, ry, rz;       // depth and K^-1 ray
+    float px, py, pz;              // projected homogeneous point (pz before +eps)
+    float ix, iy;                  // clipped source coordinates
+    float mx, my;                  // d(clipped)/d(unclipped): 0 when clipped (PyTorch clip_coordinates_set_grad)
+};
+
+__device__ __forceinline__ WarpGeo warp_geo(const float* __restrict__ disp, int hs, int ws, const float* iK,
+                                            const float* P, int y, int x, int H, int W, float min_disp,
+                                            float max_disp, float ssy, float ssx) {
+    WarpGeo g;
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bil_src(y, ssy, hs, y0, y1, wy);
+    bil_src(x, ssx, ws, x0, x1, wx);
+    const float d = (1.f - wy) * ((1.f - wx) * disp[y0 * ws + x0] + wx * disp[y0 * ws + x1]) +
+                    wy * ((1.f - wx) * disp[y1 * ws + x0] + wx * disp[y1 * ws + x1]);
+    g.depth = 1.f / (min_disp + (max_disp - min_disp) * d);
+    const float fx = (float)x, fy = (float)y;
+    g.rx = iK[0] * fx + iK[1] * fy + iK[2];
+    g.ry = iK[4] * fx + iK[5] * fy + iK[6];
+    g.rz = iK[8] * fx + iK[9] * fy + iK[10];
+    const float X = g.depth * g.rx, Y = g.depth * g.ry, Z = g.depth * g.rz;
+    g.px = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+    g.py = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+    g.pz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+    const float zi = g.pz + 1e-7f;
+    float gx = (g.px / zi / (float)(W - 1) - 0.5f) * 2.f;
+    float gy = (g.py / zi / (float)(H - 1) - 0.5f) * 2.f;
+    float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    g.mx = (ix > 0.f && ix < (float)(W - 1)) ? 1.f : 0.f;   // clip_coordinates_set_grad; NaN -> 0 too
+    g.my = (iy > 0.f && iy < (float)(H - 1)) ? 1.f : 0.f;
+    g.ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    g.iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    if (!(ix == ix)) g.ix = 0.f;
+    if (!(iy == iy)) g.iy = 0.f;
+    return g;
+}
+
+// grid (blocks over H*W, B).  pred (B,3,H,W)
+__global__ __launch_bounds__(TPB) void cgt_warp_fwd_kernel(const float* __restrict__ disp, int hs, int ws,
+                                                           const float* __restrict__ invK,
+                                                           const float* __restrict__ Pm,
+                                                           const float* __restrict__ color,
+                                                           float* __restrict__ pred, int H, int W, float min_disp,
+                                                           float max_disp) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pm + 12 * b, y, x, H, W, min_disp,
+                               max_disp, (float)hs / (float)H, (float)ws / (float)W);
+    const int x0 = (int)floorf(g.ix), y0 = (int)floorf(g.iy);
+    const float tx = g.ix - (float)x0, ty = g.iy - (float)y0;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);   // weight of an OOB corner is 0
+    const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+    const size_t HW = (size_t)H * W;
+    const float* c = color + (size_t)b * 3 * HW;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* cc = c + ch * HW;
+        pred[((size_t)b * 3 + ch) * HW + p] =
+            cc[y0 * W + x0] * w00 + cc[y0 * W + x1] * w01 + cc[y1 * W + x0] * w10 + cc[y1 * W + x1] * w11;
+    }
+}
+
+// dpred (B,3,H,W) -> ddisp_up (B,1,H,W) (accumulated over source frames) and dP (B,12) doubles
+__global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restrict__ dpred,
+                                                           const float* __restrict__ disp, int hs, int ws,
+                                                           const float* __restrict__ invK,
+                                                           const float* __restrict__ Pm,
+                                                           const float* __restrict__ color,
+                                                           float* __restrict__ ddisp_up, double* __restrict__ dP,
+                                                           int H, int W, float min_disp, float max_disp,
+                                                           int accumulate) {
+    __shared__ float red[12][4];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    float dPl[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dPl[i] = 0.f;
+    if (p < H * W) {
+        const int y = p / W, x = p - y * W;
+        const float* Pb = Pm + 12 * b;
+        const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pb, y, x, H, W, min_disp,
+                                   max_disp, (float)hs / (float)H, (float)ws / (float)W);
+        const int x0 = (int)floorf(g.ix), y0 = (int)floorf(g.iy);
+        const float tx = g.ix - (float)x0, ty = g.iy - (float)y0;
+        const bool xin = x0 + 1 <= W - 1, yin = y0 + 1 <= H - 1;
+        const int x1 = xin ? x0 + 1 : x0, y1 = yin ? y0 + 1 : y0;
+        const size_t HW = (size_t)H * W;
+        const float* c = color + (size_t)b * 3 * HW;
+        float gix = 0.f, giy = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* cc = c + ch * HW;
+            const float go = dpred[((size_t)b * 3 + ch) * HW + p];
+            const float v00 = cc[y0 * W + x0];
+            const float v01 = xin ? cc[y0 * W + x1] : 0.f;
+            const float v10 = yin ? cc[y1 * W + x0] : 0.f;
+            const float v11 = (xin && yin) ? cc[y1 * W + x1] : 0.f;
+            // PyTorch grid_sampler_2d_backward: OOB corners contribute nothing
+            gix += go * (-(v00 * (1.f - ty)) + v01 * (1.f - ty) - v10 * ty + v11 * ty);
+            giy += go * (-(v00 * (1.f - tx)) - v01 * tx + v10 * (1.f - tx) + v11 * tx);
+        }
+        // unnormalise (W/2), border clip mask, then Project's normalisation 2/(W-1)
+        const float du = gix * g.mx * (0.5f * (float)W) * (2.f / (float)(W - 1));
+        const float dv = giy * g.my * (0.5f * (float)H) * (2.f / (float)(H - 1));
+        const float zi = g.pz + 1e-7f;
+        const float dpx = du / zi, dpy = dv / zi;
+        const float dpz = -(du * g.px + dv * g.py) / (zi * zi);
+        const float X = g.depth * g.rx, Y = g.depth * g.ry, Z = g.depth * g.rz;
+        dPl[0] = dpx * X; dPl[1] = dpx * Y; dPl[2] = dpx * Z; dPl[3] = dpx;
+        dPl[4] = dpy * X; dPl[5] = dpy * Y; dPl[6] = dpy * Z; dPl[7] = dpy;
+        dPl[8] = dpz * X; dPl[9] = dpz * Y; dPl[10] = dpz * Z; dPl[11] = dpz;
+        const float dX = Pb[0] * dpx + Pb[4] * dpy + Pb[8] * dpz;
+        const float dY = Pb[1] * dpx + Pb[5] * dpy + Pb[9] * dpz;
+        const float dZ = Pb[2] * dpx + Pb[6] * dpy + Pb[10] * dpz;
+        const float ddepth = dX * g.rx + dY * g.ry + dZ * g.rz;
+        const float dd = -(max_disp - min_disp) * g.depth * g.depth * ddepth;
+        float* q = ddisp_up + (size_t)b * HW + p;
+        *q = accumulate ? *q + dd : dd;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float s = jp_wave_sum(dPl[i]);
+        if (lane == 0) red[i][wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const double s = (double)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&dP[12 * b + threadIdx.x], s);
+    }
+}
+
+// ------------------------------------------------------------------------------ SSIM + L1 forward
+// block = 4 waves; wave w of block (bx, by, b) owns columns [64*(4*bx+w), +64) and rows [ROWS*by, +ROWS)
+constexpr int SSIM_ROWS = 16;
+
+struct RowSums { float x, y, xx, yy, xy; };
+
+__device__ __forceinline__ RowSums ssim_hsum(const float* __restrict__ xr, const float* __restrict__ yr, int x,
+                                             int W, int lane, float& xc, float& yc) {
+    // centre value from this lane, neighbours from the adjacent lanes; strip / image edges reload
+    const int xs = min(x, W - 1);
+    xc = xr[xs];
+    yc = yr[xs];
+    float xl = __shfl_up(xc, 1, 64), yl = __shfl_up(yc, 1, 64);
+    float xrn = __shfl_down(xc, 1, 64), yrn = __shfl_down(yc, 1, 64);
+    if (lane == 0 || x == 0) {
+        const int j = jp_reflect(x - 1, W);
+        xl = xr[min(j, W - 1)]; yl = yr[min(j, W - 1)];
+    }
+    if (lane == 63 || x >= W - 1) {
+        const int j = jp_reflect(min(x, W - 1) + 1, W);
+        xrn = xr[j]; yrn = yr[j];
+    }
+    RowSums s;
+    s.x = xl + xc + xrn;
+    s.y = yl + yc + yrn;
+    s.xx = xl * xl + xc * xc + xrn * xrn;
+    s.yy = yl * yl + yc * yc + yrn * yrn;
+    s.xy = xl * yl + xc * yc + xrn * yrn;
+    return s;
+}
+
+__global__ __launch_bounds__(TPB) void ssim_l1_fwd_kernel(const float* __restrict__ pred,
+                                                          const float* __restrict__ target,
+                                                          float* __restrict__ out, int H, int W) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = (blockIdx.x * 4 + wv) * 64 + lane;
+    if ((blockIdx.x * 4 + wv) * 64 >= W) return;   // whole wave out of range (wave-uniform)
+    const int b = blockIdx.z;
+    const int ybeg = blockIdx.y * SSIM_ROWS, yend = min(H, ybeg + SSIM_ROWS);
+    const size_t HW = (size_t)H * W;
+    float accS[SSIM_ROWS], accL[SSIM_ROWS];
+#pragma unroll
+    for (int r = 0; r < SSIM_ROWS; ++r) accS[r] = accL[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* xp = pred + ((size_t)b * 3 + ch) * HW;
+        const float* yp = target + ((size_t)b * 3 + ch) * HW;
+        RowSums r0, r1, r2;
+        float xc, yc, xc1 = 0.f, yc1 = 0.f;
+        {
+            const int ya = jp_reflect(ybeg - 1, H);
+            r0 = ssim_hsum(xp + (size_t)ya * W, yp + (size_t)ya * W, x, W, lane, xc, yc);
+            r1 = ssim_hsum(xp + (size_t)ybeg * W, yp + (size_t)ybeg * W, x, W, lane, xc1, yc1);
+        }
+#pragma unroll
+        for (int r = 0; r < SSIM_ROWS; ++r) {
+            const int y = ybeg + r;
+            if (y < yend) {   // wave-uniform
+                const int yn = jp_reflect(y + 1, H);
+                float xc2, yc2;
+                r2 = ssim_hsum(xp + (size_t)yn * W, yp + (size_t)yn * W, x, W, lane, xc2, yc2);
+                const float k = 1.f / 9.f;
+                const float mx = (r0.x + r1.x + r2.x) * k, my = (r0.y + r1.y + r2.y) * k;
+                const float sx = (r0.xx + r1.xx + r2.xx) * k - mx * mx;
+                const float sy = (r0.yy + r1.yy + r2.yy) * k - my * my;
+                const float sxy = (r0.xy + r1.xy + r2.xy) * k - mx * my;
+                const float n = (2.f * mx * my + SSIM_C1) * (2.f * sxy + SSIM_C2);
+                const float d = (mx * mx + my * my + SSIM_C1) * (sx + sy + SSIM_C2);
+                accS[r] += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
+                const float df = yc1 - xc1;
+                accL[r] += sqrtf(df * df + 1e-6f);
+                r0 = r1; r1 = r2; xc1 = xc2; yc1 = yc2;
+            }
+        }
+    }
+    if (x < W) {
+#pragma unroll
+        for (int r = 0; r < SSIM_ROWS; ++r) {
+            const int y = ybeg + r;
+            if (y < yend) out[(size_t)b * HW + (size_t)y * W + x] = 0.85f * (accS[r] / 3.f) + 0.15f * (accL[r] / 3.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ SSIM + L1 backward
+// dpred = d( sum_q g_q * reproj(q) ) / d pred, g_q = gscale * [min_index(q) == cand] (or 1 if no index).
+// LDS tile: outputs 32 x 16, V-coefficients on (32+2) x (16+2), inputs on (32+4) x (16+4).
+constexpr int BT_W = 32, BT_H = 16;
+
+__global__ __launch_bounds__(TPB) void ssim_l1_bwd_kernel(const float* __restrict__ pred,
+                                                          const float* __restrict__ target,
+                                                          const int64_t* __restrict__ min_index, int cand,
+                                                          const float* __restrict__ gout, float gscale,
+                                                          float* __restrict__ dpred, int H, int W) {
+    __shared__ float xs[BT_H + 4][BT_W + 4];
+    __shared__ float ys[BT_H + 4][BT_W + 4];
+    __shared__ float va[BT_H + 2][BT_W + 2];
+    __shared__ float vb[BT_H + 2][BT_W + 2];
+    __shared__ float vg[BT_H + 2][BT_W + 2];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const size_t HW = (size_t)H * W;
+    const float gs = gscale * (gout ? gout[0] : 1.f);
+    const int64_t* mi = min_index ? min_index + (size_t)b * HW : nullptr;
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* xp = pred + ((size_t)b * 3 + ch) * HW;
+        const float* yp = target + ((size_t)b * 3 + ch) * HW;
+        __syncthreads();
+        for (int i = threadIdx.x; i < (BT_H + 4) * (BT_W + 4); i += TPB) {
+            const int ly = i / (BT_W + 4), lx = i - ly * (BT_W + 4);
+            // padded coordinate (y0-2+ly): clamp far-outside to keep indices legal, then reflect
+            int gy = min(max(y0 - 2 + ly, -1), H), gx = min(max(x0 - 2 + lx, -1), W);
+            gy = jp_reflect(gy, H); gx = jp_reflect(gx, W);
+            xs[ly][lx] = xp[(size_t)gy * W + gx];
+            ys[ly][lx] = yp[(size_t)gy * W + gx];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < (BT_H + 2) * (BT_W + 2); i += TPB) {
+            const int ly = i / (BT_W + 2), lx = i - ly * (BT_W + 2);
+            const int qy = y0 - 1 + ly, qx = x0 - 1 + lx;
+            float A = 0.f, Bc = 0.f, Gc = 0.f;
+            if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+                float g = gs;
+                if (mi) g = (mi[(size_t)qy * W + qx] == cand) ? gs : 0.f;
+                if (g != 0.f) {
+                    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const float xv = xs[ly + dy][lx + dx], yv = ys[ly + dy][lx + dx];
+                            sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                        }
+                    const float k = 1.f / 9.f;
+                    const float mx = sx * k, my = sy * k;
+                    const float vx = sxx * k - mx * mx, vy = syy * k - my * my, cxy = sxy * k - mx * my;
+                    const float n1 = 2.f * mx * my + SSIM_C1, n2 = 2.f * cxy + SSIM_C2;
+                    const float d1 = mx * mx + my * my + SSIM_C1, d2 = vx + vy + SSIM_C2;
+                    const float n = n1 * n2, d = d1 * d2;
+                    const float val = (1.f - n / d) * 0.5f;
+                    if (val >= 0.f && val <= 1.f) {
+                        const float k2 = 2.f / 9.f;
+                        Gc = g * k2 * n1 / d;
+                        Bc = -g * k2 * n * d1 / (d * d);
+                        A = g * k2 * (my * (n2 - n1) / d - n * mx * (d2 - d1) / (d * d));
+                    }
+                }
+            }
+            va[ly][lx] = A; vb[ly][lx] = Bc; vg[ly][lx] = Gc;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < BT_H * BT_W; i += TPB) {
+            const int ly = i / BT_W, lx = i - ly * BT_W;
+            const int ry = y0 + ly, rx = x0 + lx;
+            if (ry >= H || rx >= W) continue;
+            float SA = 0.f, SB = 0.f, SG = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int qy = ry + dy;
+                if (qy < 0 || qy >= H) continue;
+                const float wy = 1.f + ((ry == 1 && qy == 0) ? 1.f : 0.f) + ((ry == H - 2 && qy == H - 1) ? 1.f : 0.f);
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int qx = rx + dx;
+                    if (qx < 0 || qx >= W) continue;
+                    const float w = wy * (1.f + ((rx == 1 && qx == 0) ? 1.f : 0.f) +
+                                          ((rx == W - 2 && qx == W - 1) ? 1.f : 0.f));
+                    SA += w * va[ly + 1 + dy][lx + 1 + dx];
+                    SB += w * vb[ly + 1 + dy][lx + 1 + dx];
+                    SG += w * vg[ly + 1 + dy][lx + 1 + dx];
+                }
+            }
+            const float xr = xs[ly + 2][lx + 2], yr = ys[ly + 2][lx + 2];
+            float g = gs;
+            if (mi) g = (mi[(size_t)ry * W + rx] == cand) ? gs : 0.f;
+            const float df = xr - yr;
+            const float l1 = g * df / sqrtf(df * df + 1e-6f);
+            dpred[((size_t)b * 3 + ch) * HW + (size_t)ry * W + rx] =
+                -0.5f * (0.85f / 3.f) * (SA + xr * SB + yr * SG) + (0.15f / 3.f) * l1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ min-reprojection
+// cands c0..c3 (B,1,H,W) (null when absent); noise n0,n1 scaled by 1e-5 is added to c0,c1 (the identity
+// candidates, net.py:163).  Writes argmin (int64, reference dtype) and accumulates sum(min) as double.
+__global__ __launch_bounds__(TPB) void minreproj_kernel(const float* __restrict__ c0, const float* __restrict__ c1,
+                                                        const float* __restrict__ c2, const float* __restrict__ c3,
+                                                        const float* __restrict__ n0, const float* __restrict__ n1,
+                                                        int64_t* __restrict__ idx, double* __restrict__ acc,
+                                                        long total) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        float best = c0[i] + (n0 ? n0[i] * 1e-5f : 0.f);
+        int bi = 0;
+        if (c1) { const float v = c1[i] + (n1 ? n1[i] * 1e-5f : 0.f); if (v < best) { best = v; bi = 1; } }
+        if (c2) { const float v = c2[i]; if (v < best) { best = v; bi = 2; } }
+        if (c3) { const float v = c3[i]; if (v < best) { best = v; bi = 3; } }
+        idx[i] = bi;
+        s += (double)best;
+    }
+    s = jp_block_sum_d(s, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+
+__global__ void scalar_finalize_kernel(const double* __restrict__ in, float* __restrict__ out, int n,
+                                       double scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)(in[i] * scale);
+}
+
+}  // namespace
+
+#define JP_ST hipStream_t st = (hipStream_t)stream
+
+extern "C" int jp_pose_fwd(const float* axisangle, const float* translation, const float* K, float* T, float* P,
+                           int B, int invert, void* stream) {
+    JP_CHECK_ARG(axisangle && translation && K && T && P && B > 0, "pose_fwd: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(jp_cdiv(B, 64)), dim3(64), 0, st, axisangle, translation, K, T, P, B, invert);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_pose_bwd(const double* dP, const float* axisangle, const float* translation, const float* K,
+                           float* daxisangle, float* dtranslation, int B, int invert, int accumulate, void* stream) {
+    JP_CHECK_ARG(dP && axisangle && translation && K && daxisangle && dtranslation && B > 0, "pose_bwd: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(jp_cdiv(B, 64)), dim3(64), 0, st, dP, axisangle, translation, K,
+                       daxisangle, dtranslation, B, invert, accumulate);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_cgt_warp_fwd(const float* disp, int hs, int ws, const float* invK, const float* P,
+                               const float* color, float* pred, int B, int H, int W, float min_depth,
+                               float max_depth, void* stream) {
+    JP_CHECK_ARG(disp && invK && P && color && pred && B > 0 && H > 1 && W > 1, "cgt_warp_fwd: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(cgt_warp_fwd_kernel, dim3(jp_cdiv((long)H * W, TPB), B), dim3(TPB), 0, st, disp, hs, ws, invK, P,
+                       color, pred, H, W, 1.f / max_depth, 1.f / min_depth);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_cgt_warp_bwd(const float* dpred, const float* disp, int hs, int ws, const float* invK,
+                               const float* P, const float* color, float* ddisp_up, double* dP, int B, int H, int W,
+                               float min_depth, float max_depth, int accumulate, void* stream) {
+    JP_CHECK_ARG(dpred && disp && invK && P && color && ddisp_up && dP && B > 0, "cgt_warp_bwd: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv((long)H * W, TPB), B), dim3(TPB), 0, st, dpred, disp, hs, ws,
+                       invK, P, color, ddisp_up, dP, H, W, 1.f / max_depth, 1.f / min_depth, accumulate);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_ssim_l1_fwd(const float* pred, const float* target, float* out, int B, int H, int W,
+                              void* stream) {
+    JP_CHECK_ARG(pred && target && out && B > 0 && H >= 2 && W >= 2, "ssim_l1_fwd: bad args");
+    JP_ST;
+    dim3 grid(jp_cdiv(W, 256), jp_cdiv(H, SSIM_ROWS), B);
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, grid, dim3(TPB), 0, st, pred, target, out, H, W);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_ssim_l1_bwd(const float* pred, const float* target, const int64_t* min_index, int cand,
+                              const float* gout, float gscale, float* dpred, int B, int H, int W, void* stream) {
+    JP_CHECK_ARG(pred && target && dpred && B > 0 && H >= 2 && W >= 2, "ssim_l1_bwd: bad args");
+    JP_ST;
+    dim3 grid(jp_cdiv(W, BT_W), jp_cdiv(H, BT_H), B);
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, grid, dim3(TPB), 0, st, pred, target, min_index, cand, gout, gscale, dpred,
+                       H, W);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_minreproj_fwd(const float* c0, const float* c1, const float* c2, const float* c3,
+                                const float* noise0, const float* noise1, int64_t* min_index, double* acc,
+                                long total, void* stream) {
+    JP_CHECK_ARG(c0 && min_index && acc && total > 0, "minreproj_fwd: bad args");
+    JP_ST;
+    JP_HIP(hipMemsetAsync(acc, 0, sizeof(double), st));
+    hipLaunchKernelGGL(minreproj_kernel, dim3((int)std::min<long>((total + TPB - 1) / TPB, 2048)), dim3(TPB), 0, st,
+                       c0, c1, c2, c3, noise0, noise1, min_index, acc, total);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_scalar_finalize(const double* in, float* out, int n, double scale, void* stream) {
+    JP_CHECK_ARG(in && out && n > 0, "scalar_finalize: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(jp_cdiv(n, 64)), dim3(64), 0, st, in, out, n, scale);
+    JP_LAUNCH_CHECK();
+}

@@ -1,0 +1,520 @@
+// HBM-bound streaming kernels of the train step: max-pools (3x3 s2 p1 resnet.py:94, 5x5 s1 p2
+// layers.py:191, 2x2 layout_model.py:84), nearest 2x upsample (layers.py:110), channel concat /
+// split, dropout-mask multiply (depth_decoder.py:52-53), activation backward, adds, bilinear and
+// area resizes (net.py:632,692,762).  NCHW fp32; one thread per output element, lanes along W so
+// every wave touches contiguous 256-B segments.
+#include "jp_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int TPB = 256;
+inline int blocks_for(long n) { return (int)std::min<long>((n + TPB - 1) / TPB, 1 << 20); }
+
+// ------------------------------------------------------------------ max pool
+// idx stores the window-relative argmax (ky*k+kx) of the first maximum in scan order
+// (PyTorch: `val > max || isnan(val)` -> first max wins), so backward is a gather without atomics.
+__global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, long total, int H, int W,
+                                                          int OH, int OW, int k, int s, int p) {
+    for (long o = (long)blockIdx.x * TPB + threadIdx.x; o < total; o += (long)gridDim.x * TPB) {
+        const int ox = (int)(o % OW);
+        const long t = o / OW;
+        const int oy = (int)(t % OH);
+        const long nc = t / OH;
+        const float* xp = x + nc * H * W;
+        float best = -INFINITY;
+        int bi = 0;
+        bool found = false;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * s - p + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * s - p + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float v = xp[iy * W + ix];
+                if (!found || v > best || v != v) { best = v; bi = ky * k + kx; found = true; }
+            }
+        }
+        y[o] = best;
+        idx[o] = (uint8_t)bi;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                          long total, int H, int W, int OH, int OW, int k, int s,
+                                                          int p) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int ix = (int)(i % W);
+        const long t = i / W;
+        const int iy = (int)(t % H);
+        const long nc = t / H;
+        const float* dp = dy + nc * OH * OW;
+        const uint8_t* ip = idx + nc * OH * OW;
+        float g = 0.f;
+        // outputs oy with oy*s - p <= iy <= oy*s - p + k - 1
+        int oy_lo = (iy + p - k + 1 + s - 1);
+        oy_lo = oy_lo <= 0 ? 0 : oy_lo / s;
+        const int oy_hi = min(OH - 1, (iy + p) / s);
+        int ox_lo = (ix + p - k + 1 + s - 1);
+        ox_lo = ox_lo <= 0 ? 0 : ox_lo / s;
+        const int ox_hi = min(OW - 1, (ix + p) / s);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const int ky = iy - (oy * s - p);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const int kx = ix - (ox * s - p);
+                if (ip[oy * OW + ox] == ky * k + kx) g += dp[oy * OW + ox];
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+// ------------------------------------------------------------------ nearest 2x upsample
+__global__ __launch_bounds__(TPB) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             long total, int H, int W) {
+    const int OW = 2 * W, OH = 2 * H;
+    for (long o = (long)blockIdx.x * TPB + threadIdx.x; o < total; o += (long)gridDim.x * TPB) {
+        const int ox = (int)(o % OW);
+        const long t = o / OW;
+        const int oy = (int)(t % OH);
+        const long nc = t / OH;
+        y[o] = x[(nc * H + (oy >> 1)) * W + (ox >> 1)];
+    }
+}
+
+// dx[nc][y][x] = sum of the 2x2 block of dy; dy may be a channel slice of a wider tensor:
+// element (n, c, y, x) lives at dy[((n*Ctot + c0 + c)*OH + y)*OW + x]
+__global__ __launch_bounds__(TPB) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                             long total, int C, int H, int W, int Ctot, int c0,
+                                                             int accumulate) {
+    const int OW = 2 * W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long nc = t / H;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        const float* d = dy + ((n * Ctot + c0 + c) * (2L * H) + 2 * y) * OW + 2 * x;
+        const float g = d[0] + d[1] + d[OW] + d[OW + 1];
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// ------------------------------------------------------------------ channel slice copy
+// dst[n][dc0 + c][hw] = src[n][sc0 + c][hw]  for c < C  (concat and split are both this)
+__global__ __launch_bounds__(TPB) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            long total, int C, int HW, int srcC, int sc0, int dstC,
+                                                            int dc0, int accumulate) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int p = (int)(i % HW);
+        const long t = i / HW;
+        const int c = (int)(t % C);
+        const long n = t / C;
+        const float v = src[(n * srcC + sc0 + c) * HW + p];
+        float* q = dst + (n * dstC + dc0 + c) * HW + p;
+        *q = accumulate ? *q + v : v;
+    }
+}
+
+// ------------------------------------------------------------------ elementwise
+// out = alpha * a (*|+) b ...
+__global__ __launch_bounds__(TPB) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ out, long n, float alpha, float beta) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
+        out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+__global__ __launch_bounds__(TPB) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n, float scale) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
+        out[i] = a[i] * b[i] * scale;
+}
+
+__global__ __launch_bounds__(TPB) void affine_kernel(const float* __restrict__ a, float* __restrict__ out, long n,
+                                                     float scale, float shift) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
+        out[i] = a[i] * scale + shift;
+}
+
+__global__ __launch_bounds__(TPB) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                      int act) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
+        y[i] = jp_act(x[i], act);
+}
+
+// dx = dy * act'(.) expressed through the activation OUTPUT y (valid for relu / leaky / sigmoid)
+__global__ __launch_bounds__(TPB) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dx, long n, int act) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const float v = y[i];
+        float d = dy[i];
+        if (act == JP_ACT_RELU) d = v > 0.f ? d : 0.f;
+        else if (act == JP_ACT_LEAKY) d = v > 0.f ? d : 0.01f * d;
+        else if (act == JP_ACT_SIGMOID) d = d * v * (1.f - v);
+        dx[i] = d;
+    }
+}
+
+// out[n][c][hw] = a[n][c][hw] * s[n][0][hw]   (CrossViewTransformer.py:68) and its two adjoints
+__global__ __launch_bounds__(TPB) void mul_bcast_c_kernel(const float* __restrict__ a, const float* __restrict__ s,
+                                                          float* __restrict__ out, long total, int C, int HW) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int p = (int)(i % HW);
+        const long n = i / ((long)C * HW);
+        out[i] = a[i] * s[n * HW + p];
+    }
+}
+__global__ __launch_bounds__(TPB) void mul_bcast_c_bwd_s_kernel(const float* __restrict__ dout,
+                                                                const float* __restrict__ a, float* __restrict__ ds,
+                                                                long total, int C, int HW) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int p = (int)(i % HW);
+        const long n = i / HW;
+        float g = 0.f;
+        for (int c = 0; c < C; ++c) g += dout[(n * C + c) * HW + p] * a[(n * C + c) * HW + p];
+        ds[i] = g;
+    }
+}
+
+// ------------------------------------------------------------------ bilinear resize, align_corners=False
+__device__ __forceinline__ void bil_src(int o, float scale, int in, int& i0, int& i1, float& w1) {
+    float src = ((float)o + 0.5f) * scale - 0.5f;   // PyTorch area_pixel_compute_source_index
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(TPB) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long total, int H, int W, int OH, int OW, float sy,
+                                                           float sx) {
+    for (long o = (long)blockIdx.x * TPB + threadIdx.x; o < total; o += (long)gridDim.x * TPB) {
+        const int ox = (int)(o % OW);
+        const long t = o / OW;
+        const int oy = (int)(t % OH);
+        const long nc = t / OH;
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bil_src(oy, sy, H, y0, y1, wy);
+        bil_src(ox, sx, W, x0, x1, wx);
+        const float* xp = x + nc * H * W;
+        const float a = xp[y0 * W + x0], b = xp[y0 * W + x1], c = xp[y1 * W + x0], d = xp[y1 * W + x1];
+        y[o] = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
+    }
+}
+
+// gather-form adjoint: input pixel i collects from every output whose 2x2 footprint touches it
+__global__ __launch_bounds__(TPB) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                           long total, int H, int W, int OH, int OW, float sy,
+                                                           float sx, int accumulate) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int ix = (int)(i % W);
+        const long t = i / W;
+        const int iy = (int)(t % H);
+        const long nc = t / H;
+        const float* dp = dy + nc * OH * OW;
+        // outputs o with source coordinate in (i-1, i+1): o in ((i-0.5)/s-0.5, (i+1.5)/s-0.5), widened by 1
+        int oy_lo = max(0, (int)floorf(((float)iy - 0.5f) / sy - 0.5f) - 1);
+        int oy_hi = min(OH - 1, (int)ceilf(((float)iy + 1.5f) / sy - 0.5f) + 1);
+        int ox_lo = max(0, (int)floorf(((float)ix - 0.5f) / sx - 0.5f) - 1);
+        int ox_hi = min(OW - 1, (int)ceilf(((float)ix + 1.5f) / sx - 0.5f) + 1);
+        if (iy == 0) oy_lo = 0;           // clamped sources (src < 0) all land on row/col 0
+        if (ix == 0) ox_lo = 0;
+        if (iy == H - 1) oy_hi = OH - 1;  // and sources beyond the last row on row H-1
+        if (ix == W - 1) ox_hi = OW - 1;
+        float g = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1;
+            float wy;
+            bil_src(oy, sy, H, y0, y1, wy);
+            float cy = 0.f;
+            if (y0 == iy) cy += 1.f - wy;
+            if (y1 == iy) cy += wy;
+            if (cy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1;
+                float wx;
+                bil_src(ox, sx, W, x0, x1, wx);
+                float cx = 0.f;
+                if (x0 == ix) cx += 1.f - wx;
+                if (x1 == ix) cx += wx;
+                if (cx != 0.f) g += cy * cx * dp[oy * OW + ox];
+            }
+        }
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// F.interpolate(mode='area') with an integer factor f = H/OH = W/OW: mean of f x f blocks
+__global__ __launch_bounds__(TPB) void area_down_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        long total, int H, int W, int OH, int OW, int f) {
+    const float inv = 1.f / (float)(f * f);
+    for (long o = (long)blockIdx.x * TPB + threadIdx.x; o < total; o += (long)gridDim.x * TPB) {
+        const int ox = (int)(o % OW);
+        const long t = o / OW;
+        const int oy = (int)(t % OH);
+        const long nc = t / OH;
+        const float* xp = x + (nc * H + (long)oy * f) * W + (long)ox * f;
+        float s = 0.f;
+        for (int a = 0; a < f; ++a)
+            for (int b = 0; b < f; ++b) s += xp[a * W + b];
+        y[o] = s * inv;
+    }
+}
+
+// torchgeometry-style warp_perspective (net.py:285-289,468-472): for every destination pixel, its
+// normalised coordinate (linspace(-1,1)) is mapped by the 3x3 `src_norm_from_dst_norm` homography and the
+// source is sampled bilinearly with zero padding (grid_sample, align_corners=False).  C == 1.
+__global__ __launch_bounds__(TPB) void warp_perspective_kernel(const float* __restrict__ src,
+                                                               const float* __restrict__ Hm, float* __restrict__ dst,
+                                                               int h, int w, int OH, int OW) {
+    const int b = blockIdx.y;
+    const float* M = Hm + 9 * b;
+    const float* sp = src + (size_t)b * h * w;
+    for (int p = blockIdx.x * TPB + threadIdx.x; p < OH * OW; p += gridDim.x * TPB) {
+        const int oy = p / OW, ox = p - oy * OW;
+        const float gx = OW > 1 ? -1.f + 2.f * (float)ox / (float)(OW - 1) : -1.f;
+        const float gy = OH > 1 ? -1.f + 2.f * (float)oy / (float)(OH - 1) : -1.f;
+        const float X = M[0] * gx + M[1] * gy + M[2];
+        const float Y = M[3] * gx + M[4] * gy + M[5];
+        const float Z = M[6] * gx + M[7] * gy + M[8];
+        const float sx = X / Z, sy = Y / Z;
+        const float ix = ((sx + 1.f) * (float)w - 1.f) * 0.5f, iy = ((sy + 1.f) * (float)h - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float tx = ix - fx, ty = iy - fy;
+        float v = 0.f;
+        if (ix == ix && iy == iy && fx > -2.f && fy > -2.f && fx < (float)w + 1.f && fy < (float)h + 1.f) {
+            const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w;
+            const bool ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
+            if (ya && xa) v += sp[y0 * w + x0] * (1.f - tx) * (1.f - ty);
+            if (ya && xb) v += sp[y0 * w + x0 + 1] * tx * (1.f - ty);
+            if (yb && xa) v += sp[(y0 + 1) * w + x0] * (1.f - tx) * ty;
+            if (yb && xb) v += sp[(y0 + 1) * w + x0 + 1] * tx * ty;
+        }
+        dst[(size_t)b * OH * OW + p] = v;
+    }
+}
+
+// nn.Softmax2d over C == 2 channels (eval-mode head of the BEV decoder, layout_model.py:194-199)
+__global__ __launch_bounds__(TPB) void softmax_c2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         long total, int HW) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const long n = i / HW;
+        const int p = (int)(i - n * HW);
+        const float a = x[(2 * n) * HW + p], b = x[(2 * n + 1) * HW + p];
+        const float m = fmaxf(a, b);
+        const float ea = __expf(a - m), eb = __expf(b - m);
+        const float inv = 1.f / (ea + eb);
+        y[(2 * n) * HW + p] = ea * inv;
+        y[(2 * n + 1) * HW + p] = eb * inv;
+    }
+}
+
+// depth = 1 / (min_disp + (max_disp - min_disp) * disp)   (layers.py:33-38)
+__global__ __launch_bounds__(TPB) void disp_to_depth_kernel(const float* __restrict__ disp, float* __restrict__ depth,
+                                                            long n, float min_disp, float max_disp) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
+        depth[i] = 1.f / (min_disp + (max_disp - min_disp) * disp[i]);
+}
+
+// CGT scale label assembly (net.py:291-309 static / :474-475 both):
+//   out = zwarp * [laywarp passes]  (* [pixel inside the convex quad q (4 integer corners, any winding)])
+// mode 0: out = zwarp * laywarp (Argo_both); mode 1: laywarp is binarised like `.type_as(uint8)` (== 1)
+// and intersected with the filled quad (cv2.fillConvexPoly, boundary inclusive).
+__global__ __launch_bounds__(TPB) void scale_label_kernel(const float* __restrict__ zw, const float* __restrict__ lw,
+                                                          const int* __restrict__ quad, float* __restrict__ out,
+                                                          long total, int H, int W, int mode) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        float m = lw ? lw[i] : 1.f;
+        if (mode == 1) {
+            m = (lw == nullptr || m >= 0.999999f) ? 1.f : 0.f;
+            const int p = (int)(i % ((long)H * W));
+            const int y = p / W, x = p - y * W;
+            int pos = 0, neg = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ax = quad[2 * k], ay = quad[2 * k + 1];
+                const int bx = quad[2 * ((k + 1) & 3)], by = quad[2 * ((k + 1) & 3) + 1];
+                const long cr = (long)(bx - ax) * (y - ay) - (long)(by - ay) * (x - ax);
+                pos += cr > 0;
+                neg += cr < 0;
+            }
+            if (pos > 0 && neg > 0) m = 0.f;
+        }
+        out[i] = zw[i] * m;
+    }
+}
+
+}  // namespace
+
+#define JP_ST hipStream_t st = (hipStream_t)stream
+
+extern "C" int jp_maxpool_fwd(const float* x, float* y, uint8_t* idx, int NC, int H, int W, int k, int s, int p,
+                              void* stream) {
+    JP_CHECK_ARG(x && y && idx && NC > 0 && k >= 1 && k <= 15, "maxpool_fwd: bad args");
+    JP_ST;
+    const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    const long total = (long)NC * OH * OW;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, idx, total, H, W, OH, OW,
+                       k, s, p);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int NC, int H, int W, int k, int s,
+                              int p, void* stream) {
+    JP_CHECK_ARG(dy && dx && idx && NC > 0, "maxpool_bwd: bad args");
+    JP_ST;
+    const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    const long total = (long)NC * H * W;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, dy, idx, dx, total, H, W, OH,
+                       OW, k, s, p);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
+    JP_CHECK_ARG(x && y && NC > 0, "upsample2x_fwd: bad args");
+    JP_ST;
+    const long total = (long)NC * H * W * 4;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, H, W);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_upsample2x_bwd(const float* dy, float* dx, int N, int C, int H, int W, int Ctot, int c0,
+                                 int accumulate, void* stream) {
+    JP_CHECK_ARG(dy && dx && N > 0 && C > 0 && c0 + C <= Ctot, "upsample2x_bwd: bad args");
+    JP_ST;
+    const long total = (long)N * C * H * W;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, dy, dx, total, C, H, W, Ctot,
+                       c0, accumulate);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_copy_channels(const float* src, float* dst, int N, int C, int HW, int srcC, int sc0, int dstC,
+                                int dc0, int accumulate, void* stream) {
+    JP_CHECK_ARG(src && dst && N > 0 && C > 0 && sc0 + C <= srcC && dc0 + C <= dstC, "copy_channels: bad args");
+    JP_ST;
+    const long total = (long)N * C * HW;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, src, dst, total, C, HW, srcC,
+                       sc0, dstC, dc0, accumulate);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream) {
+    JP_CHECK_ARG(a && out && n > 0, "axpby: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, a, b, out, n, alpha, beta);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_mul(const float* a, const float* b, float* out, long n, float scale, void* stream) {
+    JP_CHECK_ARG(a && b && out && n > 0, "mul: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, a, b, out, n, scale);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_affine(const float* a, float* out, long n, float scale, float shift, void* stream) {
+    JP_CHECK_ARG(a && out && n > 0, "affine: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(affine_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, a, out, n, scale, shift);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_act_fwd(const float* x, float* y, long n, int act, void* stream) {
+    JP_CHECK_ARG(x && y && n > 0, "act_fwd: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, x, y, n, act);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, int act, void* stream) {
+    JP_CHECK_ARG(dy && y && dx && n > 0, "act_bwd: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, dy, y, dx, n, act);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_mul_bcast_c(const float* a, const float* s, float* out, int N, int C, int HW, void* stream) {
+    JP_CHECK_ARG(a && s && out && N > 0, "mul_bcast_c: bad args");
+    JP_ST;
+    const long total = (long)N * C * HW;
+    hipLaunchKernelGGL(mul_bcast_c_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, a, s, out, total, C, HW);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_mul_bcast_c_bwd_s(const float* dout, const float* a, float* ds, int N, int C, int HW,
+                                    void* stream) {
+    JP_CHECK_ARG(dout && a && ds && N > 0, "mul_bcast_c_bwd_s: bad args");
+    JP_ST;
+    const long total = (long)N * HW;
+    hipLaunchKernelGGL(mul_bcast_c_bwd_s_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, dout, a, ds, total, C, HW);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_bilinear_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream) {
+    JP_CHECK_ARG(x && y && NC > 0 && OH > 0 && OW > 0, "bilinear_fwd: bad args");
+    JP_ST;
+    const long total = (long)NC * OH * OW;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, H, W, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_bilinear_bwd(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, int accumulate,
+                               void* stream) {
+    JP_CHECK_ARG(dy && dx && NC > 0, "bilinear_bwd: bad args");
+    JP_ST;
+    const long total = (long)NC * H * W;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, dy, dx, total, H, W, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW, accumulate);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_area_downsample(const float* x, float* y, int NC, int H, int W, int f, void* stream) {
+    JP_CHECK_ARG(x && y && NC > 0 && f >= 1 && H % f == 0 && W % f == 0, "area_downsample: bad args");
+    JP_ST;
+    const long total = (long)NC * (H / f) * (W / f);
+    hipLaunchKernelGGL(area_down_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, H, W, H / f, W / f, f);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_warp_perspective(const float* src, const float* Hm, float* dst, int B, int h, int w, int OH, int OW,
+                                   void* stream) {
+    JP_CHECK_ARG(src && Hm && dst && B > 0, "warp_perspective: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(warp_perspective_kernel, dim3(std::min(jp_cdiv((long)OH * OW, TPB), 4096), B), dim3(TPB), 0, st,
+                       src, Hm, dst, h, w, OH, OW);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_softmax_c2(const float* x, float* y, int N, int HW, void* stream) {
+    JP_CHECK_ARG(x && y && N > 0 && HW > 0, "softmax_c2: bad args");
+    JP_ST;
+    const long total = (long)N * HW;
+    hipLaunchKernelGGL(softmax_c2_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, HW);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_disp_to_depth(const float* disp, float* depth, long n, float min_depth, float max_depth,
+                                void* stream) {
+    JP_CHECK_ARG(disp && depth && n > 0, "disp_to_depth: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(disp_to_depth_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, disp, depth, n, 1.f / max_depth,
+                       1.f / min_depth);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_scale_label_assemble(const float* zwarp, const float* laywarp, const int* quad, float* out, int B,
+                                       int H, int W, int mode, void* stream) {
+    JP_CHECK_ARG(zwarp && out && B > 0 && (mode == 0 || quad), "scale_label_assemble: bad args");
+    JP_ST;
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(scale_label_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, zwarp, laywarp, quad, out, total,
+                       H, W, mode);
+    JP_LAUNCH_CHECK();
+}

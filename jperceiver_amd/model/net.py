@@ -1,0 +1,391 @@
+"""`Baseline` — MI355X-native mirror of mono/model/mono_baseline/net.py:32-786.
+
+Same constructor (`options` with attribute *and* item access), same sub-module attribute names
+(= state-dict prefixes), `forward(inputs) -> (outputs, loss_dict)` in training / `outputs` in eval,
+same `outputs` / `loss_dict` keys.  Differences that are deliberate (SURVEY.md §8 notes):
+  * N2: layout losses are type-conditional as in the repository-root net.py:125-159
+        (static -> S head only, dynamic -> B head only, Argo_both -> both);
+        loss_weightS / loss2_weightS default to loss_weight / loss2_weight.
+  * N4: the layout branch is evaluated once; its BatchNorm running statistics receive the
+        reference's double momentum update analytically (n_updates=2).
+  * N5: dropout masks / automask noise may be supplied as inputs (("dropout_mask", i),
+        ("automask_noise", scale, j)) for bit-reproducible parity tests; otherwise the device RNG.
+  * the whole step (forward and backward) runs hand-written HIP kernels recorded on an own tape;
+    torch.autograd only sees one node that hands the per-loss upstream gradients to that tape.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops, ops_loss
+from .._lib import call
+from ..ops import Var, Tape, recording
+from .registry import MONO
+from .modules import (DepthEncoder, DepthDecoder, PoseEncoder, PoseDecoder, Encoder, Decoder, CycledViewProjection,
+                      CrossViewTransformer, SSIM, Backproject, Project)
+
+_STATIC_TYPES = ("static_raw", "static", "Argo_static", "Argo_both", "static_eigen")
+_DYNAMIC_TYPES = ("dynamic", "Argo_dynamic", "Argo_both")
+
+
+class _Opt(dict):
+    __getattr__ = dict.__getitem__
+
+
+class LossDict(dict):
+    """loss_dict with a fast path for batch_processor: `.total()` sums every entry with one kernel and is
+    wired to the tape with all-ones upstream gradients (trainer.py:35-46 semantics)."""
+
+    def __init__(self, items, lv, node):
+        super().__init__(items)
+        self._lv, self._node = lv, node
+
+    def total(self):
+        return _TotalFn.apply(self._node)
+
+
+class _StepFn(torch.autograd.Function):
+    """The single autograd node of a train step: forward hands out the loss vector, backward copies the
+    per-loss upstream gradients to the device-side `grads` vector and replays the tape in reverse."""
+
+    @staticmethod
+    def forward(ctx, hook, tape, lv):
+        ctx.tape, ctx.lv = tape, lv
+        return lv.vals.view(-1)
+
+    @staticmethod
+    def backward(ctx, dvec):
+        dvec = dvec.contiguous()
+        call("jp_axpby", dvec, None, ctx.lv.grads, dvec.numel(), 1.0, 0.0)
+        ctx.tape.backward()
+        return None, None, None
+
+
+class _TotalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss_vec):
+        tot = torch.empty((), device=loss_vec.device, dtype=loss_vec.dtype)
+        call("jp_colsum", loss_vec, tot, loss_vec.numel(), 1, 0)
+        ctx.n = loss_vec.numel()
+        return tot
+
+    @staticmethod
+    def backward(ctx, g):
+        res = torch.empty(ctx.n, device=g.device, dtype=g.dtype)
+        _broadcast_scalar(g.reshape(1).contiguous(), res)     # d total / d loss_i = 1, times the upstream scalar
+        return res
+
+
+def _broadcast_scalar(s, out):
+    """out[i] = s[0] (device scalar broadcast without a host sync): out = 0; out += bias(s) per row."""
+    call("jp_fill", out, out.numel(), 0.0)
+    call("jp_bias_act_rows", out, s, out.numel(), 1, 0)
+
+
+@MONO.register_module
+class Baseline(nn.Module):
+    def __init__(self, options):
+        super().__init__()
+        self.opt = options if hasattr(options, "keys") and hasattr(options, "frame_ids") else _Opt(options)
+        o = self.opt
+        self.num_input_frames = len(o.frame_ids)
+        self.DepthEncoder = DepthEncoder(o.depth_num_layers, o.get("depth_pretrained_path"))
+        self.DepthDecoder = DepthDecoder(self.DepthEncoder.num_ch_enc)
+        self.PoseEncoder = PoseEncoder(o.pose_num_layers, o.get("pose_pretrained_path"), num_input_images=2)
+        self.PoseDecoder = PoseDecoder(self.PoseEncoder.num_ch_enc)
+        self.LayoutEncoder = Encoder(o.depth_num_layers, True)
+        self.CycledViewProjection = CycledViewProjection(in_dim=o.occ_map_size // 32)
+        self.CrossViewTransformer = CrossViewTransformer(128)
+        nce = self.LayoutEncoder.resnet_encoder.num_ch_enc
+        self.LayoutDecoder = Decoder(nce, o.num_class)
+        self.LayoutTransformDecoder = Decoder(nce, o.num_class, "transform_decoder")
+        self.CycledViewProjectionB = CycledViewProjection(in_dim=o.occ_map_size // 32)
+        self.CrossViewTransformerB = CrossViewTransformer(128)
+        self.LayoutDecoderB = Decoder(nce, o.num_class)
+        self.LayoutTransformDecoderB = Decoder(nce, o.num_class, "transform_decoder")
+        self.ssim = SSIM()
+        self.backproject = Backproject(o.imgs_per_gpu, o.height, o.width)
+        self.project_3d = Project(o.imgs_per_gpu, o.height, o.width)
+        self.weight = {"static": o.static_weight, "dynamic": o.dynamic_weight}
+        self._hook = None
+
+    # ------------------------------------------------------------------ forward (net.py:68-82)
+    def forward(self, inputs):
+        dev = inputs[("color_aug", 0, 0)].device
+        if dev.type != "cuda":
+            raise RuntimeError("Baseline runs on the GPU only: its kernels are HIP (no CPU fallback in the product path)")
+        inputs = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in inputs.items()}
+        if not self.training:
+            return self._forward_eval(inputs)
+        tape = Tape()
+        with recording(tape):
+            outputs, lv = self._forward_train(inputs)
+        if self._hook is None or self._hook.device != dev:
+            self._hook = torch.zeros(1, device=dev, requires_grad=True)
+        vec = _StepFn.apply(self._hook, tape, lv)
+        return outputs, LossDict({n: vec[i] for i, n in enumerate(lv.names)}, lv, vec)
+
+    def _layout_head(self, sfx, F, f4, n_updates):
+        cvp = getattr(self, "CycledViewProjection" + sfx)
+        cct = getattr(self, "CrossViewTransformer" + sfx)
+        t, r = cvp._fwd(F)
+        feats, S, attn, arg = cct._fwd(F, t, r, f4)
+        top = getattr(self, "LayoutDecoder" + sfx)._fwd(feats, n_updates)
+        ttop = getattr(self, "LayoutTransformDecoder" + sfx)._fwd(t, n_updates)
+        return dict(t=t, r=r, feats=feats, S=S, attn=attn, top=top, ttop=ttop)
+
+    def _forward_eval(self, inputs):
+        img = Var(inputs[("color_aug", 0, 0)])
+        feats = self.DepthEncoder._fwd(img)
+        out = {k: v.t for k, v in self.DepthDecoder._fwd(feats).items()}
+        F = self.LayoutEncoder._fwd(img)
+        for sfx, tag in (("", "road"), ("B", "car")):
+            h = self._layout_head(sfx, F, feats[-1], 1)
+            out["topview" + sfx] = ops.softmax2(h["top"].t)
+            out["transform_topview" + sfx] = ops.softmax2(h["ttop"].t)
+            self._publish_head(out, sfx, tag, h)
+        out["origin_features"] = F.t
+        return out
+
+    @staticmethod
+    def _publish_head(out, sfx, tag, h):
+        out["features" + sfx] = h["feats"].t
+        out["features_" + tag] = h["feats"].t
+        out["transform_feature_" + tag] = h["t"].t
+        out["retransform_features" + sfx] = h["r"].t
+        out["retransform_features_" + tag] = h["r"].t
+        out["cv_attn_" + tag] = h["S"].t
+        out["cm_attn_" + tag] = h["attn"].t
+
+    def _forward_train(self, inputs):
+        o = self.opt
+        B = inputs[("color_aug", 0, 0)].shape[0]
+        H, W = o.height, o.width
+        ty = o["type"]
+        do_S, do_B = ty in _STATIC_TYPES, ty in _DYNAMIC_TYPES
+        src_frames = list(o.frame_ids[1:])
+        nS = len(o.scales)
+        names = []
+        if do_S:
+            names += ["topview_loss", "transform_topview_loss", "transform_loss", "layout_loss"]
+        if do_B:
+            names += ["topview_lossB", "transform_topview_lossB", "transform_lossB", "layout_lossB"]
+        for s in o.scales:
+            names += [("min_reconstruct_loss", s), ("scale_loss", s), ("smooth_loss", s)]
+        dev = inputs[("color_aug", 0, 0)].device
+        lv = ops_loss.LossVec(names, dev)
+
+        # ---- networks
+        img = Var(inputs[("color_aug", 0, 0)])
+        feats = self.DepthEncoder._fwd(img)
+        masks = None
+        if ("dropout_mask", 0) in inputs:
+            masks = (inputs[("dropout_mask", 0)], inputs[("dropout_mask", 1)])
+        disp = self.DepthDecoder._fwd(feats, masks)
+        outputs = {k: v.t for k, v in disp.items()}
+        F = self.LayoutEncoder._fwd(img, n_updates=2)                 # net.py:73-74 runs this branch twice (N4)
+        heads = {}
+        # the S head is always evaluated (and BN-updated twice) by the reference; B once
+        for sfx, tag, nup in (("", "road", 2), ("B", "car", 1)):
+            h = self._layout_head(sfx, F, feats[-1], nup)
+            heads[sfx] = h
+            outputs["topview" + sfx] = h["top"].t
+            outputs["transform_topview" + sfx] = h["ttop"].t
+            self._publish_head(outputs, sfx, tag, h)
+        outputs["origin_features"] = F.t
+
+        # ---- poses (net.py:630-642)
+        pf = {f: ops.bilinear_resize(Var(inputs[("color_aug", f, 0)]), 192, 640) for f in o.frame_ids}
+        K, invK = inputs[("K", 0)], inputs[("inv_K", 0)]
+        poses = []
+        for f in src_frames:
+            pair = [pf[f], pf[0]] if f < 0 else [pf[0], pf[f]]
+            pfe = self.PoseEncoder._fwd(ops.cat_channels(pair))
+            at = self.PoseDecoder._fwd(pfe)                            # (B,6)
+            aa, tr = _split6(at)
+            pp = ops_loss.pose(aa, tr, K, invert=(f < 0))
+            poses.append(pp)
+            outputs[("cam_T_cam", 0, f)] = pp.T
+            outputs[("axisangle", 0, f)] = aa.t.view(B, 1, 1, 3)
+            outputs[("translation", 0, f)] = tr.t.view(B, 1, 1, 3)
+
+        # ---- layout losses (net.py:107-138 with root-net.py conditionals)
+        lw = o.get("loss_weightS", o["loss_weight"])
+        l2w = o.get("loss2_weightS", o["loss2_weight"])
+        lsum = o["loss_sum"]
+        use_ce = 0.0 if lsum in (1, 2) else 1.0
+        use_bd = 0.0 if lsum == 1 else 1.0
+        for sfx, lab_key, cw, a, b2, on in (("", ("bothS", 0, 0), o.static_weight, lw, l2w, do_S),
+                                            ("B", ("bothD", 0, 0), o.dynamic_weight, o["loss_weight"], o["loss2_weight"], do_B)):
+            if not on:
+                continue
+            label = inputs[lab_key]
+            sdf = ops_loss.signed_distance(label) if use_bd else None
+            h = heads[sfx]
+            ops_loss.layout_loss(lv, "topview_loss" + sfx, h["top"], label, sdf, 1.0, cw, a, use_ce, b2 * use_bd)
+            ops_loss.layout_loss(lv, "transform_topview_loss" + sfx, h["ttop"], label, sdf, 1.0, cw, a, use_ce, b2 * use_bd)
+            ops_loss.l1_loss(lv, "transform_loss" + sfx, h["feats"], h["r"])
+            ops_loss.combine(lv, "layout_loss" + sfx, [("topview_loss" + sfx, 1.0), ("transform_loss" + sfx, 0.001),
+                                                      ("transform_topview_loss" + sfx, 1.0)])
+
+        # ---- photometric / scale / smoothness per scale (net.py:139-190)
+        scale_label = inputs.get(("scale_label", 0, 0))
+        if scale_label is None:
+            scale_label = self.get_scale_label(inputs)
+        outputs["scale_label"] = scale_label
+        target = inputs[("color", 0, 0)]
+        colors = [inputs[("color", f, 0)] for f in src_frames]
+        id_losses = [ops_loss.ssim_l1(c, target) for c in colors] if o.automask else []
+        crop = (153, 371, 44, 1197) if ty == "static_raw" else None
+        for si, s in enumerate(o.scales):
+            d = disp[("disp", 0, s)]
+            depth = torch.empty_like(d.t)
+            call("jp_disp_to_depth", d.t, depth, depth.numel(), o.min_depth, o.max_depth)
+            outputs[("depth", 0, s)] = depth
+            noises = []
+            if o.automask:
+                for j in range(len(src_frames)):
+                    nz = inputs.get(("automask_noise", si, j))
+                    noises.append(nz if nz is not None else ops.randn((B, 1, H, W), dev))
+            preds, idx = ops_loss.min_reprojection_loss(lv, ("min_reconstruct_loss", s), d, poses, colors, target, invK,
+                                                        id_losses, noises, H, W, o.min_depth, o.max_depth, nS)
+            for f, pr in zip(src_frames, preds):
+                outputs[("color", f, s)] = pr
+            outputs[("min_index", s)] = idx
+            ops_loss.scale_loss(lv, ("scale_loss", s), d, scale_label, o.scale_weight / (2 ** s) / nS, o.min_depth,
+                                o.max_depth, crop)
+            img_ds = ops.area_downsample(target, H // d.t.shape[2])
+            if not o.disp_norm:
+                raise NotImplementedError("disp_norm=False (stereo configs) is outside the north-star path")
+            ops_loss.smooth_loss(lv, ("smooth_loss", s), d, img_ds, o.smoothness_weight / (2 ** s) / nS)
+        return outputs, lv
+
+    # ------------------------------------------------------------------ scale label (net.py:212-476)
+    def get_scale_label(self, inputs):
+        """CGT scale label on the device.  The 3x3 homographies are tiny host-side algebra (float64) taken
+        from ("scale_H",0,0) when batch_processor pre-computed them from the CPU batch, else from the
+        GPU inputs (one small D2H copy).  Third-party semantics (torchgeometry / cv2) are restated:
+        parity unpinned, see SURVEY.md §8c."""
+        o = self.opt
+        ty = o["type"]
+        FH, FW = inputs[("color", 0, -1)].shape[2:4]
+        occ = o.occ_map_size
+        Hm = inputs.get(("scale_H", 0, 0))
+        quad = inputs.get(("scale_quad", 0, 0))
+        if Hm is None:
+            Hm_c, quad_c = scale_label_matrices(o, inputs[("odometry_K", 0, 0)].cpu(), inputs[("Tr_cam2_velo", 0, 0)].cpu(), FH, FW)
+            dev = inputs[("color", 0, 0)].device
+            Hm, quad = Hm_c.to(dev), quad_c.to(dev)
+        B = Hm.shape[0]
+        lay_key = ("both_dynamic", 0, 0) if ty == "Argo_both" else ("bothS", 0, 0)
+        lay = rot270(inputs[lay_key])
+        off = 1.9 if o.split == "argo" else 0.27
+        z = _distance_map(B, occ, off, Hm.device)
+        zw = torch.empty((B, 1, FH, FW), device=Hm.device)
+        lw = torch.empty_like(zw)
+        call("jp_warp_perspective", z, Hm, zw, B, occ, occ, FH, FW)
+        call("jp_warp_perspective", lay, Hm, lw, B, occ, occ, FH, FW)
+        out = torch.empty_like(zw)
+        if ty == "Argo_both":
+            call("jp_scale_label_assemble", zw, lw, None, out, B, FH, FW, 0)
+        elif ty in ("dynamic", "Argo_dynamic"):
+            call("jp_scale_label_assemble", zw, None, quad, out, B, FH, FW, 1)
+        else:
+            call("jp_scale_label_assemble", zw, lw, quad, out, B, FH, FW, 1)
+        return out
+
+
+def _split6(at: Var):
+    """(B,6) -> axisangle (B,3), translation (B,3) Vars with gradients routed back (pose_decoder.py:24-25)."""
+    B = at.t.shape[0]
+    aa = Var(torch.empty((B, 3), device=at.t.device), at.rg)
+    tr = Var(torch.empty((B, 3), device=at.t.device), at.rg)
+    call("jp_copy_channels", at.t, aa.t, B, 3, 1, 6, 0, 3, 0, 0)
+    call("jp_copy_channels", at.t, tr.t, B, 3, 1, 6, 3, 3, 0, 0)
+
+    def bwd():
+        if aa.g is None and tr.g is None:
+            return
+        g, acc = at.grad_buf()
+        if not acc:
+            call("jp_fill", g, g.numel(), 0.0)
+        if aa.g is not None:
+            call("jp_copy_channels", aa.g, g, B, 3, 1, 3, 0, 6, 0, 1)
+        if tr.g is not None:
+            call("jp_copy_channels", tr.g, g, B, 3, 1, 3, 0, 6, 3, 1)
+
+    ops._rec(at.rg, bwd)
+    return aa, tr
+
+
+_ROT_CACHE = {}
+
+
+def rot270(x: torch.Tensor) -> torch.Tensor:
+    """torchvision.transforms.functional.rotate(x, 270) on (B,1,n,n) == rot90(k=3): out[i][j] = x[n-1-j][i].
+    Pure index shuffle of a 256x256 label: done with a cached gather index through jp_gather_cols."""
+    B, C, n, m = x.shape
+    assert C == 1 and n == m
+    key = (n, x.device)
+    if key not in _ROT_CACHE:
+        i = torch.arange(n).view(n, 1).expand(n, n)
+        j = torch.arange(n).view(1, n).expand(n, n)
+        src = ((n - 1 - j) * n + i).reshape(1, -1)
+        _ROT_CACHE[key] = src.to(x.device)
+    idx = _ROT_CACHE[key].expand(B, -1).contiguous()
+    out = torch.empty_like(x)
+    call("jp_gather_cols", x.view(B, 1, n * n), idx, out.view(B, 1, n * n), B, 1, n * n)
+    return out
+
+
+_Z_CACHE = {}
+
+
+def _distance_map(B, occ, off, device):
+    """Forward-distance BEV map z(i) = (occ-i)*40/occ - off, rotated by 270 deg (net.py:230-242)."""
+    key = (B, occ, off, device)
+    if key not in _Z_CACHE:
+        z = (torch.arange(occ, 0, -1, dtype=torch.float32).view(1, 1, occ, 1).repeat(B, 1, 1, occ) * (40.0 / occ) - off)
+        _Z_CACHE[key] = torch.rot90(z, 3, (-2, -1)).contiguous().to(device)
+    return _Z_CACHE[key]
+
+
+def scale_label_matrices(o, odometry_K: torch.Tensor, Tr: torch.Tensor, FH: int, FW: int):
+    """Host-side (CPU, float64) part of get_scale_label_*: returns
+       Hm   (B,3,3) float32: normalised-source-from-normalised-destination homography for jp_warp_perspective
+       quad (4,2)  int32:    the "assumption region" corners in the front view (batch item 0, as the reference)."""
+    occ = o.occ_map_size
+    res = 40.0 / occ
+    K = odometry_K[:, :3, :3].double()
+    B = K.shape[0]
+    Tr = Tr.double()
+    hfg = 0.33 if o.split == "argo" else 1.73
+    ego_from_ground = torch.eye(4, dtype=torch.float64).repeat(B, 1, 1)
+    ego_from_ground[:, 2, 3] = -hfg
+    cg = torch.bmm(Tr, ego_from_ground)
+    img_H_ground = torch.bmm(K, torch.cat([cg[:, :3, 0:1], cg[:, :3, 1:2], cg[:, :3, 3:4]], 2))
+    ground_H_img = torch.linalg.inv(img_H_ground)
+    shift = int(int(40 / res) // 2)
+    sg = torch.tensor([[1 / res, 0, 0], [0, 1 / res, shift], [0, 0, 1.0]], dtype=torch.float64).repeat(B, 1, 1)
+    M = torch.linalg.inv(torch.bmm(sg, ground_H_img))                 # BEV pixel -> image pixel
+
+    def npix(h, w):
+        return torch.tensor([[2.0 / (w - 1), 0, -1], [0, 2.0 / (h - 1), -1], [0, 0, 1.0]], dtype=torch.float64)
+    dst_norm = npix(FH, FW) @ M @ torch.linalg.inv(npix(occ, occ))
+    Hm = torch.linalg.inv(dst_norm).float().contiguous()
+    # assumption-region corners (net.py:235-248,292-299)
+    r1 = occ / 40.0
+    pr = [(round(18 * r1), round(31 * r1)), (round(22 * r1), round(31 * r1)), (round(18 * r1), round(33 * r1)),
+          (round(22 * r1), round(33 * r1))]
+    rot = [[occ - pr[3][1] - 1, pr[0][0] - 1],
+           [occ - pr[3][1] + (pr[2][1] - pr[1][1]) - 1, pr[0][0] - 1],
+           [occ - pr[3][1] - 1, pr[1][0] - 1],
+           [occ - pr[3][1] + (pr[2][1] - pr[1][1]) - 1, pr[1][0] - 1]]
+    pts = torch.tensor(rot, dtype=torch.float64)
+    ph = torch.cat([pts, torch.ones(4, 1, dtype=torch.float64)], 1) @ M[0].T
+    pix = torch.round(ph[:, :2] / ph[:, 2:3])
+    order = [0, 2, 3, 1]                                               # cv2 polygon order used by the reference
+    quad = pix[order].to(torch.int32).contiguous()
+    return Hm, quad

