@@ -447,11 +447,11 @@ class CrossViewTransformer(nn.Module):
         qd = v(conv_apply(self.query_conv_depth, cross_x), (B, C // 8, n))
         kd = v(conv_apply(self.key_conv_depth, front_x), (B, C // 8, n))
         vd = conv_apply(self.value_conv_depth, df)
-        attn, _ = ops_loss.colmax(ops_loss.bmm_tn(kd, qd))
+        attn, arg_d = ops_loss.colmax(ops_loss.bmm_tn(kd, qd))
         attn = v(attn, (B, 1, w, h))
         out = ops.add(out, ops_loss.bcast_matmul(attn, vd))
-        return out, S, attn, arg
+        return out, S, attn, arg, arg_d
 
     def forward(self, front_x, cross_x, front_x_hat, depth_feature):
-        o, S, a, _ = self._fwd(Var(front_x), Var(cross_x), Var(front_x_hat), Var(depth_feature))
+        o, S, a, _, _ = self._fwd(Var(front_x), Var(cross_x), Var(front_x_hat), Var(depth_feature))
         return o.t, S.t, a.t

@@ -131,10 +131,10 @@ class Baseline(nn.Module):
         cvp = getattr(self, "CycledViewProjection" + sfx)
         cct = getattr(self, "CrossViewTransformer" + sfx)
         t, r = cvp._fwd(F)
-        feats, S, attn, arg = cct._fwd(F, t, r, f4)
+        feats, S, attn, arg, arg_d = cct._fwd(F, t, r, f4)
         top = getattr(self, "LayoutDecoder" + sfx)._fwd(feats, n_updates)
         ttop = getattr(self, "LayoutTransformDecoder" + sfx)._fwd(t, n_updates)
-        return dict(t=t, r=r, feats=feats, S=S, attn=attn, top=top, ttop=ttop)
+        return dict(t=t, r=r, feats=feats, S=S, attn=attn, top=top, ttop=ttop, arg=arg, arg_d=arg_d)
 
     def _forward_eval(self, inputs):
         img = Var(inputs[("color_aug", 0, 0)])
@@ -158,6 +158,8 @@ class Baseline(nn.Module):
         out["retransform_features_" + tag] = h["r"].t
         out["cv_attn_" + tag] = h["S"].t
         out["cm_attn_" + tag] = h["attn"].t
+        out["cv_argmax_" + tag] = h["arg"]          # hard arg-max selections (extra keys, for parity tooling)
+        out["cm_argmax_" + tag] = h["arg_d"]
 
     def _forward_train(self, inputs):
         o = self.opt

@@ -331,7 +331,15 @@ def cvp(cx, name, x):
     return t, tm("retransform_module", t)
 
 
-def cct(cx, name, front_x, cross_x, front_x_hat, depth_feature):
+def _max_dim1(e, forced=None):
+    """torch.max(e, dim=1); with `forced` indices the value is gathered instead (tie-tolerant parity:
+    a hard arg-max is discrete, so tests replay the device's selection)."""
+    if forced is None:
+        return torch.max(e, dim=1)
+    return torch.gather(e, 1, forced.unsqueeze(1)).squeeze(1), forced
+
+
+def cct(cx, name, front_x, cross_x, front_x_hat, depth_feature, force=None):
     """CrossViewTransformer.py:45-92."""
     n = name + "."
     df = F.max_pool2d(conv(cx, n + "conv1.conv", depth_feature, refl=True), 2)
@@ -340,7 +348,8 @@ def cct(cx, name, front_x, cross_x, front_x_hat, depth_feature):
     q = conv(cx, n + "query_conv", cross_x).view(B, -1, w * h)
     k = conv(cx, n + "key_conv", front_x).view(B, -1, w * h).permute(0, 2, 1)
     energy = torch.bmm(k, q)
-    front_star, arg = torch.max(energy, dim=1)
+    force = force or {}
+    front_star, arg = _max_dim1(energy, force.get("cv"))
     v = conv(cx, n + "value_conv", front_x_hat).view(B, -1, w * h)
     T = torch.gather(v, 2, arg.view(B, 1, -1).expand(-1, v.shape[1], -1)).view(B, -1, w, h)
     S = front_star.view(B, 1, w, h)
@@ -350,10 +359,10 @@ def cct(cx, name, front_x, cross_x, front_x_hat, depth_feature):
     kd = conv(cx, n + "key_conv_depth", front_x).view(B, -1, w * h).permute(0, 2, 1)
     vd = conv(cx, n + "value_conv_depth", df).view(B, -1, w, h)
     attn = kd @ qd
-    attn, _ = torch.max(attn, dim=1)
+    attn, arg_d = _max_dim1(attn, force.get("cm"))
     attn = attn.view(B, 1, w, h)
     out = out + attn @ vd          # (B,1,w,h)@(B,128,w,h): true matrix product, needs w==h
-    return out, S, attn, arg
+    return out, S, attn, arg, arg_d
 
 
 def bev_decoder(cx, prefix, x):
@@ -370,23 +379,27 @@ def bev_decoder(cx, prefix, x):
     return x
 
 
-def predict_layout(cx, inputs, depth_feature, sfx="", features=None):
+def predict_layout(cx, inputs, depth_feature, sfx="", features=None, force=None):
     """net.py:644-689."""
     o = {}
     if features is None:
         features = layout_encoder(cx, inputs[("color_aug", 0, 0)])
     enc = features
     t, r = cvp(cx, "CycledViewProjection" + sfx, features)
-    feats, S, attn, arg = cct(cx, "CrossViewTransformer" + sfx, features, t, r, depth_feature[-1])
+    tag = "car" if sfx == "B" else "road"
+    fc = None
+    if force is not None and ("cv_argmax_" + tag) in force:
+        fc = {"cv": force["cv_argmax_" + tag], "cm": force["cm_argmax_" + tag]}
+    feats, S, attn, arg, arg_d = cct(cx, "CrossViewTransformer" + sfx, features, t, r, depth_feature[-1], fc)
     o["topview" + sfx] = bev_decoder(cx, f"LayoutDecoder{sfx}.", feats)
     o["transform_topview" + sfx] = bev_decoder(cx, f"LayoutTransformDecoder{sfx}.", t)
     o["features" + sfx] = feats
     o["retransform_features" + sfx] = r
-    tag = "car" if sfx == "B" else "road"
     o["transform_feature_" + tag] = t
     o["cv_attn_" + tag] = S
     o["cm_attn_" + tag] = attn
     o["cv_argmax_" + tag] = arg
+    o["cm_argmax_" + tag] = arg_d
     if sfx == "":
         o["origin_features"] = enc
     return o, enc
@@ -613,7 +626,7 @@ def scale_label_both(opt, inputs):
 # the step
 # ----------------------------------------------------------------------------------
 
-def forward(P, Bf, opt, inputs, training=True, drop_masks=None, automask_noise=None, scale_label=None):
+def forward(P, Bf, opt, inputs, training=True, drop_masks=None, automask_noise=None, scale_label=None, force=None):
     """Baseline.forward + compute_losses (net.py:68-192), type-conditional layout losses
     per the root net.py:125-159.  Layout branch computed once; BN buffers of
     LayoutEncoder / LayoutDecoder / LayoutTransformDecoder get the reference's *double*
@@ -622,19 +635,19 @@ def forward(P, Bf, opt, inputs, training=True, drop_masks=None, automask_noise=N
     cx = Ctx(P, Bf, training)
     feats = resnet18_features(cx, "DepthEncoder.encoder.", inputs[("color_aug", 0, 0)])
     outputs = depth_decoder(cx, feats, drop_masks)
-    o, enc = predict_layout(cx, inputs, feats, "")
+    o, enc = predict_layout(cx, inputs, feats, "", force=force)
     outputs.update(o)
     if training:
         with torch.no_grad():      # net.py:74 duplicate call: only its BN-buffer side effect matters
             predict_layout(cx, inputs, [f.detach() for f in feats], "")
-    outputs.update(predict_layout(cx, inputs, feats, "B", features=enc)[0])
+    outputs.update(predict_layout(cx, inputs, feats, "B", features=enc, force=force)[0])
     if not training:
         return outputs
     outputs.update(predict_poses(cx, opt, inputs))
-    return outputs, compute_losses(opt, inputs, outputs, automask_noise, scale_label)
+    return outputs, compute_losses(opt, inputs, outputs, automask_noise, scale_label, force)
 
 
-def compute_losses(opt, inputs, outputs, automask_noise=None, scale_label=None):
+def compute_losses(opt, inputs, outputs, automask_noise=None, scale_label=None, force=None):
     """net.py:94-192 with root-net.py:125-159 type conditionals."""
     L = {}
     ty = opt["type"]
@@ -667,7 +680,8 @@ def compute_losses(opt, inputs, outputs, automask_noise=None, scale_label=None):
                 cands.append(idl + nz * 1e-5)
         for f in opt.frame_ids[1:]:
             cands.append(reprojection_loss(outputs[("color", f, scale)], target))
-        m, outputs[("min_index", scale)] = torch.min(torch.cat(cands, 1), dim=1)
+        m, outputs[("min_index", scale)] = _max_dim1(-torch.cat(cands, 1), None if force is None else force.get(("min_index", scale)))
+        m = -m
         L[("min_reconstruct_loss", scale)] = m.mean() / nS
         L[("scale_loss", scale)] = opt.scale_weight * scale_loss(opt, depth, scale_label) / (2 ** scale) / nS
         if opt.disp_norm:

@@ -31,7 +31,7 @@ def oracle_opt(meta):
                          loss_weightS=20, loss2_weightS=20)
 
 
-def run_oracle(meta, backward=True):
+def run_oracle(meta, backward=True, force=None):
     from oracle import jp_oracle as J
     opt = oracle_opt(meta)
     shapes = J.state_shapes(meta["occ"])
@@ -40,7 +40,7 @@ def run_oracle(meta, backward=True):
     state = syn.synth_state_dict(tmpl, seed=0)
     P, Bf = J.make_params(shapes, state)
     inp, masks, noise = case_inputs(meta)
-    out, L = J.forward(P, Bf, opt, inp, True, masks, noise)
+    out, L = J.forward(P, Bf, opt, inp, True, masks, noise, force=force)
     total = J.total_loss(L)
     if backward:
         total.backward()

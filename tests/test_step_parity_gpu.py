@@ -89,7 +89,9 @@ def test_train_step_matches_reference_and_oracle(case):
     for k in ("features", "featuresB", "retransform_features", "cv_attn_road", "cm_attn_car", "origin_features"):
         assert rel(out[k].cpu().numpy(), g["feat/" + k]) < 2e-3, k
 
-    # ---- gradients: which parameters get none, per-parameter norms, probes
+    # ---- gradients.  (a) vs the REFERENCE golden: which parameters get none, per-parameter norms within 5 %
+    # (the per-pixel arg-min of the automask and the CCT arg-max are discrete: a handful of selections
+    # flip between fp32 implementations and move the coarse-scale gradients by O(1 %)).
     none_ref = {k[len("gradnone/"):] for k in g.files if k.startswith("gradnone/")}
     bad = []
     for n, p in model.named_parameters():
@@ -99,12 +101,31 @@ def test_train_step_matches_reference_and_oracle(case):
             continue
         ref = float(g["gradnorm/" + n])
         floor = 1e-5 * float(g["gradnorm_module/" + n.split(".")[0]])
-        if abs(gn - ref) > 1e-2 * ref + floor:
+        if abs(gn - ref) > 5e-2 * ref + floor:
             bad.append((n, gn, ref))
-        probe = p.grad.reshape(-1)[:4].cpu().numpy()
-        if np.abs(probe - g["gradprobe/" + n]).max() > 2e-2 * ref + floor:
-            bad.append((n + "[probe]", probe.tolist(), g["gradprobe/" + n].tolist()))
-    assert not bad, f"{len(bad)} gradient mismatches, first: {bad[:8]}"
+    assert not bad, f"{len(bad)} gradient-norm mismatches vs reference golden, first: {bad[:8]}"
+    # (b) tie-tolerant exact check: replay the device's discrete selections in the oracle and compare every
+    # gradient element-wise (relative to the parameter's gradient norm).
+    force = {("min_index", s): out[("min_index", s)].cpu() for s in range(4)}
+    for tag in ("road", "car"):
+        force["cv_argmax_" + tag] = out["cv_argmax_" + tag].cpu()
+        force["cm_argmax_" + tag] = out["cm_argmax_" + tag].cpu()
+    for s in range(4):     # selections agree with the free-running oracle almost everywhere
+        agree = float((force[("min_index", s)] == ora["out"][("min_index", s)]).float().mean())
+        assert agree > 0.998, f"min_index scale {s}: only {agree:.5f} agreement"
+    ora2 = run_oracle(meta, force=force)
+    bad = []
+    for n, p in model.named_parameters():
+        r = ora2["P"][n].grad
+        if r is None:
+            continue
+        rn = float(r.norm())
+        floor = 2e-5 * float(g["gradnorm_module/" + n.split(".")[0]])
+        err = float((p.grad.detach().cpu() - r).norm())
+        if err > 1e-2 * rn + floor:
+            bad.append((n, err, rn))
+    assert not bad, f"{len(bad)} gradient mismatches vs oracle (forced selections), first: {bad[:8]}"
+    ora = ora2
 
     # ---- BN buffers incl. the double update of the duplicated layout call (N4)
     sd = model.state_dict()
