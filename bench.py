@@ -185,7 +185,7 @@ def measure_roofline(runner, batch, _lib):
         if name != "jp_conv2d_fwd_src3":
             return orig(name, *a)
         c0, c1, c2 = a[1], a[4], a[7]
-        N, H, W, Cout, KH, stride, pad = a[12], a[13], a[14], a[15], a[16], a[17], a[18]
+        N, H, W, Cout, KH, stride, pad = a[12], a[13], a[14], a[15], a[16], a[17], a[18]   # jp_conv2d_fwd_src3 ABI order
         OH = (H + 2 * pad - KH) // stride + 1
         OW = (W + 2 * pad - KH) // stride + 1
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

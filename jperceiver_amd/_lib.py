@@ -61,7 +61,8 @@ class _Lib:
         for name, (ret, args) in self.protos.items():
             f = getattr(self.cdll, name)   # AttributeError if the .so lacks a declared symbol
             f.argtypes = [_ctype(t) for t, _ in args]
-            f.restype = ctypes.c_char_p if ret.startswith("const char") else (None if ret == "void" else ctypes.c_int)
+            f.restype = (ctypes.c_char_p if ret.startswith("const char") else None if ret == "void"
+                         else ctypes.c_long if ret == "long" else ctypes.c_int)
             self.fn[name] = f
         self.ptr_args = {name: [t.endswith("*") for t, _ in args] for name, (ret, args) in self.protos.items()}
 

@@ -5,11 +5,18 @@
 //
 // Layout: activations NCHW fp32, weights [Cout][Cin][KH][KW] fp32 (the reference's state-dict
 // layout, so checkpoints stay interchangeable).
-//   forward : M = Cout,  N = batch*OH*OW pixels,  K = Cin*KH*KW   (B gathered with zero/reflect
+//   forward : M = Cout,  N = batch*OH*OW pixels,  K = taps*Cin    (B gathered with zero/reflect
 //             padding, stride, and optional fused nearest-2x-upsample + channel-concat sources)
-//   dgrad   : M = Cin,   N = batch*H*W  pixels,   K = Cout*KH*KW  (B gathers dY; the adjoint of
+//   dgrad   : M = Cin,   N = batch*H*W  pixels,   K = taps*Cout   (B gathers dY; the adjoint of
 //             reflection padding is folded into the gather, no workspace)
-//   wgrad   : M = Cout,  N = Cin*KH*KW,           K = batch*OH*OW (split-K, fp32 atomics)
+//   wgrad   : M = Cout,  N = taps*Cin,            K = batch*OH*OW (split-K, fp32 atomics)
+//
+// Two loader families.  "T" (tap-major, the fast path): K is ordered (tap, channel) with the channel
+// count padded to a multiple of 32 = the K-chunk, so the filter tap, the bounds/reflection logic and
+// the source pointer are computed ONCE per chunk per thread and each gathered element costs one
+// strided load; weights are re-packed to [tap][row][channel_padded] (a 1-2 MB, L2-resident buffer) so
+// their loads are coalesced.  "G" (generic, K ordered (channel, tap)): any channel count, used when
+// the reduction channels are few (stems with 3/6 inputs, dgrad of the 1/2/6/16-channel heads).
 #include "igemm.h"
 #include <algorithm>
 
@@ -32,18 +39,31 @@ struct Src3 {  // input as up to 3 channel segments, each optionally stored at h
     }
 };
 
-// ---------------------------------------------------------------- forward loaders
-struct PixSt {  // decoded output pixel of a conv (shared by the fwd-B and wgrad-B gathers)
+struct PixSt {  // decoded output pixel of a conv
     int img, iy0, ix0, valid;
 };
 
+__device__ __forceinline__ PixSt conv_pix(int p, int Npix, int OH, int OW, int stride, int pad) {
+    PixSt st;
+    st.valid = p < Npix;
+    int ohw = OH * OW;
+    st.img = p / ohw;
+    int pix = p - st.img * ohw;
+    int oy = pix / OW, ox = pix - oy * OW;
+    st.iy0 = oy * stride - pad;
+    st.ix0 = ox * stride - pad;
+    return st;
+}
+
+// =============================================================== generic (channel-major K) loaders
 struct FwdA {  // A[m=co][k] = W[co*K + k]
     static constexpr bool ALONG_K = true;
     typedef int St;
     const float* w;
     int M, K;
-    __device__ __forceinline__ St fix(int k) const { return k; }
-    __device__ __forceinline__ float get(St k, int m) const { return (m < M && k < K) ? w[(size_t)m * K + k] : 0.f; }
+    __device__ __forceinline__ void init(St&, int, int) const {}
+    __device__ __forceinline__ void fix(St& st, int k) const { st = k; }
+    __device__ __forceinline__ float get(St k, int m, int) const { return (m < M && k < K) ? w[(size_t)m * K + k] : 0.f; }
 };
 
 template <int KH>
@@ -61,28 +81,23 @@ __device__ __forceinline__ float conv_gather(const Src3& src, const PixSt& st, i
     return src.at(st.img, ci, iy, ix);
 }
 
-__device__ __forceinline__ PixSt conv_pix(int p, int Npix, int OH, int OW, int stride, int pad) {
-    PixSt st;
-    st.valid = p < Npix;
-    int ohw = OH * OW;
-    st.img = p / ohw;
-    int pix = p - st.img * ohw;
-    int oy = pix / OW, ox = pix - oy * OW;
-    st.iy0 = oy * stride - pad;
-    st.ix0 = ox * stride - pad;
-    return st;
-}
+struct PixKSt {
+    PixSt px;
+    int kc;
+};
 
 template <int KH>
 struct FwdB {  // B[k=(ci,dy,dx)][n=pixel]
     static constexpr bool ALONG_K = false;
-    typedef PixSt St;
+    typedef PixKSt St;
     Src3 src;
     int K, Npix, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ St fix(int p) const { return conv_pix(p, Npix, OH, OW, stride, pad); }
-    __device__ __forceinline__ float get(const St& st, int k) const {
-        if (!st.valid || k >= K) return 0.f;
-        return conv_gather<KH>(src, st, k, reflect);
+    __device__ __forceinline__ void init(St& st, int p) const { st = St{conv_pix(p, Npix, OH, OW, stride, pad), 0}; }
+    __device__ __forceinline__ void chunk(St& st, int kc) const { st.kc = kc; }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        const int k = st.kc + kl;
+        if (!st.px.valid || k >= K) return 0.f;
+        return conv_gather<KH>(src, st.px, k, reflect);
     }
 };
 
@@ -101,19 +116,24 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     }
 };
 
-// ---------------------------------------------------------------- dgrad loaders
+struct MKSt {
+    int m, kc;
+};
+
 template <int KH>
 struct DgradA {  // A[m=ci][k=(co,dy,dx)] = W[co][ci][dy][dx]
     static constexpr bool ALONG_K = false;
-    typedef int St;
+    typedef MKSt St;
     const float* w;
     int Cin, K;
-    __device__ __forceinline__ St fix(int m) const { return m; }
-    __device__ __forceinline__ float get(St ci, int k) const {
-        if (ci >= Cin || k >= K) return 0.f;
+    __device__ __forceinline__ void init(St& st, int m) const { st = St{m, 0}; }
+    __device__ __forceinline__ void chunk(St& st, int kc) const { st.kc = kc; }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        const int k = st.kc + kl;
+        if (st.m >= Cin || k >= K) return 0.f;
         int co = k / (KH * KH);
         int tap = k - co * (KH * KH);
-        return w[((size_t)co * Cin + ci) * (KH * KH) + tap];
+        return w[((size_t)co * Cin + st.m) * (KH * KH) + tap];
     }
 };
 
@@ -121,56 +141,78 @@ struct InPixSt {
     int img, y, x, valid;
 };
 
+// offsets (within one dY channel plane) of the dY entries that touched input pixel (y,x) through tap (ty,tx):
+// zero padding: at most one; ReflectionPad2d(1) + 3x3 stride 1: padded row py in [0,H+1] maps to input row
+// reflect(py-1); input row y is hit by py=y+1 and additionally by py=0 when y==1 and py=H+1 when y==H-2;
+// the dY row is py - ty and must lie in [0,H) -> at most 2 rows x 2 cols.
+struct DyOffs {
+    int o0, o1, o2, o3;
+};
+__device__ __forceinline__ DyOffs dy_offsets(int y, int x, int ty, int tx, int H, int W, int OH, int OW, int stride,
+                                             int pad, int reflect) {
+    DyOffs d{-1, -1, -1, -1};
+    if (!reflect) {
+        int ny = y + pad - ty, nx = x + pad - tx;
+        if (ny < 0 || nx < 0) return d;
+        int oy = ny / stride, ox = nx / stride;
+        if (oy * stride != ny || ox * stride != nx || oy >= OH || ox >= OW) return d;
+        d.o0 = oy * OW + ox;
+        return d;
+    }
+    int r0 = y + 1 - ty, r1 = -1, c0 = x + 1 - tx, c1 = -1;
+    if (r0 < 0 || r0 >= H) r0 = -1;
+    if (y == 1 && ty == 0) r1 = 0;
+    if (y == H - 2 && ty == 2) r1 = H - 1;
+    if (c0 < 0 || c0 >= W) c0 = -1;
+    if (x == 1 && tx == 0) c1 = 0;
+    if (x == W - 2 && tx == 2) c1 = W - 1;
+    if (r0 >= 0 && c0 >= 0) d.o0 = r0 * OW + c0;
+    if (r0 >= 0 && c1 >= 0) d.o1 = r0 * OW + c1;
+    if (r1 >= 0 && c0 >= 0) d.o2 = r1 * OW + c0;
+    if (r1 >= 0 && c1 >= 0) d.o3 = r1 * OW + c1;
+    return d;
+}
+__device__ __forceinline__ float dy_sum(const float* q, const DyOffs& d) {
+    float s = 0.f;
+    if (d.o0 >= 0) s += q[d.o0];
+    if (d.o1 >= 0) s += q[d.o1];
+    if (d.o2 >= 0) s += q[d.o2];
+    if (d.o3 >= 0) s += q[d.o3];
+    return s;
+}
+
+struct InPixKSt {
+    InPixSt px;
+    int kc;
+};
+
+__device__ __forceinline__ InPixSt in_pix(int p, int Npix, int H, int W) {
+    InPixSt px;
+    px.valid = p < Npix;
+    int hw = H * W;
+    px.img = p / hw;
+    int pix = p - px.img * hw;
+    px.y = pix / W;
+    px.x = pix - px.y * W;
+    return px;
+}
+
 template <int KH>
-struct DgradB {  // B[k=(co,dy,dx)][n=input pixel] = sum of dY entries that used x[pixel] through tap
+struct DgradB {  // B[k=(co,dy,dx)][n=input pixel]
     static constexpr bool ALONG_K = false;
-    typedef InPixSt St;
+    typedef InPixKSt St;
     const float* dy;
     int K, Npix, H, W, Cout, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ St fix(int p) const {
-        St st;
-        st.valid = p < Npix;
-        int hw = H * W;
-        st.img = p / hw;
-        int pix = p - st.img * hw;
-        st.y = pix / W;
-        st.x = pix - st.y * W;
-        return st;
-    }
-    __device__ __forceinline__ float get(const St& st, int k) const {
-        if (!st.valid || k >= K) return 0.f;
+    __device__ __forceinline__ void init(St& st, int p) const { st = St{in_pix(p, Npix, H, W), 0}; }
+    __device__ __forceinline__ void chunk(St& st, int kc) const { st.kc = kc; }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        const int k = st.kc + kl;
+        if (!st.px.valid || k >= K) return 0.f;
         int co = k / (KH * KH);
         int tap = k - co * (KH * KH);
         int ty = tap / KH, tx = tap - ty * KH;
-        const float* d = dy + (size_t)(st.img * Cout + co) * OH * OW;
-        const int y = st.y, x = st.x;
-        if (!reflect) {
-            int ny = y + pad - ty, nx = x + pad - tx;
-            if (ny < 0 || nx < 0) return 0.f;
-            int oy = ny / stride, ox = nx / stride;
-            if (oy * stride != ny || ox * stride != nx || oy >= OH || ox >= OW) return 0.f;
-            return d[oy * OW + ox];
-        }
-        // ReflectionPad2d(1) + 3x3 stride-1 conv (OH==H, OW==W).  Padded row py in [0,H+1] maps to
-        // input row reflect(py-1); input row y is hit by py=y+1, and additionally by py=0 when y==1
-        // and by py=H+1 when y==H-2.  dY row = py - ty must lie in [0,H).
-        int r0 = y + 1 - ty, r1 = -1, r2 = -1, c0 = x + 1 - tx, c1 = -1, c2 = -1;
-        if (r0 < 0 || r0 >= H) r0 = -1;
-        if (y == 1 && ty == 0) r1 = 0;
-        if (y == H - 2 && ty == 2) r2 = H - 1;
-        if (c0 < 0 || c0 >= W) c0 = -1;
-        if (x == 1 && tx == 0) c1 = 0;
-        if (x == W - 2 && tx == 2) c2 = W - 1;
-        float s = 0.f;
-#define JP_ROWSUM(r)                                  \
-        if (r >= 0) {                                     \
-            if (c0 >= 0) s += d[r * OW + c0];             \
-            if (c1 >= 0) s += d[r * OW + c1];             \
-            if (c2 >= 0) s += d[r * OW + c2];             \
-        }
-        JP_ROWSUM(r0) JP_ROWSUM(r1) JP_ROWSUM(r2)
-#undef JP_ROWSUM
-        return s;
+        const float* d = dy + (size_t)(st.px.img * Cout + co) * OH * OW;
+        return dy_sum(d, dy_offsets(st.px.y, st.px.x, ty, tx, H, W, OH, OW, stride, pad, reflect));
     }
 };
 
@@ -188,7 +230,6 @@ struct DgradEpi {  // dx[img][ci][pix] (= or +=) acc
     }
 };
 
-// ---------------------------------------------------------------- wgrad loaders
 struct WgradASt {
     size_t base;
     int valid;
@@ -198,14 +239,13 @@ struct WgradA {  // A[m=co][k=pixel] = dY[img][co][pix]
     typedef WgradASt St;
     const float* dy;
     int Cout, Npix, OHW;
-    __device__ __forceinline__ St fix(int p) const {
-        St st;
+    __device__ __forceinline__ void init(St&, int, int) const {}
+    __device__ __forceinline__ void fix(St& st, int p) const {
         st.valid = p < Npix;
         int img = p / OHW;
         st.base = (size_t)img * Cout * OHW + (p - img * OHW);
-        return st;
     }
-    __device__ __forceinline__ float get(const St& st, int m) const {
+    __device__ __forceinline__ float get(const St& st, int m, int) const {
         return (st.valid && m < Cout) ? dy[st.base + (size_t)m * OHW] : 0.f;
     }
 };
@@ -216,8 +256,9 @@ struct WgradB {  // B[k=pixel][n=(ci,dy,dx)] = xpad[img][ci][oy*s+dy][ox*s+dx]
     typedef PixSt St;
     Src3 src;
     int Kw, Npix, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ St fix(int p) const { return conv_pix(p, Npix, OH, OW, stride, pad); }
-    __device__ __forceinline__ float get(const St& st, int j) const {
+    __device__ __forceinline__ void init(St&, int, int) const {}
+    __device__ __forceinline__ void fix(St& st, int p) const { st = conv_pix(p, Npix, OH, OW, stride, pad); }
+    __device__ __forceinline__ float get(const St& st, int j, int) const {
         if (!st.valid || j >= Kw) return 0.f;
         return conv_gather<KH>(src, st, j, reflect);
     }
@@ -230,6 +271,215 @@ struct WgradEpi {  // dw[co][j] += acc   (split-K partials meet in L2 atomics)
     __device__ __forceinline__ St col(int n) const { return n; }
     __device__ __forceinline__ void put(St j, int m, float v) const { atomicAdd(dw + (size_t)m * Kw + j, v); }
 };
+
+// =============================================================== tap-major ("T") fast-path loaders
+// packed weights wp[tap][row][Cp] (row = co for forward, ci for dgrad; Cp = reduction channels padded to 32)
+struct PackASt {
+    size_t off;
+    int valid;
+};
+struct PackA {  // A[m=row][k=(tap,c)] = wp[(tap*M + m)*Cp + c]
+    static constexpr bool ALONG_K = true;
+    typedef PackASt St;
+    const float* wp;
+    int M, Kp, Cp;
+    __device__ __forceinline__ void init(St&, int, int) const {}
+    __device__ __forceinline__ void fix(St& st, int k) const {
+        st.valid = k < Kp;
+        const int tap = k / Cp;
+        st.off = (size_t)k + (size_t)tap * (size_t)(M - 1) * Cp;
+    }
+    __device__ __forceinline__ float get(const St& st, int m, int) const {
+        return (st.valid && m < M) ? wp[st.off + (size_t)m * Cp] : 0.f;
+    }
+};
+
+struct FwdBTSt {
+    PixSt px;
+    const float* p;   // element (chunk's first channel, this pixel, this tap)
+    int cs;           // channel stride of the selected source segment
+    int n;            // valid channels in this chunk (0 = nothing to load)
+};
+
+template <int KH>
+struct FwdBT {  // B[k=(tap,ci)][n=pixel]
+    static constexpr bool ALONG_K = false;
+    typedef FwdBTSt St;
+    Src3 src;
+    int Cp, Npix, OH, OW, stride, pad, reflect;
+    __device__ __forceinline__ void init(St& st, int p) const { st = St{conv_pix(p, Npix, OH, OW, stride, pad), nullptr, 0, 0}; }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int tap = kc / Cp;               // Cp % 32 == 0: the whole chunk shares one tap
+        const int ci0 = kc - tap * Cp;
+        const int dy = tap / KH, dx = tap - dy * KH;
+        int iy = st.px.iy0 + dy, ix = st.px.ix0 + dx;
+        st.n = 0;
+        if (!st.px.valid || ci0 >= src.e2) return;
+        if (reflect) {
+            iy = jp_reflect(iy, src.H);
+            ix = jp_reflect(ix, src.W);
+        } else if ((unsigned)iy >= (unsigned)src.H || (unsigned)ix >= (unsigned)src.W) {
+            return;
+        }
+        const bool a = ci0 < src.e0, b = ci0 < src.e1;   // segment ends are multiples of 32 (host-checked)
+        const float* p = a ? src.p0 : (b ? src.p1 : src.p2);
+        const int c0 = a ? 0 : (b ? src.e0 : src.e1);
+        const int ce = a ? src.e0 : (b ? src.e1 : src.e2);
+        const int sh = a ? src.s0 : (b ? src.s1 : src.s2);
+        const int h = src.H >> sh, w = src.W >> sh;
+        st.cs = h * w;
+        st.p = p + ((size_t)(st.px.img * (ce - c0) + (ci0 - c0)) * h + (iy >> sh)) * w + (ix >> sh);
+        st.n = min(32, ce - ci0);
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        return kl < st.n ? st.p[(size_t)kl * st.cs] : 0.f;
+    }
+};
+
+struct DgradBTSt {
+    InPixSt px;
+    const float* p;   // dY plane of the chunk's first channel (this image)
+    DyOffs d;         // o0 = main tap position; o1..o3 only ever set on reflect-padded border pixels
+    int n, extra;
+};
+
+template <int KH>
+struct DgradBT {  // B[k=(tap,co)][n=input pixel]
+    static constexpr bool ALONG_K = false;
+    typedef DgradBTSt St;
+    const float* dy;
+    int Cp, Npix, H, W, Cout, OH, OW, stride, pad, reflect;
+    __device__ __forceinline__ void init(St& st, int p) const {
+        st = St{in_pix(p, Npix, H, W), nullptr, DyOffs{-1, -1, -1, -1}, 0, 0};
+    }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int tap = kc / Cp;
+        const int co0 = kc - tap * Cp;
+        const int ty = tap / KH, tx = tap - ty * KH;
+        st.n = 0;
+        if (!st.px.valid || co0 >= Cout) return;
+        st.d = dy_offsets(st.px.y, st.px.x, ty, tx, H, W, OH, OW, stride, pad, reflect);
+        st.extra = (st.d.o1 >= 0) | (st.d.o2 >= 0) | (st.d.o3 >= 0);
+        if (st.d.o0 < 0 && !st.extra) return;
+        st.p = dy + (size_t)(st.px.img * Cout + co0) * OH * OW;
+        st.n = min(32, Cout - co0);
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        if (kl >= st.n) return 0.f;
+        const float* q = st.p + (size_t)kl * OH * OW;
+        float v = st.d.o0 >= 0 ? q[st.d.o0] : 0.f;
+        if (st.extra) {   // reflect-padded border pixels only (wave-divergent at image edges)
+            if (st.d.o1 >= 0) v += q[st.d.o1];
+            if (st.d.o2 >= 0) v += q[st.d.o2];
+            if (st.d.o3 >= 0) v += q[st.d.o3];
+        }
+        return v;
+    }
+};
+
+template <int KH>
+struct WgradBT {  // B[k=pixel][n=(tap,ci)], any source layout (per-element decode)
+    static constexpr bool ALONG_K = true;
+    typedef PixSt St;
+    Src3 src;
+    int Np, Cp, Cin, Npix, OH, OW, stride, pad, reflect;
+    unsigned magic;   // floor(2^32 / Cp) + 1: n / Cp == umulhi(n, magic) for n < 2^16
+    __device__ __forceinline__ void init(St&, int, int) const {}
+    __device__ __forceinline__ void fix(St& st, int p) const { st = conv_pix(p, Npix, OH, OW, stride, pad); }
+    __device__ __forceinline__ float get(const St& st, int n, int) const {
+        if (!st.valid || n >= Np) return 0.f;
+        const int tap = (int)__umulhi((unsigned)n, magic);
+        const int ci = n - tap * Cp;
+        if (ci >= Cin) return 0.f;
+        const int dy = tap / KH, dx = tap - dy * KH;
+        int iy = st.iy0 + dy, ix = st.ix0 + dx;
+        if (reflect) {
+            iy = jp_reflect(iy, src.H);
+            ix = jp_reflect(ix, src.W);
+        } else if ((unsigned)iy >= (unsigned)src.H || (unsigned)ix >= (unsigned)src.W) {
+            return 0.f;
+        }
+        return src.at(st.img, ci, iy, ix);
+    }
+};
+
+// single full-resolution source: the (tap, ci) decode of every slot is done ONCE per thread (the N index of a
+// slot never changes over the K loop), leaving ~8 integer ops per gathered element.
+struct WgradB1St {
+    PixSt px;
+    const float* base;   // x + img*Cin*H*W
+    int off[32];         // ci*H*W, or -1 for padded / out-of-range slots
+    int dd[32];          // dy | dx << 8
+};
+
+template <int KH>
+struct WgradBT1 {
+    static constexpr bool ALONG_K = true;
+    typedef WgradB1St St;
+    const float* x;
+    int Np, Cp, Cin, H, W, Npix, OH, OW, stride, pad, reflect;
+    unsigned magic;
+    __device__ __forceinline__ void init(St& st, int n_first, int step) const {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int n = n_first + step * r;
+            const int tap = (int)__umulhi((unsigned)n, magic);
+            const int ci = n - tap * Cp;
+            const int dy = tap / KH, dx = tap - dy * KH;
+            st.off[r] = (n < Np && ci < Cin) ? ci * H * W : -1;
+            st.dd[r] = dy | (dx << 8);
+        }
+    }
+    __device__ __forceinline__ void fix(St& st, int p) const {
+        st.px = conv_pix(p, Npix, OH, OW, stride, pad);
+        st.base = x + (size_t)st.px.img * Cin * H * W;
+    }
+    __device__ __forceinline__ float get(const St& st, int, int r) const {
+        if (!st.px.valid || st.off[r] < 0) return 0.f;
+        int iy = st.px.iy0 + (st.dd[r] & 255), ix = st.px.ix0 + (st.dd[r] >> 8);
+        if (reflect) {
+            iy = jp_reflect(iy, H);
+            ix = jp_reflect(ix, W);
+        } else if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) {
+            return 0.f;
+        }
+        return st.base[st.off[r] + iy * W + ix];
+    }
+};
+
+struct WgradEpiT {  // dw[co][ci][tap] += acc for n = tap*Cp + ci
+    typedef int St;
+    float* dw;
+    int Cp, Cin, KHW;
+    unsigned magic;
+    __device__ __forceinline__ St col(int n) const {
+        const int tap = (int)__umulhi((unsigned)n, magic);
+        const int ci = n - tap * Cp;
+        return ci < Cin ? ci * KHW + tap : -1;
+    }
+    __device__ __forceinline__ void put(St j, int m, float v) const {
+        if (j >= 0) atomicAdd(dw + (size_t)m * Cin * KHW + j, v);
+    }
+};
+
+// wp[tap][row][Cp]: forward rows = co (src W[co][ci][tap]); dgrad rows = ci, reduction = co
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KHW,
+                                    int Cp, int for_dgrad) {
+    const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+    const long total = (long)KHW * rows * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const long t = i / Cp;
+        const int r = (int)(t % rows);
+        const int tap = (int)(t / rows);
+        float v = 0.f;
+        if (c < red) {
+            const int co = for_dgrad ? c : r, ci = for_dgrad ? r : c;
+            v = w[((size_t)co * Cin + ci) * KHW + tap];
+        }
+        wp[i] = v;
+    }
+}
 
 constexpr int KC = 32;
 
@@ -256,6 +506,20 @@ Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1
     return s;
 }
 
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+inline bool seg_aligned(int c0, int c1, int c2) {   // every segment end except the last is a multiple of 32
+    if (c1 == 0 && c2 == 0) return true;
+    if (c0 % 32) return false;
+    if (c2 != 0 && (c0 + c1) % 32) return false;
+    return true;
+}
+
+void pack_weights(const float* w, float* wp, int Cout, int Cin, int KHW, int Cp, int for_dgrad, hipStream_t st) {
+    const long total = (long)KHW * (for_dgrad ? Cin : Cout) * Cp;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, w, wp,
+                       Cout, Cin, KHW, Cp, for_dgrad);
+}
+
 }  // namespace
 
 #define JP_KH_SWITCH(KHV, ...)                                  \
@@ -266,10 +530,18 @@ Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1
         default: jp_set_last_error("conv: kernel size must be 1, 3 or 7"); return JP_EBADARG; \
     }
 
+// floats of caller-owned scratch for the packed-weight fast path (0 = the generic path will be used).
+// which: 0 forward, 1 dgrad, 2 wgrad
+extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
+    if (which == 0) return Cin >= 32 ? (long)KH * KH * Cout * pad32(Cin) : 0;
+    if (which == 1) return Cout >= 32 ? (long)KH * KH * Cin * pad32(Cout) : 0;
+    return 0;
+}
+
 extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
                                   const float* x2, int c2, int up2, const float* w, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int KH, int stride, int pad, int pad_mode, int act,
-                                  void* stream) {
+                                  float* ws, void* stream) {
     JP_CHECK_ARG(x0 && w && y, "conv2d_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && c0 > 0 && stride >= 1, "conv2d_fwd: bad dims");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && (pad >= H || pad >= W)), "conv2d_fwd: reflect pad >= size");
@@ -277,40 +549,61 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW;
     JP_CHECK_ARG(npix < (1L << 31) && (long)N * Cin * H * W < (1L << 31) * 2, "conv2d_fwd: tensor too large");
-    const int K = Cin * KH * KH;
     hipStream_t st = (hipStream_t)stream;
-    FwdA a{w, Cout, K};
     FwdEpi e{y, bias, Cout, OH * OW, act};
-    JP_KH_SWITCH(KH, {
-        FwdB<KH_> b{make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W), K, (int)npix, OH, OW, stride, pad,
-                    pad_mode == JP_PAD_REFLECT};
-        launch_auto(a, b, e, Cout, (int)npix, K, 1, jp_cdiv(K, KC) * KC, st);
-    });
+    const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
+    if (ws && Cin >= 32 && seg_aligned(c0, c1, c2)) {   // tap-major fast path
+        const int Cp = pad32(Cin), Kp = KH * KH * Cp;
+        pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
+        PackA a{ws, Cout, Kp, Cp};
+        JP_KH_SWITCH(KH, {
+            FwdBT<KH_> b{src, Cp, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+            launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+        });
+    } else {
+        const int K = Cin * KH * KH;
+        FwdA a{w, Cout, K};
+        JP_KH_SWITCH(KH, {
+            FwdB<KH_> b{src, K, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+            launch_auto(a, b, e, Cout, (int)npix, K, 1, jp_cdiv(K, KC) * KC, st);
+        });
+    }
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
-                             int W, int Cout, int KH, int stride, int pad, int pad_mode, int act, void* stream) {
+                             int W, int Cout, int KH, int stride, int pad, int pad_mode, int act, float* ws,
+                             void* stream) {
     return jp_conv2d_fwd_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, w, bias, y, N, H, W, Cout, KH, stride, pad,
-                              pad_mode, act, stream);
+                              pad_mode, act, ws, stream);
 }
 
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
-                               int KH, int stride, int pad, int pad_mode, int accumulate, void* stream) {
+                               int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, void* stream) {
     JP_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && !(KH == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2)),
                  "conv2d_dgrad: reflect mode supports 3x3 stride 1 pad 1 only");
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * H * W;
     JP_CHECK_ARG(npix < (1L << 31), "conv2d_dgrad: tensor too large");
-    const int K = Cout * KH * KH;
     hipStream_t st = (hipStream_t)stream;
     DgradEpi e{dx, Cin, H * W, accumulate};
-    JP_KH_SWITCH(KH, {
-        DgradA<KH_> a{w, Cin, K};
-        DgradB<KH_> b{dy, K, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-        launch_auto(a, b, e, Cin, (int)npix, K, 1, jp_cdiv(K, KC) * KC, st);
-    });
+    if (ws && Cout >= 32) {
+        const int Cp = pad32(Cout), Kp = KH * KH * Cp;
+        pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
+        PackA a{ws, Cin, Kp, Cp};
+        JP_KH_SWITCH(KH, {
+            DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+            launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
+        });
+    } else {
+        const int K = Cout * KH * KH;
+        JP_KH_SWITCH(KH, {
+            DgradA<KH_> a{w, Cin, K};
+            DgradB<KH_> b{dy, K, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+            launch_auto(a, b, e, Cin, (int)npix, K, 1, jp_cdiv(K, KC) * KC, st);
+        });
+    }
     JP_LAUNCH_CHECK();
 }
 
@@ -326,18 +619,36 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
     const int Kw = Cin * KH * KH;
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) JP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Kw, st));
-    // split-K so that ~2k workgroups are in flight (256 CUs x 8 XCD-interleaved)
-    const int tiles = jp_cdiv(Cout, Cout <= 64 ? 64 : 128) * jp_cdiv(Kw, Cout <= 64 ? 256 : 128);
-    int splits = (int)std::min<long>(std::max(1, 2048 / std::max(1, tiles)), jp_cdiv(npix, 4 * KC));
+    const bool fast = Cin >= 32;
+    const int Cp = pad32(Cin), Np = fast ? KH * KH * Cp : Kw;
+    const int tiles = jp_cdiv(Cout, Cout <= 64 ? 64 : 128) * jp_cdiv(Np, Cout <= 64 ? 256 : 128);
+    // ~1k workgroups in flight, but at least 64 K-chunks per split so the 16k-atomic epilogue stays amortised
+    int splits = (int)std::min<long>(std::max(1, 1024 / std::max(1, tiles)), std::max<long>(1, npix / (64 * KC)));
     int kps = jp_cdiv(jp_cdiv(npix, splits), KC) * KC;
     splits = jp_cdiv(npix, kps);
     WgradA a{dy, Cout, (int)npix, OH * OW};
-    WgradEpi e{dw, Kw};
-    JP_KH_SWITCH(KH, {
-        WgradB<KH_> b{make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W), Kw, (int)npix, OH, OW, stride, pad,
-                      pad_mode == JP_PAD_REFLECT};
-        launch_auto(a, b, e, Cout, Kw, (int)npix, splits, kps, st);
-    });
+    const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
+    if (fast) {
+        const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cp) + 1u;
+        WgradEpiT e{dw, Cp, Cin, KH * KH, magic};
+        if (c1 == 0 && c2 == 0 && up0 == 0 && (long)Cin * H * W < (1L << 31)) {
+            JP_KH_SWITCH(KH, {
+                WgradBT1<KH_> b{x0, Np, Cp, Cin, H, W, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT, magic};
+                launch_auto(a, b, e, Cout, Np, (int)npix, splits, kps, st);
+            });
+        } else {
+            JP_KH_SWITCH(KH, {
+                WgradBT<KH_> b{src, Np, Cp, Cin, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT, magic};
+                launch_auto(a, b, e, Cout, Np, (int)npix, splits, kps, st);
+            });
+        }
+    } else {
+        WgradEpi e{dw, Kw};
+        JP_KH_SWITCH(KH, {
+            WgradB<KH_> b{src, Kw, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+            launch_auto(a, b, e, Cout, Kw, (int)npix, splits, kps, st);
+        });
+    }
     JP_LAUNCH_CHECK();
 }
 

@@ -1,6 +1,6 @@
 // One LDS-staged fp32-MFMA implicit-GEMM engine for gfx950:  C[m][n] (+)= sum_k A(m,k) * B(k,n)
 // with pluggable gather-loaders for A and B and a pluggable epilogue.  conv2d forward, dgrad and
-// wgrad, 1x1 convs and the dense layers are all instances of this kernel (conv.hip).
+// wgrad and the 1x1 convs are all instances of this kernel (conv.hip).
 //
 // Geometry: 256 threads = 4 wave64.  Every wave owns a 64x64 output tile as 2x2
 // v_mfma_f32_32x32x2_f32 accumulators (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak, guide
@@ -9,6 +9,14 @@
 // under the previous chunk's MFMAs), stored to LDS as As[k][m] / Bs[k][n] (row pad 1 -> both the
 // lane-along-k and lane-along-mn store patterns and the MFMA fragment reads are bank-conflict
 // free) and consumed with one ds_read_b32 per operand per MFMA.
+//
+// Loader protocol (all state lives in registers; the functors are read-only kernel arguments):
+//   ALONG_K  loader (lanes run along k):  init(st, first_mn, mn_step)  once      -> per-slot tables
+//                                          fix(st, k)                   per chunk -> decode this thread's k
+//                                          get(st, mn, r)               per element (r = compile-time slot)
+//   ALONG_MN loader (lanes run along m/n): init(st, mn)                  once      -> decode this thread's m/n
+//                                          chunk(st, kc)                 per chunk -> chunk-uniform part
+//                                          get(st, kl, r)                per element (kl = k - kc)
 #pragma once
 #include "jp_common.h"
 
@@ -33,35 +41,40 @@ __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi e
     const int kend = min(K, kbeg + k_per_split);
 
     // ---- loader thread mappings
-    // ALONG_K  : lanes run along k (kk = t % KC), mn = t / KC + (256/KC) * r
-    // ALONG_MN : lanes run along m/n (mn = t % B), kk = t / B + (256/B) * r      (B <= 256)
+    // ALONG_K  : kk = t % KC, mn = t / KC + (256/KC) * r
+    // ALONG_MN : mn = t % B,  kk = t / B + (256/B) * r      (B <= 256)
     constexpr int A_ROWS = ALoad::ALONG_K ? (256 / KC) : (256 / BM);
     constexpr int B_ROWS = BLoad::ALONG_K ? (256 / KC) : (256 / BN);
     const int a_fix_l = ALoad::ALONG_K ? (t % KC) : (t % BM);
     const int a_var_l = ALoad::ALONG_K ? (t / KC) : (t / BM);
     const int b_fix_l = BLoad::ALONG_K ? (t % KC) : (t % BN);
     const int b_var_l = BLoad::ALONG_K ? (t / KC) : (t / BN);
-    // loader state lives in registers (the functors themselves are read-only kernel arguments)
-    typename ALoad::St sa = al.fix(ALoad::ALONG_K ? 0 : m0 + a_fix_l);
-    typename BLoad::St sb = bl.fix(BLoad::ALONG_K ? 0 : n0 + b_fix_l);
+    typename ALoad::St sa;
+    typename BLoad::St sb;
+    if constexpr (ALoad::ALONG_K) al.init(sa, m0 + a_var_l, A_ROWS);
+    else al.init(sa, m0 + a_fix_l);
+    if constexpr (BLoad::ALONG_K) bl.init(sb, n0 + b_var_l, B_ROWS);
+    else bl.init(sb, n0 + b_fix_l);
 
     float ra[NA], rb[NB];
     auto gload = [&](int kc) {
-        if (ALoad::ALONG_K) {
-            sa = al.fix(kc + a_fix_l);
+        if constexpr (ALoad::ALONG_K) {
+            al.fix(sa, kc + a_fix_l);
 #pragma unroll
-            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, m0 + a_var_l + A_ROWS * r);
+            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, m0 + a_var_l + A_ROWS * r, r);
         } else {
+            al.chunk(sa, kc);
 #pragma unroll
-            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, kc + a_var_l + A_ROWS * r);
+            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, a_var_l + A_ROWS * r, r);
         }
-        if (BLoad::ALONG_K) {
-            sb = bl.fix(kc + b_fix_l);
+        if constexpr (BLoad::ALONG_K) {
+            bl.fix(sb, kc + b_fix_l);
 #pragma unroll
-            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, n0 + b_var_l + B_ROWS * r);
+            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, n0 + b_var_l + B_ROWS * r, r);
         } else {
+            bl.chunk(sb, kc);
 #pragma unroll
-            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, kc + b_var_l + B_ROWS * r);
+            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, b_var_l + B_ROWS * r, r);
         }
     };
     auto lstore = [&]() {

@@ -73,14 +73,16 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------ nearest 2x upsample
 __global__ __launch_bounds__(TPB) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             long total, int H, int W) {
+                                                             long total, int C, int H, int W, int dstC, int dc0) {
     const int OW = 2 * W, OH = 2 * H;
     for (long o = (long)blockIdx.x * TPB + threadIdx.x; o < total; o += (long)gridDim.x * TPB) {
         const int ox = (int)(o % OW);
         const long t = o / OW;
         const int oy = (int)(t % OH);
         const long nc = t / OH;
-        y[o] = x[(nc * H + (oy >> 1)) * W + (ox >> 1)];
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        y[((n * dstC + dc0 + c) * OH + oy) * OW + ox] = x[(nc * H + (oy >> 1)) * W + (ox >> 1)];
     }
 }
 
@@ -376,11 +378,13 @@ extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, in
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
-    JP_CHECK_ARG(x && y && NC > 0, "upsample2x_fwd: bad args");
+// y[n][dc0 + c] = nearest-2x(x[n][c]) written into a channel slice of a (N, dstC, 2H, 2W) tensor
+extern "C" int jp_upsample2x_fwd(const float* x, float* y, int N, int C, int H, int W, int dstC, int dc0,
+                                 void* stream) {
+    JP_CHECK_ARG(x && y && N > 0 && C > 0 && dc0 + C <= dstC, "upsample2x_fwd: bad args");
     JP_ST;
-    const long total = (long)NC * H * W * 4;
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, H, W);
+    const long total = (long)N * C * H * W * 4;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, C, H, W, dstC, dc0);
     JP_LAUNCH_CHECK();
 }
 
