@@ -522,6 +522,17 @@ void pack_weights(const float* w, float* wp, int Cout, int Cin, int KHW, int Cp,
 
 }  // namespace
 
+// conv_small.hip: direct kernels for <= 4 output channels (disparity / BEV logits heads)
+int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
+                      const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act, int reflect,
+                      hipStream_t st);
+int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
+                        int up2, const float* dy, float* dw, int N, int H, int W, int Cout, int reflect,
+                        hipStream_t st);
+static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
+    return Cout <= 4 && KH == 3 && stride == 1 && pad == 1 && (long)Cout * Cin * 9 * 4 <= 48 * 1024;
+}
+
 #define JP_KH_SWITCH(KHV, ...)                                  \
     switch (KHV) {                                              \
         case 1: { constexpr int KH_ = 1; __VA_ARGS__; } break;  \
@@ -551,6 +562,11 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     JP_CHECK_ARG(npix < (1L << 31) && (long)N * Cin * H * W < (1L << 31) * 2, "conv2d_fwd: tensor too large");
     hipStream_t st = (hipStream_t)stream;
     FwdEpi e{y, bias, Cout, OH * OW, act};
+    if (small_head(Cin, Cout, KH, stride, pad)) {
+        jp_conv_small_fwd(x0, c0, up0, x1, c1, up1, x2, c2, up2, w, bias, y, N, H, W, Cout, act,
+                          pad_mode == JP_PAD_REFLECT, st);
+        JP_LAUNCH_CHECK();
+    }
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
     if (ws && Cin >= 32 && seg_aligned(c0, c1, c2)) {   // tap-major fast path
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
@@ -619,6 +635,10 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
     const int Kw = Cin * KH * KH;
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) JP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Kw, st));
+    if (small_head(Cin, Cout, KH, stride, pad)) {
+        jp_conv_small_wgrad(x0, c0, up0, x1, c1, up1, x2, c2, up2, dy, dw, N, H, W, Cout, pad_mode == JP_PAD_REFLECT, st);
+        JP_LAUNCH_CHECK();
+    }
     const bool fast = Cin >= 32;
     const int Cp = pad32(Cin), Np = fast ? KH * KH * Cp : Kw;
     const int tiles = jp_cdiv(Cout, Cout <= 64 ? 64 : 128) * jp_cdiv(Np, Cout <= 64 ? 256 : 128);

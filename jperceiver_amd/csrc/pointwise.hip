@@ -14,60 +14,90 @@ inline int blocks_for(long n) { return (int)std::min<long>((n + TPB - 1) / TPB, 
 // ------------------------------------------------------------------ max pool
 // idx stores the window-relative argmax (ky*k+kx) of the first maximum in scan order
 // (PyTorch: `val > max || isnan(val)` -> first max wins), so backward is a gather without atomics.
+constexpr int MP_TW = 64, MP_TH = 8;   // output (fwd) / input (bwd) tile per workgroup
+
+// LDS-tiled: the input patch of a 64x8 output tile is staged once (coalesced rows, -inf outside the image),
+// then every output scans its k x k window from LDS.  grid (tiles_x, tiles_y, planes)
 __global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          uint8_t* __restrict__ idx, long total, int H, int W,
-                                                          int OH, int OW, int k, int s, int p) {
-    for (long o = (long)blockIdx.x * TPB + threadIdx.x; o < total; o += (long)gridDim.x * TPB) {
-        const int ox = (int)(o % OW);
-        const long t = o / OW;
-        const int oy = (int)(t % OH);
-        const long nc = t / OH;
-        const float* xp = x + nc * H * W;
+                                                          uint8_t* __restrict__ idx, int H, int W, int OH, int OW,
+                                                          int k, int s, int p) {
+    extern __shared__ float tile[];
+    const size_t nc = blockIdx.z;
+    const float* xp = x + nc * H * W;
+    const int ox0 = blockIdx.x * MP_TW, oy0 = blockIdx.y * MP_TH;
+    const int pw = (MP_TW - 1) * s + k, ph = (MP_TH - 1) * s + k;
+    const int ix0 = ox0 * s - p, iy0 = oy0 * s - p;
+    for (int i = threadIdx.x; i < pw * ph; i += TPB) {
+        const int ly = i / pw, lx = i - ly * pw;
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        tile[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xp[iy * W + ix] : -INFINITY;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < MP_TW * MP_TH; o += TPB) {
+        const int ty = o / MP_TW, tx = o - ty * MP_TW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (oy >= OH || ox >= OW) continue;
         float best = -INFINITY;
-        int bi = 0;
-        bool found = false;
+        int bi = -1;
         for (int ky = 0; ky < k; ++ky) {
-            const int iy = oy * s - p + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
+            const float* row = tile + (ty * s + ky) * pw + tx * s;
+            const bool rin = (unsigned)(iy0 + ty * s + ky) < (unsigned)H;
             for (int kx = 0; kx < k; ++kx) {
-                const int ix = ox * s - p + kx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const float v = xp[iy * W + ix];
-                if (!found || v > best || v != v) { best = v; bi = ky * k + kx; found = true; }
+                const float v = row[kx];
+                const bool in = rin && (unsigned)(ix0 + tx * s + kx) < (unsigned)W;
+                // PyTorch: first element in scan order with (val > max) || isnan(val); padding never wins
+                if (in && (bi < 0 || v > best || v != v)) { best = v; bi = ky * k + kx; }
             }
         }
-        y[o] = best;
-        idx[o] = (uint8_t)bi;
+        y[nc * OH * OW + oy * OW + ox] = best;
+        idx[nc * OH * OW + oy * OW + ox] = (uint8_t)max(bi, 0);
     }
 }
 
+// gather-form backward over a 64x8 INPUT tile: the covering dy / argmax patch is staged in LDS
 __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                           const uint8_t* __restrict__ idx, float* __restrict__ dx,
-                                                          long total, int H, int W, int OH, int OW, int k, int s,
-                                                          int p) {
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const int ix = (int)(i % W);
-        const long t = i / W;
-        const int iy = (int)(t % H);
-        const long nc = t / H;
-        const float* dp = dy + nc * OH * OW;
-        const uint8_t* ip = idx + nc * OH * OW;
-        float g = 0.f;
-        // outputs oy with oy*s - p <= iy <= oy*s - p + k - 1
-        int oy_lo = (iy + p - k + 1 + s - 1);
-        oy_lo = oy_lo <= 0 ? 0 : oy_lo / s;
+                                                          int H, int W, int OH, int OW, int k, int s, int p, int pw,
+                                                          int ph) {
+    extern __shared__ float tile[];           // [ph*pw] dy  then  [ph*pw] idx (as int)
+    int* itile = reinterpret_cast<int*>(tile + pw * ph);
+    const size_t nc = blockIdx.z;
+    const float* dp = dy + nc * OH * OW;
+    const uint8_t* ip = idx + nc * OH * OW;
+    const int ix0 = blockIdx.x * MP_TW, iy0 = blockIdx.y * MP_TH;
+    // first output row/col that can cover the tile's first input row/col
+    int oy0 = iy0 + p - k + 1;
+    oy0 = oy0 <= 0 ? 0 : (oy0 + s - 1) / s;
+    int ox0 = ix0 + p - k + 1;
+    ox0 = ox0 <= 0 ? 0 : (ox0 + s - 1) / s;
+    for (int i = threadIdx.x; i < pw * ph; i += TPB) {
+        const int ly = i / pw, lx = i - ly * pw;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        const bool in = oy < OH && ox < OW;
+        tile[i] = in ? dp[oy * OW + ox] : 0.f;
+        itile[i] = in ? (int)ip[oy * OW + ox] : -1;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < MP_TW * MP_TH; o += TPB) {
+        const int ty = o / MP_TW, tx = o - ty * MP_TW;
+        const int iy = iy0 + ty, ix = ix0 + tx;
+        if (iy >= H || ix >= W) continue;
+        int oy_lo = iy + p - k + 1;
+        oy_lo = oy_lo <= 0 ? 0 : (oy_lo + s - 1) / s;
         const int oy_hi = min(OH - 1, (iy + p) / s);
-        int ox_lo = (ix + p - k + 1 + s - 1);
-        ox_lo = ox_lo <= 0 ? 0 : ox_lo / s;
+        int ox_lo = ix + p - k + 1;
+        ox_lo = ox_lo <= 0 ? 0 : (ox_lo + s - 1) / s;
         const int ox_hi = min(OW - 1, (ix + p) / s);
+        float g = 0.f;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             const int ky = iy - (oy * s - p);
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 const int kx = ix - (ox * s - p);
-                if (ip[oy * OW + ox] == ky * k + kx) g += dp[oy * OW + ox];
+                const int li = (oy - oy0) * pw + (ox - ox0);
+                if (itile[li] == ky * k + kx) g += tile[li];
             }
         }
-        dx[i] = g;
+        dx[nc * H * W + iy * W + ix] = g;
     }
 }
 
@@ -358,23 +388,24 @@ __global__ __launch_bounds__(TPB) void scale_label_kernel(const float* __restric
 
 extern "C" int jp_maxpool_fwd(const float* x, float* y, uint8_t* idx, int NC, int H, int W, int k, int s, int p,
                               void* stream) {
-    JP_CHECK_ARG(x && y && idx && NC > 0 && k >= 1 && k <= 15, "maxpool_fwd: bad args");
+    JP_CHECK_ARG(x && y && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_fwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
-    const long total = (long)NC * OH * OW;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, idx, total, H, W, OH, OW,
-                       k, s, p);
+    const int pw = (MP_TW - 1) * s + k, ph = (MP_TH - 1) * s + k;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(jp_cdiv(OW, MP_TW), jp_cdiv(OH, MP_TH), NC), dim3(TPB),
+                       sizeof(float) * pw * ph, st, x, y, idx, H, W, OH, OW, k, s, p);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int NC, int H, int W, int k, int s,
                               int p, void* stream) {
-    JP_CHECK_ARG(dy && dx && idx && NC > 0, "maxpool_bwd: bad args");
+    JP_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_bwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
-    const long total = (long)NC * H * W;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, dy, idx, dx, total, H, W, OH,
-                       OW, k, s, p);
+    // outputs that can cover a 64x8 input tile
+    const int pw = (MP_TW + k - 2) / s + 2, ph = (MP_TH + k - 2) / s + 2;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MP_TH), NC), dim3(TPB),
+                       2 * sizeof(float) * pw * ph, st, dy, idx, dx, H, W, OH, OW, k, s, p, pw, ph);
     JP_LAUNCH_CHECK();
 }
 
