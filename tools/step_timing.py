@@ -29,7 +29,15 @@ rec = []
 orig = _lib.call
 def timed(name, *a):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); orig(name, *a); e1.record(); rec.append((name, e0, e1))
+    e0.record(); orig(name, *a); e1.record()
+    key = name
+    if name == "jp_conv2d_fwd_src3":
+        key = "fwd   %4d->%4d k%d s%d @%4d fl=%.1f" % (a[1] + a[4] + a[7], a[15], a[16], a[17], a[13], 2e-9 * a[12] * (a[13] // a[17]) * (a[14] // a[17]) * a[15] * (a[1] + a[4] + a[7]) * a[16] ** 2)
+    elif name == "jp_conv2d_dgrad":
+        key = "dgrad %4d->%4d k%d s%d @%4d fl=%.1f" % (a[4], a[7], a[8], a[9], a[5], 2e-9 * a[3] * (a[5] // a[9]) * (a[6] // a[9]) * a[7] * a[4] * a[8] ** 2)
+    elif name == "jp_conv2d_wgrad_src3":
+        key = "wgrad %4d->%4d k%d s%d @%4d fl=%.1f" % (a[1] + a[4] + a[7], a[14], a[15], a[16], a[12], 2e-9 * a[11] * (a[12] // a[16]) * (a[13] // a[16]) * a[14] * (a[1] + a[4] + a[7]) * a[15] ** 2)
+    rec.append((key, e0, e1))
 for m in (ops, ops_loss, netmod, rt, mods):
     if hasattr(m, "call"): m.call = timed
 t0 = time.perf_counter(); runner.train_iter(batch); torch.cuda.synchronize(); wall = time.perf_counter() - t0
@@ -38,6 +46,9 @@ for n, e0, e1 in rec:
     agg[n][0] += 1; agg[n][1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in agg.values())
 print("instrumented step wall %.1f ms, sum of kernel events %.1f ms, %d launches" % (wall * 1e3, tot, len(rec)))
-for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
-    print("  %-28s %5d launches %10.2f ms  %5.1f%%" % (n, c, t, 100 * t / tot))
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOPN", "25"))]:
+    tf = ""
+    if "fl=" in n:
+        tf = "  %.1f TF" % (float(n.split("fl=")[1]) * c / t)
+    print("  %-44s %4d x %9.2f ms  %5.1f%%%s" % (n, c, t, 100 * t / tot, tf))
 print("max mem GB", torch.cuda.max_memory_allocated() / 2**30)
