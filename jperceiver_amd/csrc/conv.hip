@@ -19,6 +19,7 @@
 // the reduction channels are few (stems with 3/6 inputs, dgrad of the 1/2/6/16-channel heads).
 #include "igemm.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -338,42 +339,111 @@ struct FwdBT {  // B[k=(tap,ci)][n=pixel]
 
 struct DgradBTSt {
     InPixSt px;
-    const float* p;   // dY plane of the chunk's first channel (this image)
-    DyOffs d;         // o0 = main tap position; o1..o3 only ever set on reflect-padded border pixels
-    int n, extra;
+    const float* p;   // dY element (chunk's first channel) at the tap position
+    int n;
 };
 
+// main dgrad gather: the single dY entry reached through tap (ty,tx) by the *direct* (non-folded) path.
+// With reflection padding the extra folded-in entries of the 4 border-adjacent lines are added by a second,
+// tiny launch (DgradBorderB below), which keeps this hot loop as lean as the forward gather.
 template <int KH>
 struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     static constexpr bool ALONG_K = false;
     typedef DgradBTSt St;
     const float* dy;
     int Cp, Npix, H, W, Cout, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ void init(St& st, int p) const {
-        st = St{in_pix(p, Npix, H, W), nullptr, DyOffs{-1, -1, -1, -1}, 0, 0};
-    }
+    __device__ __forceinline__ void init(St& st, int p) const { st = St{in_pix(p, Npix, H, W), nullptr, 0}; }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
         const int tap = kc / Cp;
         const int co0 = kc - tap * Cp;
         const int ty = tap / KH, tx = tap - ty * KH;
         st.n = 0;
         if (!st.px.valid || co0 >= Cout) return;
-        st.d = dy_offsets(st.px.y, st.px.x, ty, tx, H, W, OH, OW, stride, pad, reflect);
-        st.extra = (st.d.o1 >= 0) | (st.d.o2 >= 0) | (st.d.o3 >= 0);
-        if (st.d.o0 < 0 && !st.extra) return;
-        st.p = dy + (size_t)(st.px.img * Cout + co0) * OH * OW;
+        int oy, ox;
+        if (reflect) {   // 3x3 stride 1 pad 1: direct path = padded row y+1, dY row y+1-ty
+            oy = st.px.y + 1 - ty;
+            ox = st.px.x + 1 - tx;
+            if ((unsigned)oy >= (unsigned)OH || (unsigned)ox >= (unsigned)OW) return;
+        } else {
+            const int ny = st.px.y + pad - ty, nx = st.px.x + pad - tx;
+            if (ny < 0 || nx < 0) return;
+            oy = ny / stride;
+            ox = nx / stride;
+            if (oy * stride != ny || ox * stride != nx || oy >= OH || ox >= OW) return;
+        }
+        st.p = dy + ((size_t)(st.px.img * Cout + co0) * OH + oy) * OW + ox;
+        st.n = min(32, Cout - co0);
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        return kl < st.n ? st.p[(size_t)kl * OH * OW] : 0.f;
+    }
+};
+
+// Border pass of the reflection-pad adjoint.  N enumerates the 2W+2H border-adjacent pixels of every image
+// (rows 1 and H-2, columns 1 and W-2; duplicates masked); the gather returns only the folded-in ("extra")
+// dY entries: row extras r1 = 0 (y==1, ty==0) / H-1 (y==H-2, ty==2), column extras likewise.
+struct DgradBorderSt {
+    InPixSt px;
+    const float* p;
+    int o1, o2, o3, n;
+};
+__device__ __forceinline__ InPixSt border_pix(int b, int Nb, int H, int W) {
+    InPixSt px;
+    const int per = 2 * W + 2 * H;
+    px.valid = b < Nb;
+    px.img = b / per;
+    const int i = b - px.img * per;
+    int y, x;
+    bool dup = false;
+    if (i < W) { y = 1; x = i; }
+    else if (i < 2 * W) { y = H - 2; x = i - W; dup = (H - 2 == 1); }
+    else if (i < 2 * W + H) { y = i - 2 * W; x = 1; dup = (y == 1 || y == H - 2); }
+    else { y = i - 2 * W - H; x = W - 2; dup = (y == 1 || y == H - 2) || (W - 2 == 1); }
+    px.y = y; px.x = x;
+    if (dup) px.valid = 0;
+    return px;
+}
+
+template <int KH>
+struct DgradBorderB {
+    static constexpr bool ALONG_K = false;
+    typedef DgradBorderSt St;
+    const float* dy;
+    int Cp, Nb, H, W, Cout;
+    __device__ __forceinline__ void init(St& st, int b) const { st = St{border_pix(b, Nb, H, W), nullptr, -1, -1, -1, 0}; }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int tap = kc / Cp;
+        const int co0 = kc - tap * Cp;
+        const int ty = tap / KH, tx = tap - ty * KH;
+        st.n = 0;
+        if (!st.px.valid || co0 >= Cout) return;
+        const DyOffs d = dy_offsets(st.px.y, st.px.x, ty, tx, H, W, H, W, 1, 1, 1);
+        if (d.o1 < 0 && d.o2 < 0 && d.o3 < 0) return;
+        st.o1 = d.o1; st.o2 = d.o2; st.o3 = d.o3;
+        st.p = dy + (size_t)(st.px.img * Cout + co0) * H * W;
         st.n = min(32, Cout - co0);
     }
     __device__ __forceinline__ float get(const St& st, int kl, int) const {
         if (kl >= st.n) return 0.f;
-        const float* q = st.p + (size_t)kl * OH * OW;
-        float v = st.d.o0 >= 0 ? q[st.d.o0] : 0.f;
-        if (st.extra) {   // reflect-padded border pixels only (wave-divergent at image edges)
-            if (st.d.o1 >= 0) v += q[st.d.o1];
-            if (st.d.o2 >= 0) v += q[st.d.o2];
-            if (st.d.o3 >= 0) v += q[st.d.o3];
-        }
+        const float* q = st.p + (size_t)kl * H * W;
+        float v = 0.f;
+        if (st.o1 >= 0) v += q[st.o1];
+        if (st.o2 >= 0) v += q[st.o2];
+        if (st.o3 >= 0) v += q[st.o3];
         return v;
+    }
+};
+
+struct DgradBorderEpi {  // dx[img][ci][y][x] += acc for the border pixel b
+    typedef long St;
+    float* dx;
+    int Cin, H, W, Nb;
+    __device__ __forceinline__ St col(int b) const {
+        const InPixSt px = border_pix(b, Nb, H, W);
+        return px.valid ? (long)px.img * Cin * H * W + px.y * W + px.x : -1;
+    }
+    __device__ __forceinline__ void put(St base, int m, float v) const {
+        if (base >= 0) dx[base + (size_t)m * H * W] += v;
     }
 };
 
@@ -486,7 +556,11 @@ constexpr int KC = 32;
 template <int WM, int WN, class A, class B, class E>
 void launch(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st) {
     dim3 grid(jp_cdiv(N, 64 * WN), jp_cdiv(M, 64 * WM), splits);
-    hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E>), grid, dim3(256), 0, st, a, b, e, M, N, K, kps);
+    static const int db = getenv("JP_IGEMM_DB") ? atoi(getenv("JP_IGEMM_DB")) : 0;
+    if (db)
+        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, true>), grid, dim3(256), 0, st, a, b, e, M, N, K, kps);
+    else
+        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false>), grid, dim3(256), 0, st, a, b, e, M, N, K, kps);
 }
 
 template <class A, class B, class E>
@@ -612,6 +686,12 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
             launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
         });
+        if (pad_mode == JP_PAD_REFLECT) {   // fold the reflected ring back in (border-adjacent lines only)
+            const int Nb = N * (2 * W + 2 * H);
+            DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
+            DgradBorderEpi be{dx, Cin, H, W, Nb};
+            launch_auto(a, bb, be, Cin, Nb, Kp, 1, Kp, st);
+        }
     } else {
         const int K = Cout * KH * KH;
         JP_KH_SWITCH(KH, {

@@ -22,15 +22,16 @@
 
 typedef float jp_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi>
+template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi, bool DB = false>
 __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi epi, int M, int N, int K,
                                                       int k_per_split) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA = BM + 1, LDB = BN + 1;
     constexpr int NA = BM * KC / 256, NB = BN * KC / 256;  // elements per thread per chunk
-    __shared__ float As[KC * LDA];
-    __shared__ float Bs[KC * LDB];
+    // DB: two LDS stages -> the next chunk is stored while the current one is consumed, one barrier per chunk
+    __shared__ float As[(DB ? 2 : 1) * KC * LDA];
+    __shared__ float Bs[(DB ? 2 : 1) * KC * LDB];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -77,16 +78,18 @@ __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi e
             for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, b_var_l + B_ROWS * r, r);
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int stage) {
+        float* Ad = As + stage * (KC * LDA);
+        float* Bd = Bs + stage * (KC * LDB);
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
-            if (ALoad::ALONG_K) As[a_fix_l * LDA + a_var_l + A_ROWS * r] = ra[r];
-            else As[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = ra[r];
+            if (ALoad::ALONG_K) Ad[a_fix_l * LDA + a_var_l + A_ROWS * r] = ra[r];
+            else Ad[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = ra[r];
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            if (BLoad::ALONG_K) Bs[b_fix_l * LDB + b_var_l + B_ROWS * r] = rb[r];
-            else Bs[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = rb[r];
+            if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = rb[r];
+            else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = rb[r];
         }
     };
 
@@ -102,21 +105,43 @@ __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi e
     const float* ap = As + lhi * LDA + wm * 64 + l31;
     const float* bp = Bs + lhi * LDB + wn * 64 + l31;
 
-    if (kbeg < kend) gload(kbeg);
-    for (int kc = kbeg; kc < kend; kc += KC) {
-        lstore();
-        __syncthreads();
-        if (kc + KC < kend) gload(kc + KC);  // in flight during the MFMAs below
+    auto compute = [&](int stage) {
+        const float* aq = ap + stage * (KC * LDA);
+        const float* bq = bp + stage * (KC * LDB);
 #pragma unroll 4
         for (int kk = 0; kk < KC; kk += 2) {
-            const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
-            const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
+            const float a0 = aq[kk * LDA], a1 = aq[kk * LDA + 32];
+            const float b0 = bq[kk * LDB], b1 = bq[kk * LDB + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+    };
+    if constexpr (DB) {
+        if (kbeg < kend) {
+            gload(kbeg);
+            lstore(0);
+        }
         __syncthreads();
+        int cur = 0;
+        for (int kc = kbeg; kc < kend; kc += KC) {
+            const bool more = kc + KC < kend;
+            if (more) gload(kc + KC);   // in flight during the MFMAs below
+            compute(cur);
+            if (more) lstore(cur ^ 1);  // the other stage was last read before the previous barrier
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        if (kbeg < kend) gload(kbeg);
+        for (int kc = kbeg; kc < kend; kc += KC) {
+            lstore(0);
+            __syncthreads();
+            if (kc + KC < kend) gload(kc + KC);  // in flight during the MFMAs below
+            compute(0);
+            __syncthreads();
+        }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
