@@ -97,10 +97,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        # "nccl" == RCCL over xGMI.  JP_DIST_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box.
+        dist.init_process_group(os.environ.get("JP_DIST_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     from jperceiver_amd import synthetic as syn, _lib
@@ -205,7 +206,7 @@ def measure_roofline(runner, batch, _lib):
     ms = sum(t for _, t in dom)
     ach = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-            "traffic": None, "kernel": "jp_igemm_kernel<2,2,32,FwdA,FwdB<3>,FwdEpi> (3x3 conv forward)",
+            "traffic": None, "kernel": "jp_igemm_kernel<*,*,32,PackA,FwdBT<3>,FwdEpi> (3x3 conv forward, Cout>64)",
             "launches": len(dom), "avg_launch_ms": round(ms / max(1, len(dom)), 4),
             "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 2)}
 

@@ -723,7 +723,9 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
     const int Cp = pad32(Cin), Np = fast ? KH * KH * Cp : Kw;
     const int tiles = jp_cdiv(Cout, Cout <= 64 ? 64 : 128) * jp_cdiv(Np, Cout <= 64 ? 256 : 128);
     // ~1k workgroups in flight, but at least 64 K-chunks per split so the 16k-atomic epilogue stays amortised
-    int splits = (int)std::min<long>(std::max(1, 1024 / std::max(1, tiles)), std::max<long>(1, npix / (64 * KC)));
+    static const int tgt_blocks = getenv("JP_WGRAD_BLOCKS") ? atoi(getenv("JP_WGRAD_BLOCKS")) : 512;
+    static const int min_chunks = getenv("JP_WGRAD_MINCHUNKS") ? atoi(getenv("JP_WGRAD_MINCHUNKS")) : 64;
+    int splits = (int)std::min<long>(std::max(1, tgt_blocks / std::max(1, tiles)), std::max<long>(1, npix / (min_chunks * KC)));
     int kps = jp_cdiv(jp_cdiv(npix, splits), KC) * KC;
     splits = jp_cdiv(npix, kps);
     WgradA a{dy, Cout, (int)npix, OH * OW};
