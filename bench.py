@@ -152,7 +152,8 @@ def main():
 
     log(f"{args.steps} timed steps: {ms:.1f} ms/step, {value:.2f} images/s")
     roof, cpu = None, None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the instrumented step (it contains the gradient all-reduce); rank 0 reports
         roof = measure_roofline(runner, batch, _lib)
         log(f"roofline: {roof}")
     if world > 1:
