@@ -151,6 +151,15 @@ def main():
     value = B * world * args.steps / dt
 
     log(f"{args.steps} timed steps: {ms:.1f} ms/step, {value:.2f} images/s")
+    if os.environ.get("JP_PMC_CALIB") and rank == 0:
+        # known-byte streaming copy (4 B/lane loads and stores, the igemm gather's access width) so that the
+        # FETCH_SIZE / WRITE_SIZE counters of a rocprofv3 --pmc pass can be calibrated (MI355X_MICROARCH.md §HBM)
+        n = 1 << 28
+        a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        for _ in range(3):
+            _lib.call("jp_axpby", a, None, b, n, 1.0, 0.0)
+        torch.cuda.synchronize()
+        del a, b
     roof, cpu = None, None
     if not args.no_roofline:
         # every rank runs the instrumented step (it contains the gradient all-reduce); rank 0 reports

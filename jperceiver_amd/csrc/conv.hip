@@ -283,12 +283,15 @@ struct PackA {  // A[m=row][k=(tap,c)] = wp[(tap*M + m)*Cp + c]
     static constexpr bool ALONG_K = true;
     typedef PackASt St;
     const float* wp;
-    int M, Kp, Cp;
+    int M, Kp, Cp, khw;
     __device__ __forceinline__ void init(St&, int, int) const {}
     __device__ __forceinline__ void fix(St& st, int k) const {
+        // K order = (channel chunk of 32, tap, channel in chunk): the 9 taps of one channel chunk are consecutive
+        // K-chunks, so the gathered input rows are re-read while still hot in L1/L2 instead of from the fabric
         st.valid = k < Kp;
-        const int tap = k / Cp;
-        st.off = (size_t)k + (size_t)tap * (size_t)(M - 1) * Cp;
+        const int q = k >> 5, cl = k & 31;
+        const int cc = q / khw, tap = q - cc * khw;
+        st.off = (size_t)tap * M * Cp + cc * 32 + cl;
     }
     __device__ __forceinline__ float get(const St& st, int m, int) const {
         return (st.valid && m < M) ? wp[st.off + (size_t)m * Cp] : 0.f;
@@ -310,8 +313,9 @@ struct FwdBT {  // B[k=(tap,ci)][n=pixel]
     int Cp, Npix, OH, OW, stride, pad, reflect;
     __device__ __forceinline__ void init(St& st, int p) const { st = St{conv_pix(p, Npix, OH, OW, stride, pad), nullptr, 0, 0}; }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
-        const int tap = kc / Cp;               // Cp % 32 == 0: the whole chunk shares one tap
-        const int ci0 = kc - tap * Cp;
+        const int q = kc >> 5;                 // chunk index = channel_chunk * taps + tap
+        const int cc = q / (KH * KH), tap = q - cc * (KH * KH);
+        const int ci0 = cc << 5;
         const int dy = tap / KH, dx = tap - dy * KH;
         int iy = st.px.iy0 + dy, ix = st.px.ix0 + dx;
         st.n = 0;
@@ -354,8 +358,9 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     int Cp, Npix, H, W, Cout, OH, OW, stride, pad, reflect;
     __device__ __forceinline__ void init(St& st, int p) const { st = St{in_pix(p, Npix, H, W), nullptr, 0}; }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
-        const int tap = kc / Cp;
-        const int co0 = kc - tap * Cp;
+        const int q = kc >> 5;
+        const int cc = q / (KH * KH), tap = q - cc * (KH * KH);
+        const int co0 = cc << 5;
         const int ty = tap / KH, tx = tap - ty * KH;
         st.n = 0;
         if (!st.px.valid || co0 >= Cout) return;
@@ -412,8 +417,9 @@ struct DgradBorderB {
     int Cp, Nb, H, W, Cout;
     __device__ __forceinline__ void init(St& st, int b) const { st = St{border_pix(b, Nb, H, W), nullptr, -1, -1, -1, 0}; }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
-        const int tap = kc / Cp;
-        const int co0 = kc - tap * Cp;
+        const int q = kc >> 5;
+        const int cc = q / (KH * KH), tap = q - cc * (KH * KH);
+        const int co0 = cc << 5;
         const int ty = tap / KH, tx = tap - ty * KH;
         st.n = 0;
         if (!st.px.valid || co0 >= Cout) return;
@@ -645,7 +651,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     if (ws && Cin >= 32 && seg_aligned(c0, c1, c2)) {   // tap-major fast path
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
-        PackA a{ws, Cout, Kp, Cp};
+        PackA a{ws, Cout, Kp, Cp, KH * KH};
         JP_KH_SWITCH(KH, {
             FwdBT<KH_> b{src, Cp, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
             launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
@@ -681,7 +687,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     if (ws && Cout >= 32) {
         const int Cp = pad32(Cout), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
-        PackA a{ws, Cin, Kp, Cp};
+        PackA a{ws, Cin, Kp, Cp, KH * KH};
         JP_KH_SWITCH(KH, {
             DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
             launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md §HBM /
+§rocprofv3 PMC slots prescribe) of `JP_PMC_CALIB=1 python bench.py ...` into per-launch HBM traffic of the
+dominant kernel.  The counters are calibrated on the known-byte streaming copy bench.py appends (axpby_kernel,
+4 B/lane accesses like the igemm gather): gfx950's FETCH_SIZE under-reports wide coalesced reads, so
+bytes = counter_KB * 1024 * (known copy bytes / counter_KB*1024 of the copy)."""
+import json
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, value, grid_size from counters_collection where counter_name=?", (counter,)).fetchall()
+    out = {}
+    for name, v, g in rows:
+        out.setdefault(name, []).append((v, g))
+    return out
+
+
+def main(fetch_db, write_db, out_json):
+    F, W = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    n = 1 << 28
+    copy = [k for k in F if "axpby_kernel" in k][0]
+    # the calibration launches are the three largest-grid axpby dispatches (1 GiB in, 1 GiB out each)
+    cf = sorted(F[copy], key=lambda t: -t[1])[:3]
+    cw = sorted(W[copy], key=lambda t: -t[1])[:3]
+    known = 4.0 * n
+    kf = known / (sum(v for v, _ in cf) / len(cf) * 1024.0)
+    kw = known / (sum(v for v, _ in cw) / len(cw) * 1024.0)
+    dom = [k for k in F if re.search(r"jp_igemm_kernel<2, 2, 32.*PackA.*FwdBT<3>", k)]
+    assert len(dom) == 1, dom
+    fv = [v for v, _ in F[dom[0]]]
+    wv = [v for v, _ in W[dom[0]]]
+    res = {
+        "kernel": re.sub(r"\(anonymous namespace\)::", "", dom[0])[:120],
+        "launches_profiled": len(fv),
+        "fetch_KB_raw_avg": sum(fv) / len(fv), "write_KB_raw_avg": sum(wv) / len(wv),
+        "calibration": {"copy_bytes_each_way": known, "fetch_factor": kf, "write_factor": kw,
+                        "copy_fetch_KB_raw": [v for v, _ in cf], "copy_write_KB_raw": [v for v, _ in cw]},
+    }
+    res["traffic_bytes_per_launch"] = (res["fetch_KB_raw_avg"] * kf + res["write_KB_raw_avg"] * kw) * 1024.0
+    json.dump(res, open(out_json, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
