@@ -203,7 +203,9 @@ def measure_roofline(runner, batch, _lib):
         e0.record()
         orig(name, *a)
         e1.record()
-        rec.append((KH, Cout, N * OH * OW, 2.0 * N * OH * OW * Cout * (c0 + c1 + c2) * KH * KH, e0, e1))
+        Cin = c0 + c1 + c2
+        alg_bytes = 4.0 * (N * Cin * H * W + N * Cout * OH * OW + Cout * Cin * KH * KH)   # read x once, write y once, read w
+        rec.append((KH, Cout, N * OH * OW, 2.0 * N * OH * OW * Cout * Cin * KH * KH, e0, e1, alg_bytes))
     from jperceiver_amd import ops
     ops.call = timed_call
     try:
@@ -211,12 +213,21 @@ def measure_roofline(runner, batch, _lib):
         torch.cuda.synchronize()
     finally:
         ops.call = orig
-    dom = [(f, e0.elapsed_time(e1)) for KH, Cout, npix, f, e0, e1 in rec if KH == 3 and Cout > 64 and npix > 64]
-    flops = sum(f for f, _ in dom)
-    ms = sum(t for _, t in dom)
+    dom = [(f, e0.elapsed_time(e1), ab) for KH, Cout, npix, f, e0, e1, ab in rec if KH == 3 and Cout > 64 and npix > 64]
+    flops = sum(f for f, _, _ in dom)
+    ms = sum(t for _, t, _ in dom)
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM/fabric bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    # in separate runs, FETCH_SIZE x2 per the gfx950 calibration; tools/pmc_traffic.py) — null if not profiled
+    traffic = None
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        traffic = round(json.load(open(f))["traffic_bytes_per_launch"])
+    except Exception:
+        pass
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-            "traffic": None, "kernel": "jp_igemm_kernel<*,*,32,PackA,FwdBT<3>,FwdEpi> (3x3 conv forward, Cout>64)",
+            "traffic": traffic, "algorithmic_bytes_per_launch": round(sum(ab for _, _, ab in dom) / max(1, len(dom))), "kernel": "jp_igemm_kernel<*,*,32,PackA,FwdBT<3>,FwdEpi> (3x3 conv forward, Cout>64)",
             "launches": len(dom), "avg_launch_ms": round(ms / max(1, len(dom)), 4),
             "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 2)}
 
