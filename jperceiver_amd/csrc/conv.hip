@@ -779,7 +779,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
     int splits, kps;
     // table path over a channel sub-range [cb, cb+cn) of a single full-resolution source
     auto run_table = [&](int cb, int cn) -> int {
-        const int Cp = pad32(cn), Np = KH * KH * Cp;
+        const int Cp = cn, Np = KH * KH * Cp;    // the slot tables need no channel padding
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cp) + 1u;
         plan(Np, &splits, &kps);
         WgradEpiT e{dw, Cp, cn, KH * KH, cb, Cin, magic};
@@ -790,7 +790,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         });
         return 0;
     };
-    if (Cin < 32 && !(single && Cin >= 1 && false)) {          // generic (channel-major) path: stems
+    if (!single && Cin < 32) {          // generic (channel-major) path: multi-source inputs with few channels
         WgradEpi e{dw, Kw};
         plan(Kw, &splits, &kps);
         JP_KH_SWITCH(KH, {
