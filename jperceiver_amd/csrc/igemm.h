@@ -22,7 +22,7 @@
 
 typedef float jp_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi, bool DB = false>
+template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi, bool DB = false, bool IL = false>
 __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi epi, int M, int N, int K,
                                                       int k_per_split) {
     static_assert(WM * WN == 4, "4 waves per block");
@@ -132,6 +132,44 @@ __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi e
             if (more) lstore(cur ^ 1);  // the other stage was last read before the previous barrier
             __syncthreads();
             cur ^= 1;
+        }
+    } else if constexpr (IL) {
+        // interleaved variant: the next chunk's gather (address VALU + global loads) is spread between the MFMAs of
+        // the current chunk, so the wave keeps feeding the matrix pipe while it does its integer work
+        constexpr int STEPS = KC / 2;
+        if (kbeg < kend) gload(kbeg);
+        for (int kc = kbeg; kc < kend; kc += KC) {
+            lstore(0);
+            __syncthreads();
+            const bool more = kc + KC < kend;
+            const int kn = kc + KC;
+            if (more) {
+                if constexpr (ALoad::ALONG_K) al.fix(sa, kn + a_fix_l); else al.chunk(sa, kn);
+                if constexpr (BLoad::ALONG_K) bl.fix(sb, kn + b_fix_l); else bl.chunk(sb, kn);
+            }
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                if (more) {
+#pragma unroll
+                    for (int r = s * NA / STEPS; r < (s + 1) * NA / STEPS; ++r) {
+                        if constexpr (ALoad::ALONG_K) ra[r] = al.get(sa, m0 + a_var_l + A_ROWS * r, r);
+                        else ra[r] = al.get(sa, a_var_l + A_ROWS * r, r);
+                    }
+#pragma unroll
+                    for (int r = s * NB / STEPS; r < (s + 1) * NB / STEPS; ++r) {
+                        if constexpr (BLoad::ALONG_K) rb[r] = bl.get(sb, n0 + b_var_l + B_ROWS * r, r);
+                        else rb[r] = bl.get(sb, b_var_l + B_ROWS * r, r);
+                    }
+                }
+                const int kk = 2 * s;
+                const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
+                const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
         }
     } else {
         if (kbeg < kend) gload(kbeg);
