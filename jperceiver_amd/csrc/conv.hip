@@ -464,7 +464,7 @@ struct WgradBT {  // B[k=pixel][n=(tap,ci)], any source layout (per-element deco
     __device__ __forceinline__ void fix(St& st, int p) const { st = conv_pix(p, Npix, OH, OW, stride, pad); }
     __device__ __forceinline__ float get(const St& st, int n, int) const {
         if (!st.valid || n >= Np) return 0.f;
-        const int tap = (int)__umulhi((unsigned)n, magic);
+        const int tap = (Cp == 1 ? n : (int)__umulhi((unsigned)n, magic));
         const int ci = n - tap * Cp;
         if (ci >= Cin) return 0.f;
         const int dy = tap / KH, dx = tap - dy * KH;
@@ -499,7 +499,7 @@ struct WgradBT1 {
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const int n = n_first + step * r;
-            const int tap = (int)__umulhi((unsigned)n, magic);
+            const int tap = (Cp == 1 ? n : (int)__umulhi((unsigned)n, magic));
             const int ci = n - tap * Cp;
             const int dy = tap / KH, dx = tap - dy * KH;
             st.off[r] = (n < Np && ci < Cin) ? ci * H * W : -1;
@@ -568,7 +568,7 @@ struct WgradEpiT {  // dw[co][c_off + ci][tap] += acc for n = tap*Cp + ci
     int Cp, Cin, KHW, c_off, Ctot;
     unsigned magic;
     __device__ __forceinline__ St col(int n) const {
-        const int tap = (int)__umulhi((unsigned)n, magic);
+        const int tap = (Cp == 1 ? n : (int)__umulhi((unsigned)n, magic));
         const int ci = n - tap * Cp;
         return ci < Cin ? (c_off + ci) * KHW + tap : -1;
     }

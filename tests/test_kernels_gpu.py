@@ -49,6 +49,10 @@ CONV_CASES = [
     (2, 512, 6, 20, 256, 1, 1, 0, 0, 1, True),      # pose reduce + relu
     (2, 200, 8, 8, 72, 3, 1, 1, 0, 0, True),        # odd channel counts, zero pad
     (1, 64, 70, 130, 64, 3, 1, 1, 0, 0, False),     # N-tile tail (pixels not multiple of 64)
+    (2, 129, 10, 14, 96, 3, 1, 1, 1, 2, True),      # 128-aligned wgrad path + 1-channel tail (the 513-channel iconv shape)
+    (1, 150, 9, 11, 80, 3, 1, 1, 0, 0, False),      # ... + 22-channel tail
+    (2, 256, 8, 8, 128, 3, 1, 1, 1, 0, True),       # uniform-tap wgrad, reflect
+    (2, 128, 6, 10, 72, 1, 1, 0, 0, 0, False),      # uniform-tap wgrad, 1x1
 ]
 
 
