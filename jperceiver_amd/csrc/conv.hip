@@ -117,6 +117,25 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     }
 };
 
+struct AtomicEpi {  // out[img][m][pix] += acc : split-K forward / dgrad on grids too small to fill the chip
+    typedef size_t St;
+    float* out;
+    int C, HW;
+    __device__ __forceinline__ St col(int p) const {
+        int img = p / HW;
+        return (size_t)img * C * HW + (p - img * HW);
+    }
+    __device__ __forceinline__ void put(St base, int m, float v) const { atomicAdd(out + base + (size_t)m * HW, v); }
+};
+
+__global__ void bias_act_nchw_kernel(float* __restrict__ y, const float* __restrict__ bias, long total, int C, int HW,
+                                     int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        y[i] = jp_act(y[i] + (bias ? bias[c] : 0.f), act);
+    }
+}
+
 struct MKSt {
     int m, kc;
 };
@@ -528,7 +547,7 @@ struct WgradBT1 {
 // (same cost as the forward gather, ~100 fewer VGPRs than the table version -> 3 waves/SIMD).
 struct WgradBUSt {
     const float* q;   // x element (first slot's channel) at this chunk's pixel shifted by the tile's tap
-    int dy, dx, c0, ok;
+    int dy, dx, c0, ok, step;
 };
 template <int KH>
 struct WgradBU {
@@ -536,7 +555,8 @@ struct WgradBU {
     typedef WgradBUSt St;
     const float* x;
     int Cpp, Cin, Ctot, H, W, Npix, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ void init(St& st, int n_first, int) const {
+    __device__ __forceinline__ void init(St& st, int n_first, int step) const {
+        st.step = step;
         const int tap = n_first / Cpp;          // Cpp % tile == 0: identical for every slot of the workgroup
         st.c0 = n_first - tap * Cpp;
         st.dy = tap / KH;
@@ -557,8 +577,8 @@ struct WgradBU {
         if (st.ok) st.q = x + ((size_t)(px.img * Ctot + st.c0) * H + iy) * W + ix;
     }
     __device__ __forceinline__ float get(const St& st, int, int r) const {
-        // slot r holds channel c0 + 8*r (8 = slot step of the lanes-along-K mapping)
-        return (st.ok && st.c0 + 8 * r < Cin) ? st.q[(size_t)(8 * r) * H * W] : 0.f;
+        // slot r holds channel c0 + step*r (step = slot stride of the lanes-along-K mapping)
+        return (st.ok && st.c0 + st.step * r < Cin) ? st.q[(size_t)(st.step * r) * H * W] : 0.f;
     }
 };
 
@@ -605,15 +625,18 @@ void launch(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t
     static const int il_env = getenv("JP_IGEMM_IL") ? atoi(getenv("JP_IGEMM_IL")) : -1;
     if (il_env >= 0) il = il_env != 0;
     if (il)
-        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, true>), grid, dim3(256), 0, st, a, b, e, M, N, K, kps);
+        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, true>), grid, dim3(64 * WM * WN), 0, st, a, b, e, M, N, K, kps);
     else
-        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, false>), grid, dim3(256), 0, st, a, b, e, M, N, K, kps);
+        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, false>), grid, dim3(64 * WM * WN), 0, st, a, b, e, M, N, K, kps);
 }
 
 template <class A, class B, class E>
 void launch_auto(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st, bool il = false) {
+    static const int big = getenv("JP_IGEMM_BIG") ? atoi(getenv("JP_IGEMM_BIG")) : 0;
     if (M <= 64) launch<1, 4>(a, b, e, M, N, K, splits, kps, st, il);
     else if (N <= 64) launch<4, 1>(a, b, e, M, N, K, splits, kps, st, il);
+    else if (big == 1 && M >= 256 && N >= 4096) launch<4, 2>(a, b, e, M, N, K, splits, kps, st, il);   // 8 waves, 256x128
+    else if (big == 2 && M >= 128 && N >= 4096) launch<2, 4>(a, b, e, M, N, K, splits, kps, st, il);   // 8 waves, 128x256
     else launch<2, 2>(a, b, e, M, N, K, splits, kps, st, il);
 }
 
@@ -628,6 +651,15 @@ Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1
 }
 
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
+// split-K factor for forward / dgrad launches whose tile grid cannot fill 256 CUs (pose encoder, 32x32 .. 6x20 maps)
+inline int small_grid_splits(int M, long N, int Kp) {
+    const int bm = M <= 64 ? 64 : (N <= 64 ? 256 : 128), bn = M <= 64 ? 256 : (N <= 64 ? 64 : 128);
+    const long tiles = (long)jp_cdiv(M, bm) * jp_cdiv(N, bn);
+    if (tiles >= 192) return 1;
+    const int chunks = Kp / KC;
+    int sp = (int)std::min<long>(jp_cdiv(512, tiles), chunks / 8);
+    return std::max(1, sp);
+}
 inline bool seg_aligned(int c0, int c1, int c2) {   // every segment end except the last is a multiple of 32
     if (c1 == 0 && c2 == 0) return true;
     if (c0 % 32) return false;
@@ -693,6 +725,22 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
         PackA a{ws, Cout, Kp, Cp, KH * KH};
+        const int sp = small_grid_splits(Cout, npix, Kp);
+        if (sp > 1) {
+            const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
+            JP_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)npix * Cout, st));
+            AtomicEpi ea{y, Cout, OH * OW};
+            JP_KH_SWITCH(KH, {
+                FwdBT<KH_> b{src, Cp, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+                launch_auto(a, b, ea, Cout, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+            });
+            if (bias || act != JP_ACT_NONE) {
+                const long total = npix * Cout;
+                hipLaunchKernelGGL(bias_act_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st,
+                                   y, bias, total, Cout, OH * OW, act);
+            }
+            JP_LAUNCH_CHECK();
+        }
         JP_KH_SWITCH(KH, {
             FwdBT<KH_> b{src, Cp, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
             launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
@@ -729,10 +777,21 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         const int Cp = pad32(Cout), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
         PackA a{ws, Cin, Kp, Cp, KH * KH};
-        JP_KH_SWITCH(KH, {
-            DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-            launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
-        });
+        const int sp = small_grid_splits(Cin, npix, Kp);
+        if (sp > 1) {
+            const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
+            if (!accumulate) JP_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)npix * Cin, st));
+            AtomicEpi ea{dx, Cin, H * W};
+            JP_KH_SWITCH(KH, {
+                DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+                launch_auto(a, b, ea, Cin, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+            });
+        } else {
+            JP_KH_SWITCH(KH, {
+                DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+                launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
+            });
+        }
         if (pad_mode == JP_PAD_REFLECT) {   // fold the reflected ring back in (border-adjacent lines only)
             const int Nb = N * (2 * W + 2 * H);
             DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};

@@ -2,7 +2,7 @@
 // with pluggable gather-loaders for A and B and a pluggable epilogue.  conv2d forward, dgrad and
 // wgrad and the 1x1 convs are all instances of this kernel (conv.hip).
 //
-// Geometry: 256 threads = 4 wave64.  Every wave owns a 64x64 output tile as 2x2
+// Geometry: 4 or 8 wave64 per workgroup.  Every wave owns a 64x64 output tile as 2x2
 // v_mfma_f32_32x32x2_f32 accumulators (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak, guide
 // cdna_hip_programming.md §3).  Block tile = (64*WM) x (64*WN), WM*WN == 4.  The K loop is chunked
 // by KC; each chunk is gathered global->registers (prefetched one chunk ahead, so the loads fly
@@ -23,12 +23,13 @@
 typedef float jp_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi, bool DB = false, bool IL = false>
-__global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi epi, int M, int N, int K,
-                                                      int k_per_split) {
-    static_assert(WM * WN == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad bl, Epi epi, int M, int N, int K,
+                                                               int k_per_split) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per block");
+    constexpr int NT = 64 * WM * WN;             // threads per workgroup
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDA = BM + 1, LDB = BN + 1;
-    constexpr int NA = BM * KC / 256, NB = BN * KC / 256;  // elements per thread per chunk
+    constexpr int NA = BM * KC / NT, NB = BN * KC / NT;  // elements per thread per chunk
     // DB: two LDS stages -> the next chunk is stored while the current one is consumed, one barrier per chunk
     __shared__ float As[(DB ? 2 : 1) * KC * LDA];
     __shared__ float Bs[(DB ? 2 : 1) * KC * LDB];
@@ -44,8 +45,9 @@ __global__ __launch_bounds__(256) void jp_igemm_kernel(ALoad al, BLoad bl, Epi e
     // ---- loader thread mappings
     // ALONG_K  : kk = t % KC, mn = t / KC + (256/KC) * r
     // ALONG_MN : mn = t % B,  kk = t / B + (256/B) * r      (B <= 256)
-    constexpr int A_ROWS = ALoad::ALONG_K ? (256 / KC) : (256 / BM);
-    constexpr int B_ROWS = BLoad::ALONG_K ? (256 / KC) : (256 / BN);
+    constexpr int A_ROWS = ALoad::ALONG_K ? (NT / KC) : (NT / BM);
+    constexpr int B_ROWS = BLoad::ALONG_K ? (NT / KC) : (NT / BN);
+    static_assert(BM <= NT && BN <= NT, "lanes-along-m/n mapping needs tile width <= threads");
     const int a_fix_l = ALoad::ALONG_K ? (t % KC) : (t % BM);
     const int a_var_l = ALoad::ALONG_K ? (t / KC) : (t / BM);
     const int b_fix_l = BLoad::ALONG_K ? (t % KC) : (t % BN);
