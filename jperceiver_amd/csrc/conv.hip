@@ -833,6 +833,8 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         // ~2 workgroups per CU, but at least 64 K-chunks per split so the 16k-atomic epilogue stays amortised
         const int tiles = jp_cdiv(Cout, Cout <= 64 ? 64 : 128) * jp_cdiv(Np, Cout <= 64 ? 256 : 128);
         int sp = (int)std::min<long>(std::max(1, tgt_blocks / std::max(1, tiles)), std::max<long>(1, npix / (min_chunks * KC)));
+        if ((long)sp * tiles < 256)   // tiny maps (pose encoder): filling the chip matters more than epilogue amortisation
+            sp = (int)std::min<long>(std::max(1, tgt_blocks / std::max(1, tiles)), std::max<long>(1, npix / (8 * KC)));
         *kps = jp_cdiv(jp_cdiv(npix, sp), KC) * KC;
         *splits = jp_cdiv(npix, *kps);
     };
