@@ -23,6 +23,10 @@
 
 namespace {
 
+// Masked-out gathers read this word instead of branching around the load: the gather stays a straight run of
+// unconditional global loads (no exec-mask save/restore per element).
+__device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct Src3 {  // input as up to 3 channel segments, each optionally stored at half resolution
     const float *p0, *p1, *p2;
     int e0, e1, e2;     // cumulative channel ends
@@ -295,75 +299,102 @@ struct WgradEpi {  // dw[co][j] += acc   (split-K partials meet in L2 atomics)
 // =============================================================== tap-major ("T") fast-path loaders
 // packed weights wp[tap][row][Cp] (row = co for forward, ci for dgrad; Cp = reduction channels padded to 32)
 struct PackASt {
-    size_t off;
-    int valid;
+    const float* base;   // wave-uniform: (tap, channel chunk) corner of the packed weights
+    unsigned voff;       // per-lane byte offset: (row within the 8-row group, channel within the chunk)
 };
 struct PackA {  // A[m=row][k=(tap,c)] = wp[(tap*M + m)*Cp + c]
     static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
     typedef PackASt St;
     const float* wp;
     int M, Kp, Cp, khw;
-    __device__ __forceinline__ void init(St&, int, int) const {}
+    __device__ __forceinline__ void init(St& st, int, int) const {
+        st.base = wp;
+        st.voff = ((threadIdx.x >> 5) * Cp + (threadIdx.x & 31)) * 4u;
+    }
     __device__ __forceinline__ void fix(St& st, int k) const {
         // K order = (channel chunk of 32, tap, channel in chunk): the 9 taps of one channel chunk are consecutive
         // K-chunks, so the gathered input rows are re-read while still hot in L1/L2 instead of from the fabric
-        st.valid = k < Kp;
-        const int q = k >> 5, cl = k & 31;
+        const int q = __builtin_amdgcn_readfirstlane(k >> 5);
         const int cc = q / khw, tap = q - cc * khw;
-        st.off = (size_t)tap * M * Cp + cc * 32 + cl;
+        st.base = wp + (size_t)tap * M * Cp + cc * 32;
     }
-    __device__ __forceinline__ float get(const St& st, int m, int) const {
-        return (st.valid && m < M) ? wp[st.off + (size_t)m * Cp] : 0.f;
+    // rows >= M are not masked: they read the next tap's rows (or the scratch slack after the last tap, see
+    // jp_conv2d_ws_floats) and the epilogue never stores them.  Kp is a multiple of KC.
+    __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
+        const float* rp = st.base + (size_t)m_u * Cp;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
 };
 
 struct FwdBTSt {
-    PixSt px;
-    const float* p;   // element (chunk's first channel, this pixel, this tap)
-    int cs;           // channel stride of the selected source segment
-    int n;            // valid channels in this chunk (0 = nothing to load)
+    int img_rel, iy0, ix0;   // per-lane: image relative to the block's first image, top-left tap coordinate
+    int img0;                // uniform: image of the block's first pixel
+    const float* rowp;       // uniform: plane (segment, img0, first channel of the chunk)
+    unsigned voff;           // per-lane byte offset of (relative image, tap position) from rowp
+    int hw, nm1;             // uniform: plane size of the segment; valid channels in this chunk - 1
+    int ok;                  // per-lane, zero padding only: the tap lies inside the image
 };
 
-template <int KH>
+template <int KH, bool REFLECT>
 struct FwdBT {  // B[k=(tap,ci)][n=pixel]
     static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
     typedef FwdBTSt St;
     Src3 src;
-    int Cp, Npix, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ void init(St& st, int p) const { st = St{conv_pix(p, Npix, OH, OW, stride, pad), nullptr, 0, 0}; }
+    int Cp, Npix, OH, OW, stride, pad;
+    __device__ __forceinline__ void init(St& st, int p, int p0) const {
+        const int ohw = OH * OW;
+        p = min(p, Npix - 1);          // columns >= N are computed on a duplicate pixel and never stored
+        const int img = p / ohw, pix = p - img * ohw;
+        const int oy = pix / OW, ox = pix - oy * OW;
+        st.img0 = min(p0, Npix - 1) / ohw;
+        st.img_rel = img - st.img0;
+        st.iy0 = oy * stride - pad;
+        st.ix0 = ox * stride - pad;
+        st.rowp = src.p0;
+        st.voff = 0;
+        st.hw = 0;
+        st.nm1 = 0;
+        st.ok = 1;
+    }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
         const int q = kc >> 5;                 // chunk index = channel_chunk * taps + tap
         const int cc = q / (KH * KH), tap = q - cc * (KH * KH);
         const int ci0 = cc << 5;
         const int dy = tap / KH, dx = tap - dy * KH;
-        int iy = st.px.iy0 + dy, ix = st.px.ix0 + dx;
-        st.n = 0;
-        if (!st.px.valid || ci0 >= src.e2) return;
-        if (reflect) {
+        int iy = st.iy0 + dy, ix = st.ix0 + dx;
+        if (REFLECT) {
             iy = jp_reflect(iy, src.H);
             ix = jp_reflect(ix, src.W);
-        } else if ((unsigned)iy >= (unsigned)src.H || (unsigned)ix >= (unsigned)src.W) {
-            return;
+        } else {
+            st.ok = (unsigned)iy < (unsigned)src.H && (unsigned)ix < (unsigned)src.W;
+            iy = min(max(iy, 0), src.H - 1);
+            ix = min(max(ix, 0), src.W - 1);
         }
         const bool a = ci0 < src.e0, b = ci0 < src.e1;   // segment ends are multiples of 32 (host-checked)
         const float* p = a ? src.p0 : (b ? src.p1 : src.p2);
         const int c0 = a ? 0 : (b ? src.e0 : src.e1);
         const int ce = a ? src.e0 : (b ? src.e1 : src.e2);
         const int sh = a ? src.s0 : (b ? src.s1 : src.s2);
-        const int h = src.H >> sh, w = src.W >> sh;
-        st.cs = h * w;
-        st.p = p + ((size_t)(st.px.img * (ce - c0) + (ci0 - c0)) * h + (iy >> sh)) * w + (ix >> sh);
-        st.n = min(32, ce - ci0);
+        const int h = src.H >> sh, w = src.W >> sh, Cs = ce - c0;
+        st.hw = h * w;
+        st.voff = (unsigned)((st.img_rel * Cs * h + (iy >> sh)) * w + (ix >> sh)) * 4u;
+        st.rowp = p + (size_t)(st.img0 * Cs + (ci0 - c0)) * st.hw;
+        st.nm1 = min(32, ce - ci0) - 1;       // rows beyond are clamped: their packed weights are zero
     }
-    __device__ __forceinline__ float get(const St& st, int kl, int) const {
-        return kl < st.n ? st.p[(size_t)kl * st.cs] : 0.f;
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {   // kl is wave-uniform
+        const float* rp = st.rowp + (size_t)min(kl, st.nm1) * st.hw;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    __device__ __forceinline__ float post(const St& st, float v) const { return (REFLECT || st.ok) ? v : 0.f; }
 };
 
 struct DgradBTSt {
-    InPixSt px;
-    const float* p;   // dY element (chunk's first channel) at the tap position
-    int n;
+    int img_rel, y, x, img0;
+    const float* rowp;   // uniform: dY plane (img0, first output channel of the chunk)
+    unsigned voff;       // per-lane byte offset of (relative image, tap position)
+    int nm1, ok;
 };
 
 // main dgrad gather: the single dY entry reached through tap (ty,tx) by the *direct* (non-folded) path.
@@ -372,35 +403,52 @@ struct DgradBTSt {
 template <int KH>
 struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
     typedef DgradBTSt St;
     const float* dy;
     int Cp, Npix, H, W, Cout, OH, OW, stride, pad, reflect;
-    __device__ __forceinline__ void init(St& st, int p) const { st = St{in_pix(p, Npix, H, W), nullptr, 0}; }
+    __device__ __forceinline__ void init(St& st, int p, int p0) const {
+        const int hw = H * W;
+        p = min(p, Npix - 1);
+        const int img = p / hw, pix = p - img * hw;
+        st.y = pix / W;
+        st.x = pix - st.y * W;
+        st.img0 = min(p0, Npix - 1) / hw;
+        st.img_rel = img - st.img0;
+        st.rowp = dy;
+        st.voff = 0;
+        st.nm1 = 0;
+        st.ok = 0;
+    }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
         const int q = kc >> 5;
         const int cc = q / (KH * KH), tap = q - cc * (KH * KH);
         const int co0 = cc << 5;
         const int ty = tap / KH, tx = tap - ty * KH;
-        st.n = 0;
-        if (!st.px.valid || co0 >= Cout) return;
-        int oy, ox;
+        int oy, ox, ok;
         if (reflect) {   // 3x3 stride 1 pad 1: direct path = padded row y+1, dY row y+1-ty
-            oy = st.px.y + 1 - ty;
-            ox = st.px.x + 1 - tx;
-            if ((unsigned)oy >= (unsigned)OH || (unsigned)ox >= (unsigned)OW) return;
+            oy = st.y + 1 - ty;
+            ox = st.x + 1 - tx;
+            ok = 1;
         } else {
-            const int ny = st.px.y + pad - ty, nx = st.px.x + pad - tx;
-            if (ny < 0 || nx < 0) return;
+            const int ny = st.y + pad - ty, nx = st.x + pad - tx;
             oy = ny / stride;
             ox = nx / stride;
-            if (oy * stride != ny || ox * stride != nx || oy >= OH || ox >= OW) return;
+            ok = ny >= 0 && nx >= 0 && oy * stride == ny && ox * stride == nx;
         }
-        st.p = dy + ((size_t)(st.px.img * Cout + co0) * OH + oy) * OW + ox;
-        st.n = min(32, Cout - co0);
+        st.ok = ok && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+        oy = min(max(oy, 0), OH - 1);
+        ox = min(max(ox, 0), OW - 1);
+        const int ohw = OH * OW;
+        st.voff = (unsigned)(st.img_rel * Cout * ohw + oy * OW + ox) * 4u;
+        st.rowp = dy + (size_t)(st.img0 * Cout + co0) * ohw;
+        st.nm1 = min(32, Cout - co0) - 1;
     }
-    __device__ __forceinline__ float get(const St& st, int kl, int) const {
-        return kl < st.n ? st.p[(size_t)kl * OH * OW] : 0.f;
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {   // kl is wave-uniform
+        const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (OH * OW);
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    __device__ __forceinline__ float post(const St& st, float v) const { return st.ok ? v : 0.f; }
 };
 
 // Border pass of the reflection-pad adjoint.  N enumerates the 2W+2H border-adjacent pixels of every image
@@ -618,26 +666,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 constexpr int KC = 32;
 
-template <int WM, int WN, class A, class B, class E>
-void launch(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st, bool il = false) {
+// IL: gather interleaved with the MFMAs (measured +6 % on wgrad, -6 % on fwd/dgrad -> wgrad only)
+template <bool IL, int WM, int WN, class A, class B, class E>
+void launch(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st) {
     dim3 grid(jp_cdiv(N, 64 * WN), jp_cdiv(M, 64 * WM), splits);
-    // il: gather interleaved with the MFMAs (measured +6 % on wgrad, -6 % on fwd/dgrad -> wgrad only)
-    static const int il_env = getenv("JP_IGEMM_IL") ? atoi(getenv("JP_IGEMM_IL")) : -1;
-    if (il_env >= 0) il = il_env != 0;
-    if (il)
-        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, true>), grid, dim3(64 * WM * WN), 0, st, a, b, e, M, N, K, kps);
-    else
-        hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, false>), grid, dim3(64 * WM * WN), 0, st, a, b, e, M, N, K, kps);
+    hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, IL>), grid, dim3(64 * WM * WN), 0, st, a, b, e, M, N, K, kps);
 }
 
-template <class A, class B, class E>
-void launch_auto(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st, bool il = false) {
-    static const int big = getenv("JP_IGEMM_BIG") ? atoi(getenv("JP_IGEMM_BIG")) : 0;
-    if (M <= 64) launch<1, 4>(a, b, e, M, N, K, splits, kps, st, il);
-    else if (N <= 64) launch<4, 1>(a, b, e, M, N, K, splits, kps, st, il);
-    else if (big == 1 && M >= 256 && N >= 4096) launch<4, 2>(a, b, e, M, N, K, splits, kps, st, il);   // 8 waves, 256x128
-    else if (big == 2 && M >= 128 && N >= 4096) launch<2, 4>(a, b, e, M, N, K, splits, kps, st, il);   // 8 waves, 128x256
-    else launch<2, 2>(a, b, e, M, N, K, splits, kps, st, il);
+template <bool IL = false, class A, class B, class E>
+void launch_auto(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st) {
+    if (M <= 64) launch<IL, 1, 4>(a, b, e, M, N, K, splits, kps, st);
+    else if (N <= 64) launch<IL, 4, 1>(a, b, e, M, N, K, splits, kps, st);
+    else launch<IL, 2, 2>(a, b, e, M, N, K, splits, kps, st);
 }
 
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
@@ -697,8 +737,9 @@ static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
 // floats of caller-owned scratch for the packed-weight fast path (0 = the generic path will be used).
 // which: 0 forward, 1 dgrad, 2 wgrad
 extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
-    if (which == 0) return Cin >= 32 ? (long)KH * KH * Cout * pad32(Cin) : 0;
-    if (which == 1) return Cout >= 32 ? (long)KH * KH * Cin * pad32(Cout) : 0;
+    // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
+    if (which == 0) return Cin >= 32 ? ((long)KH * KH * Cout + 256) * pad32(Cin) : 0;
+    if (which == 1) return Cout >= 32 ? ((long)KH * KH * Cin + 256) * pad32(Cout) : 0;
     return 0;
 }
 
@@ -731,8 +772,13 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             JP_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)npix * Cout, st));
             AtomicEpi ea{y, Cout, OH * OW};
             JP_KH_SWITCH(KH, {
-                FwdBT<KH_> b{src, Cp, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-                launch_auto(a, b, ea, Cout, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+                if (pad_mode == JP_PAD_REFLECT) {
+                    FwdBT<KH_, true> b{src, Cp, (int)npix, OH, OW, stride, pad};
+                    launch_auto(a, b, ea, Cout, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+                } else {
+                    FwdBT<KH_, false> b{src, Cp, (int)npix, OH, OW, stride, pad};
+                    launch_auto(a, b, ea, Cout, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+                }
             });
             if (bias || act != JP_ACT_NONE) {
                 const long total = npix * Cout;
@@ -742,8 +788,13 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             JP_LAUNCH_CHECK();
         }
         JP_KH_SWITCH(KH, {
-            FwdBT<KH_> b{src, Cp, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-            launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+            if (pad_mode == JP_PAD_REFLECT) {
+                FwdBT<KH_, true> b{src, Cp, (int)npix, OH, OW, stride, pad};
+                launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+            } else {
+                FwdBT<KH_, false> b{src, Cp, (int)npix, OH, OW, stride, pad};
+                launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+            }
         });
     } else {
         const int K = Cin * KH * KH;
@@ -849,7 +900,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         JP_KH_SWITCH(KH, {
             WgradBT1<KH_> b{x0 + (size_t)cb * H * W, Np, Cp, cn, Cin, H, W, (int)npix, OH, OW, stride, pad,
                             pad_mode == JP_PAD_REFLECT, magic};
-            launch_auto(a, b, e, Cout, Np, (int)npix, splits, kps, st, true);
+            launch_auto<true>(a, b, e, Cout, Np, (int)npix, splits, kps, st);
         });
         return 0;
     };
@@ -858,7 +909,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         plan(Kw, &splits, &kps);
         JP_KH_SWITCH(KH, {
             WgradB<KH_> b{src, Kw, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-            launch_auto(a, b, e, Cout, Kw, (int)npix, splits, kps, st, true);
+            launch_auto<true>(a, b, e, Cout, Kw, (int)npix, splits, kps, st);
         });
     } else if (single && Cout > 64 && Cin >= 128 && (Cin % 128 == 0 || Cin % 128 <= 32)) {
         // uniform-tap path on the 128-aligned part (+ a table pass for a short channel tail, e.g. 513 = 512 + 1)
@@ -869,7 +920,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         WgradEpiT e{dw, Cm, Cm, KH * KH, 0, Cin, magic};
         JP_KH_SWITCH(KH, {
             WgradBU<KH_> b{x0, Cm, Cm, Cin, H, W, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-            launch<2, 2>(a, b, e, Cout, Np, (int)npix, splits, kps, st, true);
+            launch<true, 2, 2>(a, b, e, Cout, Np, (int)npix, splits, kps, st);
         });
         if (tail) {
             const int rc = run_table(Cm, tail);
@@ -885,7 +936,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         WgradEpiT e{dw, Cp, Cin, KH * KH, 0, Cin, magic};
         JP_KH_SWITCH(KH, {
             WgradBT<KH_> b{src, Np, Cp, Cin, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT, magic};
-            launch_auto(a, b, e, Cout, Np, (int)npix, splits, kps, st, true);
+            launch_auto<true>(a, b, e, Cout, Np, (int)npix, splits, kps, st);
         });
     }
     JP_LAUNCH_CHECK();

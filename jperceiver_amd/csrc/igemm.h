@@ -17,8 +17,21 @@
 //   ALONG_MN loader (lanes run along m/n): init(st, mn)                  once      -> decode this thread's m/n
 //                                          chunk(st, kc)                 per chunk -> chunk-uniform part
 //                                          get(st, kl, r)                per element (kl = k - kc)
+//
+// Scalar-base loaders (SPLIT / POST below): a loader may split every address into a wave-uniform 64-bit base
+// (SGPRs, advanced with SALU) plus a per-lane 32-bit byte offset that is constant over a chunk, so a gathered
+// element costs one global_load_dword (saddr form) and zero VALU -- the VALU port is what the MFMA stream
+// shares.  ALONG_K loaders flag it with SPLIT and implement get_u(st, uniform_mn, r); ALONG_MN loaders get a
+// wave-uniform k row for free (tile widths are multiples of 64).  POST loaders mask a loaded value when it is
+// stored to LDS (zero padding) instead of branching around the load.
 #pragma once
 #include "jp_common.h"
+#include <type_traits>
+
+template <class L, class = void> struct jp_has_post : std::false_type {};
+template <class L> struct jp_has_post<L, std::void_t<decltype(L::POST)>> : std::true_type {};
+template <class L, class = void> struct jp_has_split : std::false_type {};
+template <class L> struct jp_has_split<L, std::void_t<decltype(L::SPLIT)>> : std::true_type {};
 
 typedef float jp_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -49,49 +62,61 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
     constexpr int B_ROWS = BLoad::ALONG_K ? (NT / KC) : (NT / BN);
     static_assert(BM <= NT && BN <= NT, "lanes-along-m/n mapping needs tile width <= threads");
     const int a_fix_l = ALoad::ALONG_K ? (t % KC) : (t % BM);
-    const int a_var_l = ALoad::ALONG_K ? (t / KC) : (t / BM);
+    const int a_var_l = ALoad::ALONG_K ? (t / KC) : __builtin_amdgcn_readfirstlane(t / BM);   // wave-uniform
     const int b_fix_l = BLoad::ALONG_K ? (t % KC) : (t % BN);
-    const int b_var_l = BLoad::ALONG_K ? (t / KC) : (t / BN);
+    const int b_var_l = BLoad::ALONG_K ? (t / KC) : __builtin_amdgcn_readfirstlane(t / BN);
     typename ALoad::St sa;
     typename BLoad::St sb;
     if constexpr (ALoad::ALONG_K) al.init(sa, m0 + a_var_l, A_ROWS);
+    else if constexpr (jp_has_post<ALoad>::value) al.init(sa, m0 + a_fix_l, m0);
     else al.init(sa, m0 + a_fix_l);
     if constexpr (BLoad::ALONG_K) bl.init(sb, n0 + b_var_l, B_ROWS);
+    else if constexpr (jp_has_post<BLoad>::value) bl.init(sb, n0 + b_fix_l, n0);
     else bl.init(sb, n0 + b_fix_l);
 
     float ra[NA], rb[NB];
-    auto gload = [&](int kc) {
+    auto getA = [&](int r) -> float {
         if constexpr (ALoad::ALONG_K) {
-            al.fix(sa, kc + a_fix_l);
-#pragma unroll
-            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, m0 + a_var_l + A_ROWS * r, r);
+            if constexpr (jp_has_split<ALoad>::value) return al.get_u(sa, m0 + A_ROWS * r, r);
+            else return al.get(sa, m0 + a_var_l + A_ROWS * r, r);
         } else {
-            al.chunk(sa, kc);
-#pragma unroll
-            for (int r = 0; r < NA; ++r) ra[r] = al.get(sa, a_var_l + A_ROWS * r, r);
+            return al.get(sa, a_var_l + A_ROWS * r, r);
         }
+    };
+    auto getB = [&](int r) -> float {
         if constexpr (BLoad::ALONG_K) {
-            bl.fix(sb, kc + b_fix_l);
-#pragma unroll
-            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, n0 + b_var_l + B_ROWS * r, r);
+            if constexpr (jp_has_split<BLoad>::value) return bl.get_u(sb, n0 + B_ROWS * r, r);
+            else return bl.get(sb, n0 + b_var_l + B_ROWS * r, r);
         } else {
-            bl.chunk(sb, kc);
-#pragma unroll
-            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, b_var_l + B_ROWS * r, r);
+            return bl.get(sb, b_var_l + B_ROWS * r, r);
         }
+    };
+    auto gload = [&](int kc) {
+        if constexpr (ALoad::ALONG_K) al.fix(sa, kc + a_fix_l);
+        else al.chunk(sa, kc);
+#pragma unroll
+        for (int r = 0; r < NA; ++r) ra[r] = getA(r);
+        if constexpr (BLoad::ALONG_K) bl.fix(sb, kc + b_fix_l);
+        else bl.chunk(sb, kc);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) rb[r] = getB(r);
     };
     auto lstore = [&](int stage) {
         float* Ad = As + stage * (KC * LDA);
         float* Bd = Bs + stage * (KC * LDB);
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
-            if (ALoad::ALONG_K) Ad[a_fix_l * LDA + a_var_l + A_ROWS * r] = ra[r];
-            else Ad[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = ra[r];
+            float v = ra[r];
+            if constexpr (jp_has_post<ALoad>::value) v = al.post(sa, v);
+            if (ALoad::ALONG_K) Ad[a_fix_l * LDA + a_var_l + A_ROWS * r] = v;
+            else Ad[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = v;
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = rb[r];
-            else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = rb[r];
+            float v = rb[r];
+            if constexpr (jp_has_post<BLoad>::value) v = bl.post(sb, v);
+            if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = v;
+            else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = v;
         }
     };
 
@@ -110,14 +135,21 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
     auto compute = [&](int stage) {
         const float* aq = ap + stage * (KC * LDA);
         const float* bq = bp + stage * (KC * LDB);
+        // operands of step kk+2 are read from LDS before the MFMAs of step kk issue (the scheduling barriers keep
+        // the compiler from re-serialising read -> wait -> MFMA), so the LDS latency hides under the matrix pipe
+        float a0 = aq[0], a1 = aq[32], b0 = bq[0], b1 = bq[32];
 #pragma unroll 4
         for (int kk = 0; kk < KC; kk += 2) {
-            const float a0 = aq[kk * LDA], a1 = aq[kk * LDA + 32];
-            const float b0 = bq[kk * LDB], b1 = bq[kk * LDB + 32];
+            const int kn = kk + 2 < KC ? kk + 2 : kk;   // the last step re-reads its own operands (unused)
+            const float na0 = aq[kn * LDA], na1 = aq[kn * LDA + 32];
+            const float nb0 = bq[kn * LDB], nb1 = bq[kn * LDB + 32];
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
     };
     if constexpr (DB) {
@@ -153,15 +185,9 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
             for (int s = 0; s < STEPS; ++s) {
                 if (more) {
 #pragma unroll
-                    for (int r = s * NA / STEPS; r < (s + 1) * NA / STEPS; ++r) {
-                        if constexpr (ALoad::ALONG_K) ra[r] = al.get(sa, m0 + a_var_l + A_ROWS * r, r);
-                        else ra[r] = al.get(sa, a_var_l + A_ROWS * r, r);
-                    }
+                    for (int r = s * NA / STEPS; r < (s + 1) * NA / STEPS; ++r) ra[r] = getA(r);
 #pragma unroll
-                    for (int r = s * NB / STEPS; r < (s + 1) * NB / STEPS; ++r) {
-                        if constexpr (BLoad::ALONG_K) rb[r] = bl.get(sb, n0 + b_var_l + B_ROWS * r, r);
-                        else rb[r] = bl.get(sb, b_var_l + B_ROWS * r, r);
-                    }
+                    for (int r = s * NB / STEPS; r < (s + 1) * NB / STEPS; ++r) rb[r] = getB(r);
                 }
                 const int kk = 2 * s;
                 const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];

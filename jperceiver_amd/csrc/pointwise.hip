@@ -101,6 +101,103 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// Compile-time (K, S) forward: 64x16 output tile, every thread owns 4 vertically adjacent outputs of one column so a
+// staged row is read once from LDS and feeds all the windows that contain it (rows arrive in scan order, so the
+// first-maximum rule is preserved).  Padding is staged as -inf and therefore never wins.
+constexpr int MPF_TH = 16;
+template <int K, int S>
+__global__ __launch_bounds__(TPB) void maxpool_fwd_t_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            uint8_t* __restrict__ idx, int H, int W, int OH, int OW,
+                                                            int p) {
+    constexpr int PW = (MP_TW - 1) * S + K, PH = (MPF_TH - 1) * S + K;
+    __shared__ float tile[PW * PH];
+    const size_t nc = blockIdx.z;
+    const float* xp = x + nc * H * W;
+    const int ox0 = blockIdx.x * MP_TW, oy0 = blockIdx.y * MPF_TH;
+    const int ix0 = ox0 * S - p, iy0 = oy0 * S - p;
+    for (int i = threadIdx.x; i < PW * PH; i += TPB) {
+        const int ly = i / PW, lx = i - ly * PW;
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        tile[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xp[iy * W + ix] : -INFINITY;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float best[4];
+    int bi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    const float* base = tile + (q * 4 * S) * PW + tx * S;
+    constexpr int R = 3 * S + K;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float v[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) v[kx] = base[r * PW + kx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ky = r - j * S;
+            if (ky < 0 || ky >= K) continue;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const bool take = v[kx] > best[j] || v[kx] != v[kx];
+                best[j] = take ? v[kx] : best[j];
+                bi[j] = take ? ky * K + kx : bi[j];
+            }
+        }
+    }
+    const int ox = ox0 + tx;
+    if (ox >= OW) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + q * 4 + j;
+        if (oy < OH) {
+            y[nc * OH * OW + oy * OW + ox] = best[j];
+            idx[nc * OH * OW + oy * OW + ox] = (uint8_t)bi[j];
+        }
+    }
+}
+
+// Compile-time K, stride 1 backward: 64x16 input tile, the covering (dy, argmax) patch staged with -1 outside the
+// output, so the K*K candidate scan needs no bounds tests.
+template <int K>
+__global__ __launch_bounds__(TPB) void maxpool_bwd_s1_kernel(const float* __restrict__ dy,
+                                                             const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                             int H, int W, int OH, int OW, int p) {
+    constexpr int PW = MP_TW + K - 1, PH = MPF_TH + K - 1;
+    __shared__ float tile[PW * PH];
+    __shared__ int itile[PW * PH];
+    const size_t nc = blockIdx.z;
+    const float* dp = dy + nc * OH * OW;
+    const uint8_t* ip = idx + nc * OH * OW;
+    const int ix0 = blockIdx.x * MP_TW, iy0 = blockIdx.y * MPF_TH;
+    const int oy0 = iy0 + p - (K - 1), ox0 = ix0 + p - (K - 1);
+    for (int i = threadIdx.x; i < PW * PH; i += TPB) {
+        const int ly = i / PW, lx = i - ly * PW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        const bool in = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+        tile[i] = in ? dp[oy * OW + ox] : 0.f;
+        itile[i] = in ? (int)ip[oy * OW + ox] : -1;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ix = ix0 + tx;
+    if (ix >= W) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ty = q * 4 + j, iy = iy0 + ty;
+        if (iy >= H) break;
+        float g = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int li = (ty + K - 1 - ky) * PW + tx + K - 1 - kx;
+                g += itile[li] == ky * K + kx ? tile[li] : 0.f;
+            }
+        dx[nc * H * W + iy * W + ix] = g;
+    }
+}
+
 // ------------------------------------------------------------------ nearest 2x upsample
 __global__ __launch_bounds__(TPB) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              long total, int C, int H, int W, int dstC, int dc0) {
@@ -391,6 +488,19 @@ extern "C" int jp_maxpool_fwd(const float* x, float* y, uint8_t* idx, int NC, in
     JP_CHECK_ARG(x && y && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_fwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    const dim3 gt(jp_cdiv(OW, MP_TW), jp_cdiv(OH, MPF_TH), NC);
+    if (k == 5 && s == 1) {
+        hipLaunchKernelGGL((maxpool_fwd_t_kernel<5, 1>), gt, dim3(TPB), 0, st, x, y, idx, H, W, OH, OW, p);
+        JP_LAUNCH_CHECK();
+    }
+    if (k == 3 && s == 2) {
+        hipLaunchKernelGGL((maxpool_fwd_t_kernel<3, 2>), gt, dim3(TPB), 0, st, x, y, idx, H, W, OH, OW, p);
+        JP_LAUNCH_CHECK();
+    }
+    if (k == 2 && s == 2) {
+        hipLaunchKernelGGL((maxpool_fwd_t_kernel<2, 2>), gt, dim3(TPB), 0, st, x, y, idx, H, W, OH, OW, p);
+        JP_LAUNCH_CHECK();
+    }
     const int pw = (MP_TW - 1) * s + k, ph = (MP_TH - 1) * s + k;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(jp_cdiv(OW, MP_TW), jp_cdiv(OH, MP_TH), NC), dim3(TPB),
                        sizeof(float) * pw * ph, st, x, y, idx, H, W, OH, OW, k, s, p);
@@ -402,6 +512,11 @@ extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, in
     JP_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_bwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    if (k == 5 && s == 1) {
+        hipLaunchKernelGGL((maxpool_bwd_s1_kernel<5>), dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MPF_TH), NC), dim3(TPB), 0, st,
+                           dy, idx, dx, H, W, OH, OW, p);
+        JP_LAUNCH_CHECK();
+    }
     // outputs that can cover a 64x8 input tile
     const int pw = (MP_TW + k - 2) / s + 2, ph = (MP_TH + k - 2) / s + 2;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MP_TH), NC), dim3(TPB),

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import call
+from ._lib import call, lib as _jplib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -90,6 +90,11 @@ def param(p: torch.nn.Parameter) -> Var:
     return Var(p.data, p.requires_grad, p.grad)
 
 
+def _ws_floats(Cin, Cout, KH, which):
+    """Caller-owned packed-weight scratch of the conv fast path (jp_conv2d_ws_floats)."""
+    return int(_jplib().fn["jp_conv2d_ws_floats"](Cin, Cout, KH, which))
+
+
 def _pad32(c):
     return (c + 31) // 32 * 32
 
@@ -124,7 +129,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             s3 += [None, 0, 0]
     bt = b.t if b is not None else None
     # scratch for the packed-weight (tap-major) fast path; None -> generic path (few reduction channels)
-    ws_f = _new((KH * KH * Cout * _pad32(Cin),), w.t) if Cin >= 32 else None
+    ws_f = _new((_ws_floats(Cin, Cout, KH, 0),), w.t) if Cin >= 32 else None
     call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act, ws_f)
     del ws_f
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
@@ -157,7 +162,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             else:
                 call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1)
         if any(v.rg for v, _ in srcs):
-            ws_d = _new((KH * KH * Cin * _pad32(Cout),), w.t) if Cout >= 32 else None
+            ws_d = _new((_ws_floats(Cin, Cout, KH, 1),), w.t) if Cout >= 32 else None
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()
                 call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc, ws_d)

@@ -1,0 +1,70 @@
+// Microbenchmark (GPU-box aid): what fraction of the 157.3 TF fp32-MFMA peak does a bare
+// v_mfma_f32_32x32x2_f32 stream sustain on MI355X, alone / with the LDS operand reads / with barriers?
+// build: hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_peak.hip -o gpurun_out/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+    __shared__ float As[32 * 129], Bs[32 * 129];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < 32 * 129; i += 256) { As[i] = seed * (i & 7); Bs[i] = seed * (i & 3); }
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* ap = As + (lane >> 5) * 129 + (wave >> 1) * 64 + (lane & 31);
+    const float* bp = Bs + (lane >> 5) * 129 + (wave & 1) * 64 + (lane & 31);
+    float a0 = seed, a1 = seed + 1, b0 = seed + 2, b1 = seed + 3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            if (MODE >= 1) {
+                a0 = ap[kk * 129]; a1 = ap[kk * 129 + 32];
+                b0 = bp[kk * 129]; b1 = bp[kk * 129 + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (MODE >= 2) {
+            __syncthreads();
+            if (MODE >= 3) {   // 32 LDS writes per thread per chunk like the igemm staging
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { As[(r * 2 + (t >> 7)) * 129 + (t & 127)] = a0 + r; Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = b0 + r; }
+            }
+            __syncthreads();
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + t] = s;
+}
+
+template <int MODE>
+void run(const char* name, int blocks, int iters, float* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 4, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 64 * 4096.0;
+    printf("%-28s blocks=%5d (%.0f/CU)  %.3f ms  %.1f TF  (%.1f%% of 157.3)\n", name, blocks, blocks / 256.0, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3 * 100);
+}
+
+int main() {
+    float* out; hipMalloc(&out, 4096 * 256 * 4 * 4);
+    for (int bpc = 1; bpc <= 3; ++bpc) {
+        run<0>("pure mfma", 256 * bpc, 2000, out);
+        run<1>("mfma + lds operand reads", 256 * bpc, 2000, out);
+        run<2>("  + 2 barriers / 64 mfma", 256 * bpc, 2000, out);
+        run<3>("  + 32 lds writes / chunk", 256 * bpc, 2000, out);
+    }
+    run<1>("mfma + lds reads, 12 waves of blocks", 256 * 3 * 4, 500, out);
+    return 0;
+}
