@@ -387,7 +387,7 @@ struct FwdBT {  // B[k=(tap,ci)][n=pixel]
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * st.hw;
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
-    __device__ __forceinline__ float post(const St& st, float v) const { return (REFLECT || st.ok) ? v : 0.f; }
+    __device__ __forceinline__ float post(const St& st, float v, int) const { return (REFLECT || st.ok) ? v : 0.f; }
 };
 
 struct DgradBTSt {
@@ -448,7 +448,7 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (OH * OW);
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
-    __device__ __forceinline__ float post(const St& st, float v) const { return st.ok ? v : 0.f; }
+    __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
 // Border pass of the reflection-pad adjoint.  N enumerates the 2W+2H border-adjacent pixels of every image
@@ -630,6 +630,144 @@ struct WgradBU {
     }
 };
 
+// ---- scalar-base wgrad loaders (igemm.h SPLIT protocol).  Preconditions (host-checked): OH*OW % 32 == 0, so a
+// K chunk of 32 pixels never straddles two images (the image and the chunk's first pixel are wave-uniform), and
+// Cout % 8 == 0, so the 8-row slot groups can be clamped with scalar arithmetic.
+struct WgradASSt {
+    const float* base;   // uniform: dY (image of the chunk, channel 0, first pixel of the chunk)
+    unsigned voff;       // per-lane: (row within the slot group, pixel within the chunk), constant
+};
+struct WgradAS {  // A[m=co][k=pixel] = dY[img][co][pix]
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    typedef WgradASSt St;
+    const float* dy;
+    int Cout, Npix, OHW;
+    __device__ __forceinline__ void init(St& st, int, int) const {
+        st.base = dy;
+        st.voff = ((threadIdx.x >> 5) * OHW + (threadIdx.x & 31)) * 4u;
+    }
+    __device__ __forceinline__ void fix(St& st, int p) const {
+        const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
+        const int img = p0 / OHW;
+        st.base = dy + (size_t)img * Cout * OHW + (p0 - img * OHW);
+    }
+    __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
+        const float* rp = st.base + (size_t)min(m_u, Cout - 8) * OHW;   // rows >= Cout: duplicates, never stored
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+};
+
+// uniform-tap B gather (Cin % 128 == 0, 128-wide N tile -> one filter tap per workgroup), scalar-base form
+struct WgradBUSSt {
+    int dy, dx, c0;      // uniform: the tile's tap and first channel
+    const float* base;   // uniform: x (image of the chunk, channel c0)
+    unsigned voff;       // per-lane: (channel within the slot group, tap-shifted pixel)
+    int ok;
+};
+template <int KH, bool REFLECT>
+struct WgradBUS {
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    static constexpr bool POST = true;
+    typedef WgradBUSSt St;
+    const float* x;
+    int Cpp, Ctot, H, W, OH, OW, stride, pad;
+    __device__ __forceinline__ void init(St& st, int n_first, int) const {
+        const int n0 = __builtin_amdgcn_readfirstlane(n_first - (int)(threadIdx.x >> 5));
+        const int tap = n0 / Cpp;
+        st.c0 = n0 - tap * Cpp;
+        st.dy = tap / KH;
+        st.dx = tap - st.dy * KH;
+        st.base = x;
+        st.voff = 0;
+        st.ok = 1;
+    }
+    __device__ __forceinline__ void fix(St& st, int p) const {
+        const int ohw = OH * OW;
+        const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
+        const int img = p0 / ohw;                       // uniform
+        const int pix = p - img * ohw;
+        const int oy = pix / OW, ox = pix - oy * OW;
+        int iy = oy * stride - pad + st.dy, ix = ox * stride - pad + st.dx;
+        if (REFLECT) {
+            iy = jp_reflect(iy, H);
+            ix = jp_reflect(ix, W);
+        } else {
+            st.ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            iy = min(max(iy, 0), H - 1);
+            ix = min(max(ix, 0), W - 1);
+        }
+        st.voff = (unsigned)(((threadIdx.x >> 5) * H + iy) * W + ix) * 4u;
+        st.base = x + (size_t)(img * Ctot + st.c0) * H * W;
+    }
+    __device__ __forceinline__ float get_u(const St& st, int, int r) const {   // slot r = channel c0 + 8r (+ lane part)
+        const float* rp = st.base + (size_t)(8 * r) * H * W;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+    __device__ __forceinline__ float post(const St& st, float v, int) const { return (REFLECT || st.ok) ? v : 0.f; }
+};
+
+// 64-channel inputs: a 64*TPT wide N tile holds TPT whole filter taps, and slot group r (8 columns) belongs to tap
+// slot r/8 at compile time -> one per-lane offset per tap per chunk, every element one scalar-base load.
+template <int TPT>
+struct WgradBMSSt {
+    int tap0;            // uniform: first tap of the tile
+    const float* base;   // uniform: x (image of the chunk, first channel of the sub-range)
+    unsigned voff[TPT];  // per-lane: (channel within the slot group, pixel shifted by tap slot s)
+    unsigned ok;         // per-lane bit s: tap slot s lies inside the image (zero padding)
+};
+template <int KH, bool REFLECT, int TPT>
+struct WgradBMS {
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    static constexpr bool POST = true;
+    typedef WgradBMSSt<TPT> St;
+    const float* x;      // already offset to the first channel of the 64-channel sub-range
+    int Ctot, H, W, OH, OW, stride, pad;
+    __device__ __forceinline__ void init(St& st, int n_first, int) const {
+        const int n0 = __builtin_amdgcn_readfirstlane(n_first - (int)(threadIdx.x >> 5));
+        st.tap0 = n0 >> 6;
+        st.base = x;
+        st.ok = ~0u;
+#pragma unroll
+        for (int s = 0; s < TPT; ++s) st.voff[s] = 0;
+    }
+    __device__ __forceinline__ void fix(St& st, int p) const {
+        const int ohw = OH * OW;
+        const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
+        const int img = p0 / ohw;                       // uniform
+        const int pix = p - img * ohw;
+        const int oy = pix / OW, ox = pix - oy * OW;
+        const int by = oy * stride - pad, bx = ox * stride - pad;
+        unsigned ok = 0;
+#pragma unroll
+        for (int s = 0; s < TPT; ++s) {
+            const int tap = min(st.tap0 + s, KH * KH - 1);   // taps past the filter: duplicate columns, never stored
+            const int dy = tap / KH, dx = tap - dy * KH;
+            int iy = by + dy, ix = bx + dx;
+            if (REFLECT) {
+                iy = jp_reflect(iy, H);
+                ix = jp_reflect(ix, W);
+            } else {
+                ok |= (unsigned)((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) << s;
+                iy = min(max(iy, 0), H - 1);
+                ix = min(max(ix, 0), W - 1);
+            }
+            st.voff[s] = (unsigned)(((threadIdx.x >> 5) * H + iy) * W + ix) * 4u;
+        }
+        st.ok = ok;
+        st.base = x + (size_t)img * Ctot * H * W;
+    }
+    __device__ __forceinline__ float get_u(const St& st, int, int r) const {
+        const float* rp = st.base + (size_t)((8 * r) & 63) * H * W;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[(8 * r) >> 6]);
+    }
+    __device__ __forceinline__ float post(const St& st, float v, int r) const {
+        return (REFLECT || ((st.ok >> ((8 * r) >> 6)) & 1u)) ? v : 0.f;
+    }
+};
+
 struct WgradEpiT {  // dw[co][c_off + ci][tap] += acc for n = tap*Cp + ci
     typedef int St;
     float* dw;
@@ -644,6 +782,28 @@ struct WgradEpiT {  // dw[co][c_off + ci][tap] += acc for n = tap*Cp + ci
         if (j >= 0) atomicAdd(dw + (size_t)m * Ctot * KHW + j, v);
     }
 };
+
+struct WgradEpiWS {  // split-K partial tiles as plain stores into caller scratch ws[split][m][n]; wgrad_reduce sums them
+    typedef int St;
+    float* ws;
+    int M, Np;
+    __device__ __forceinline__ St col(int n) const { return n; }
+    __device__ __forceinline__ void put(St n, int m, float v) const { ws[((size_t)blockIdx.z * M + m) * Np + n] = v; }
+};
+
+// dw[m][c_off + ci][tap] += sum_s ws[s][m][n = tap*Cp + ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int M, int Np, int splits,
+                                    int Cp, int Cin, int KHW, int c_off, int Ctot) {
+    const long total = (long)M * Np;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / Np), n = (int)(i - (long)m * Np);
+        const int tap = n / Cp, ci = n - tap * Cp;
+        if (ci >= Cin) continue;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
+        dw[((size_t)m * Ctot + c_off + ci) * KHW + tap] += s;
+    }
+}
 
 // wp[tap][row][Cp]: forward rows = co (src W[co][ci][tap]); dgrad rows = ci, reduction = co
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KHW,
@@ -665,6 +825,33 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 constexpr int KC = 32;
+
+// split-K plan of a wgrad GEMM (M x Np, K = npix): workgroups run in rounds of `slots` = 256 CUs x per_cu; a split
+// costs its K chunks plus an epilogue -- ~14 chunk-times when the partial tile is merged with device-scope atomics,
+// ~3 when it is stored to scratch and summed by wgrad_reduce_kernel (whose pass over splits*M*Np floats is charged
+// too).  Returns the split count minimising rounds * (chunks per split + epilogue).
+struct WgradPlan {
+    int splits, kps;
+    bool use_ws;
+    long ws_need;
+};
+inline WgradPlan wgrad_plan(int M, int Np, long npix, int BM, int BN, int per_cu, long ws_floats) {
+    const long tiles = (long)jp_cdiv(M, BM) * jp_cdiv(Np, BN), chunks = jp_cdiv(npix, KC), slots = 256L * per_cu;
+    WgradPlan best{1, (int)(chunks * KC), false, 0};
+    double bc = 1e30;
+    for (long sp = 1; sp <= std::max<long>(1, chunks / 4) && sp <= 4096; ++sp) {
+        const long per = jp_cdiv(chunks, sp), need = sp * (long)M * Np;
+        const double rounds = (double)jp_cdiv(sp * tiles, slots);
+        const double c_at = rounds * (per + 14.0);
+        if (c_at < bc * 0.999) { bc = c_at; best = WgradPlan{(int)sp, (int)(per * KC), false, 0}; }
+        if (sp > 1 && need <= ws_floats) {
+            const double c_ws = rounds * (per + 3.0) + (need * 4.0 / 3.0e12 + 6e-6) / 7e-6;
+            if (c_ws < bc * 0.999) { bc = c_ws; best = WgradPlan{(int)sp, (int)(per * KC), true, need}; }
+        }
+    }
+    best.splits = jp_cdiv(npix, best.kps);
+    return best;
+}
 
 // IL: gather interleaved with the MFMAs (measured +6 % on wgrad, -6 % on fwd/dgrad -> wgrad only)
 template <bool IL, int WM, int WN, class A, class B, class E>
@@ -790,7 +977,9 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         JP_KH_SWITCH(KH, {
             if (pad_mode == JP_PAD_REFLECT) {
                 FwdBT<KH_, true> b{src, Cp, (int)npix, OH, OW, stride, pad};
-                launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+                static const int ilf = getenv("JP_IL_FWD") ? atoi(getenv("JP_IL_FWD")) : 0;
+                if (ilf) launch_auto<true>(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+                else launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
             } else {
                 FwdBT<KH_, false> b{src, Cp, (int)npix, OH, OW, stride, pad};
                 launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
@@ -840,7 +1029,9 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         } else {
             JP_KH_SWITCH(KH, {
                 DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-                launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
+                static const int ild = getenv("JP_IL_DGRAD") ? atoi(getenv("JP_IL_DGRAD")) : 0;
+                if (ild) launch_auto<true>(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
+                else launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
             });
         }
         if (pad_mode == JP_PAD_REFLECT) {   // fold the reflected ring back in (border-adjacent lines only)
@@ -863,7 +1054,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
 extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
                                     const float* x2, int c2, int up2, const float* dy, float* dw, int N, int H, int W,
                                     int Cout, int KH, int stride, int pad, int pad_mode, int accumulate,
-                                    void* stream) {
+                                    float* ws, long ws_floats, void* stream) {
     JP_CHECK_ARG(x0 && dy && dw, "conv2d_wgrad: null pointer");
     const int Cin = c0 + c1 + c2;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
@@ -878,17 +1069,30 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
     }
     WgradA a{dy, Cout, (int)npix, OH * OW};
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
-    static const int tgt_blocks = getenv("JP_WGRAD_BLOCKS") ? atoi(getenv("JP_WGRAD_BLOCKS")) : 512;
-    static const int min_chunks = getenv("JP_WGRAD_MINCHUNKS") ? atoi(getenv("JP_WGRAD_MINCHUNKS")) : 64;
-    auto plan = [&](int Np, int* splits, int* kps) {
-        // ~2 workgroups per CU, but at least 64 K-chunks per split so the 16k-atomic epilogue stays amortised
-        const int tiles = jp_cdiv(Cout, Cout <= 64 ? 64 : 128) * jp_cdiv(Np, Cout <= 64 ? 256 : 128);
-        int sp = (int)std::min<long>(std::max(1, tgt_blocks / std::max(1, tiles)), std::max<long>(1, npix / (min_chunks * KC)));
-        if ((long)sp * tiles < 256)   // tiny maps (pose encoder): filling the chip matters more than epilogue amortisation
-            sp = (int)std::min<long>(std::max(1, tgt_blocks / std::max(1, tiles)), std::max<long>(1, npix / (8 * KC)));
-        *kps = jp_cdiv(jp_cdiv(npix, sp), KC) * KC;
-        *splits = jp_cdiv(npix, *kps);
+    if (!ws) ws_floats = 0;
+    auto plan = [&](int Np, int* splits, int* kps, int per_cu = 2) {   // atomic-epilogue paths
+        const bool narrow = Cout <= 64;
+        const WgradPlan p = wgrad_plan(Cout, Np, npix, narrow ? 64 : 128, narrow ? 256 : 128, per_cu, 0);
+        *splits = p.splits;
+        *kps = p.kps;
     };
+    // scalar-base paths: scratch-reduced split-K when the caller provided scratch and the plan prefers it
+    auto go = [&](auto wm, auto wn, auto a_, auto b_, const WgradEpiT& e, int Np) {
+        constexpr int WM = decltype(wm)::value, WN = decltype(wn)::value;
+        const WgradPlan p = wgrad_plan(Cout, Np, npix, 64 * WM, 64 * WN, 3, ws_floats);
+        if (p.use_ws) {
+            WgradEpiWS ew{ws, Cout, Np};
+            launch<true, WM, WN>(a_, b_, ew, Cout, Np, (int)npix, p.splits, p.kps, st);
+            const long total = (long)Cout * Np;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st,
+                               ws, dw, Cout, Np, p.splits, e.Cp, e.Cin, e.KHW, e.c_off, e.Ctot);
+        } else {
+            launch<true, WM, WN>(a_, b_, e, Cout, Np, (int)npix, p.splits, p.kps, st);
+        }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
     const bool single = (c1 == 0 && c2 == 0 && up0 == 0 && (long)Cin * H * W < (1L << 31));
     int splits, kps;
     // table path over a channel sub-range [cb, cb+cn) of a single full-resolution source
@@ -916,16 +1120,45 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         const int Cm = Cin / 128 * 128, tail = Cin - Cm;
         const int Np = KH * KH * Cm;
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cm) + 1u;
-        plan(Np, &splits, &kps);
+        const bool scalar_ok = (OH * OW) % 32 == 0 && Cout % 8 == 0 && (long)8 * H * W * 4 < (1L << 31);
         WgradEpiT e{dw, Cm, Cm, KH * KH, 0, Cin, magic};
-        JP_KH_SWITCH(KH, {
-            WgradBU<KH_> b{x0, Cm, Cm, Cin, H, W, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-            launch<true, 2, 2>(a, b, e, Cout, Np, (int)npix, splits, kps, st);
-        });
+        if (scalar_ok) {   // scalar-base loaders
+            WgradAS as{dy, Cout, (int)npix, OH * OW};
+            JP_KH_SWITCH(KH, {
+                if (pad_mode == JP_PAD_REFLECT) {
+                    WgradBUS<KH_, true> b{x0, Cm, Cin, H, W, OH, OW, stride, pad};
+                    go(I2{}, I2{}, as, b, e, Np);
+                } else {
+                    WgradBUS<KH_, false> b{x0, Cm, Cin, H, W, OH, OW, stride, pad};
+                    go(I2{}, I2{}, as, b, e, Np);
+                }
+            });
+        } else {
+            plan(Np, &splits, &kps);
+            JP_KH_SWITCH(KH, {
+                WgradBU<KH_> b{x0, Cm, Cm, Cin, H, W, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+                launch<true, 2, 2>(a, b, e, Cout, Np, (int)npix, splits, kps, st);
+            });
+        }
         if (tail) {
             const int rc = run_table(Cm, tail);
             if (rc) return rc;
         }
+    } else if (single && Cin == 64 && (OH * OW) % 32 == 0 && Cout % 8 == 0 && (long)8 * H * W * 4 < (1L << 31)) {
+        // 64 input channels (ResNet stem / layer1): whole taps per N tile, scalar-base loaders
+        const int Np = KH * KH * 64;
+        const unsigned magic = (unsigned)((1ULL << 32) / 64u) + 1u;
+        WgradEpiT e{dw, 64, 64, KH * KH, 0, Cin, magic};
+        WgradAS as{dy, Cout, (int)npix, OH * OW};
+        JP_KH_SWITCH(KH, {
+            if (pad_mode == JP_PAD_REFLECT) {
+                if (Cout <= 64) { WgradBMS<KH_, true, 4> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I1{}, I4{}, as, b, e, Np); }
+                else { WgradBMS<KH_, true, 2> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I2{}, I2{}, as, b, e, Np); }
+            } else {
+                if (Cout <= 64) { WgradBMS<KH_, false, 4> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I1{}, I4{}, as, b, e, Np); }
+                else { WgradBMS<KH_, false, 2> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I2{}, I2{}, as, b, e, Np); }
+            }
+        });
     } else if (single) {
         const int rc = run_table(0, Cin);
         if (rc) return rc;
@@ -943,7 +1176,20 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
 }
 
 extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
-                               int KH, int stride, int pad, int pad_mode, int accumulate, void* stream) {
+                               int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, long ws_floats,
+                               void* stream) {
     return jp_conv2d_wgrad_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, dy, dw, N, H, W, Cout, KH, stride, pad,
-                                pad_mode, accumulate, stream);
+                                pad_mode, accumulate, ws, ws_floats, stream);
+}
+
+// floats of optional caller scratch with which jp_conv2d_wgrad[_src3] merges its split-K partial tiles through a
+// reduction pass instead of device-scope atomics (0 = no benefit for this shape).  Capped at 32 Mi floats.
+extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+    const long npix = (long)N * OH * OW, cap = 32L << 20;
+    if ((OH * OW) % 32 != 0 || Cout % 8 != 0 || Cin < 64) return 0;
+    const int Np = KH * KH * (Cin / 64 * 64);
+    const bool narrow = Cout <= 64 && Cin == 64;
+    const WgradPlan p = wgrad_plan(Cout, Np, npix, narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
+    return p.use_ws ? p.ws_need : 0;
 }

@@ -51,7 +51,25 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), each with
+    // its own L2.  Remap so the gridDim.y M-tiles of one N-tile are consecutive dispatches *on the same XCD*: the
+    // gathered B rows (the big operand) are then fetched into that L2 once and shared, instead of once per M-tile
+    // from HBM / Infinity Cache a whole grid-row later.
+    int mt = blockIdx.y, nt = blockIdx.x;
+    if (gridDim.y > 1) {
+        const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
+        const int L = blockIdx.x + blockIdx.y * gx;
+        if (L < G * gy) {
+            const int j = L >> 3;
+            mt = j % gy;
+            nt = ((j / gy) << 3) + (L & 7);
+        } else {
+            const int i = L - G * gy;
+            mt = i % gy;
+            nt = G + i / gy;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
     const int kbeg = blockIdx.z * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
 
@@ -107,14 +125,14 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
             float v = ra[r];
-            if constexpr (jp_has_post<ALoad>::value) v = al.post(sa, v);
+            if constexpr (jp_has_post<ALoad>::value) v = al.post(sa, v, r);
             if (ALoad::ALONG_K) Ad[a_fix_l * LDA + a_var_l + A_ROWS * r] = v;
             else Ad[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = v;
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
             float v = rb[r];
-            if constexpr (jp_has_post<BLoad>::value) v = bl.post(sb, v);
+            if constexpr (jp_has_post<BLoad>::value) v = bl.post(sb, v, r);
             if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = v;
             else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = v;
         }

@@ -156,11 +156,17 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                     else:
                         call("jp_copy_channels", v.t, xc, N, C, H * W, C, 0, Cin, c0, 0)
                     c0 += C
+                nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad))
+                ws_w = _new((nws,), dy) if nws else None
                 call("jp_conv2d_wgrad_src3", xc, Cin, 0, None, 0, 0, None, 0, 0, dy, w.g, N, H, W, Cout, KH, stride, pad,
-                     pad_mode, 1)
-                del xc
+                     pad_mode, 1, ws_w, nws)
+                del xc, ws_w
             else:
-                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1)
+                single = len(srcs) == 1 and not srcs[0][1]
+                nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad)) if single else 0
+                ws_w = _new((nws,), dy) if nws else None
+                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
+                del ws_w
         if any(v.rg for v, _ in srcs):
             ws_d = _new((_ws_floats(Cin, Cout, KH, 1),), w.t) if Cout >= 32 else None
             if len(srcs) == 1 and srcs[0][1] == 0:

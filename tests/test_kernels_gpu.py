@@ -53,6 +53,14 @@ CONV_CASES = [
     (1, 150, 9, 11, 80, 3, 1, 1, 0, 0, False),      # ... + 22-channel tail
     (2, 256, 8, 8, 128, 3, 1, 1, 1, 0, True),       # uniform-tap wgrad, reflect
     (2, 128, 6, 10, 72, 1, 1, 0, 0, 0, False),      # uniform-tap wgrad, 1x1
+    (2, 64, 16, 24, 64, 3, 1, 1, 0, 0, False),      # 64-ch whole-tap wgrad tiles, Cout<=64 (4 taps / tile), zero pad
+    (2, 64, 16, 24, 64, 3, 1, 1, 1, 0, True),       # ... reflect
+    (2, 64, 32, 48, 128, 3, 2, 1, 0, 0, False),     # ... stride 2, 2 taps / tile
+    (2, 64, 32, 48, 128, 1, 2, 0, 0, 0, False),     # ... 1x1 stride 2
+    (2, 128, 16, 32, 256, 3, 2, 1, 0, 0, False),    # scalar-base uniform-tap wgrad, stride 2 zero pad
+    (2, 256, 16, 16, 128, 3, 1, 1, 0, 1, True),     # scalar-base uniform-tap wgrad, zero pad
+    (5, 64, 6, 10, 64, 3, 1, 1, 0, 0, False),       # pixel tiles straddling several images (relative-image offsets)
+    (5, 96, 6, 10, 160, 3, 1, 1, 1, 0, False),      # ... reflect
 ]
 
 

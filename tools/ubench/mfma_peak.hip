@@ -5,6 +5,64 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// MODE 4/5: the full igemm loop shape -- 32 global dword loads per thread per chunk prefetched into registers
+// under the MFMAs, stored to LDS between two barriers.  4 = every block streams its own rows (L2/HBM), 5 = all
+// blocks re-read the same 32 KB (L1/L2-hot).
+template <int MODE>
+__global__ __launch_bounds__(256) void kg(float* out, const float* __restrict__ src, int iters, size_t span) {
+    __shared__ float As[32 * 129], Bs[32 * 129];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* ap = As + (lane >> 5) * 129 + (wave >> 1) * 64 + (lane & 31);
+    const float* bp = Bs + (lane >> 5) * 129 + (wave & 1) * 64 + (lane & 31);
+    float ra[16], rb[16];
+    auto gload = [&](int it) {
+        const float* q = src + (MODE == 4 ? ((size_t)blockIdx.x * 8192 + (size_t)it * 8192 * 1024) % span : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ra[r] = q[r * 256 + t]; rb[r] = q[4096 + r * 256 + t]; }
+    };
+    gload(0);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { As[(r * 2 + (t >> 7)) * 129 + (t & 127)] = ra[r]; Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = rb[r]; }
+        __syncthreads();
+        gload(it + 1);
+        float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+#pragma unroll 4
+        for (int kk = 0; kk < 32; kk += 2) {
+            const int kn = kk + 2 < 32 ? kk + 2 : kk;
+            const float na0 = ap[kn * 129], na1 = ap[kn * 129 + 32], nb0 = bp[kn * 129], nb1 = bp[kn * 129 + 32];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + t] = s + ra[0] + rb[0];
+}
+
+template <int MODE>
+void rung(const char* name, int blocks, int iters, float* out, const float* src, size_t span) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, out, src, 4, span);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, out, src, iters, span);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 64 * 4096.0;
+    printf("%-40s blocks=%5d (%.0f/CU)  %.3f ms  %.1f TF  (%.1f%% of 157.3)\n", name, blocks, blocks / 256.0, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3 * 100);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     __shared__ float As[32 * 129], Bs[32 * 129];
@@ -66,5 +124,13 @@ int main() {
         run<3>("  + 32 lds writes / chunk", 256 * bpc, 2000, out);
     }
     run<1>("mfma + lds reads, 12 waves of blocks", 256 * 3 * 4, 500, out);
+    const size_t span = (size_t)1 << 28;   // 1 GiB of floats
+    float* src; hipMalloc(&src, (span + (1 << 24)) * 4); hipMemset(src, 0, (span + (1 << 24)) * 4);
+    for (int bpc = 1; bpc <= 3; ++bpc) {
+        rung<5>("igemm loop, L1/L2-hot source", 256 * bpc, 1000, out, src, span);
+        rung<4>("igemm loop, streaming source", 256 * bpc, 1000, out, src, span);
+    }
+    rung<5>("igemm loop hot, 12 rounds of blocks", 256 * 3 * 12, 72, out, src, span);
+    rung<4>("igemm loop streaming, 12 rounds", 256 * 3 * 12, 72, out, src, span);
     return 0;
 }
