@@ -977,9 +977,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         JP_KH_SWITCH(KH, {
             if (pad_mode == JP_PAD_REFLECT) {
                 FwdBT<KH_, true> b{src, Cp, (int)npix, OH, OW, stride, pad};
-                static const int ilf = getenv("JP_IL_FWD") ? atoi(getenv("JP_IL_FWD")) : 0;
-                if (ilf) launch_auto<true>(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
-                else launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
+                launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
             } else {
                 FwdBT<KH_, false> b{src, Cp, (int)npix, OH, OW, stride, pad};
                 launch_auto(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);
@@ -1029,9 +1027,16 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         } else {
             JP_KH_SWITCH(KH, {
                 DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
-                static const int ild = getenv("JP_IL_DGRAD") ? atoi(getenv("JP_IL_DGRAD")) : 0;
-                if (ild) launch_auto<true>(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
-                else launch_auto(a, b, e, Cin, (int)npix, Kp, 1, Kp, st);
+                // a short row tail (513 = 4*128 + 1 input channels of the iconv layers) runs as its own 64-row launch
+                // instead of a fifth, almost empty 128-row tile column
+                const int tail = (Cin > 128 && Cin % 128 <= 16) ? Cin % 128 : 0;
+                const int Mm = Cin - tail;
+                launch_auto(a, b, e, Mm, (int)npix, Kp, 1, Kp, st);
+                if (tail) {
+                    PackA at{ws + (size_t)Mm * Cp, Cin, Kp, Cp, KH * KH};
+                    DgradEpi et{dx + (size_t)Mm * H * W, Cin, H * W, accumulate};
+                    launch_auto(at, b, et, tail, (int)npix, Kp, 1, Kp, st);
+                }
             });
         }
         if (pad_mode == JP_PAD_REFLECT) {   // fold the reflected ring back in (border-adjacent lines only)

@@ -213,6 +213,39 @@ __global__ __launch_bounds__(TPB) void upsample2x_fwd_kernel(const float* __rest
     }
 }
 
+// W % 4 == 0: one float4 of input -> two rows x two float4 of output (16-B accesses on both sides, 32-bit indexing)
+__global__ __launch_bounds__(TPB) void upsample2x_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                unsigned total4, int C, int H, int W4, int dstC,
+                                                                int dc0) {
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total4; i += gridDim.x * TPB) {
+        const unsigned xq = i % W4, t = i / W4;
+        const unsigned yy = t % H, nc = t / H;
+        const unsigned c = nc % C, n = nc / C;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4* o = reinterpret_cast<float4*>(y + (((size_t)n * dstC + dc0 + c) * (2 * H) + 2 * yy) * (8 * W4)) + 2 * xq;
+        const float4 a = make_float4(v.x, v.x, v.y, v.y), b = make_float4(v.z, v.z, v.w, v.w);
+        o[0] = a; o[1] = b;
+        o[2 * W4] = a; o[2 * W4 + 1] = b;
+    }
+}
+
+// W % 2 == 0: two input-gradient elements from two float4 rows of dy
+__global__ __launch_bounds__(TPB) void upsample2x_bwd_v2_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                unsigned total2, int C, int H, int W2, int Ctot, int c0,
+                                                                int accumulate) {
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total2; i += gridDim.x * TPB) {
+        const unsigned xp = i % W2, t = i / W2;
+        const unsigned yy = t % H, nc = t / H;
+        const unsigned c = nc % C, n = nc / C;
+        const float4* d = reinterpret_cast<const float4*>(dy + (((size_t)n * Ctot + c0 + c) * (2 * H) + 2 * yy) * (4 * W2)) + xp;
+        const float4 r0 = d[0], r1 = d[W2];
+        float2 g = make_float2(r0.x + r0.y + r1.x + r1.y, r0.z + r0.w + r1.z + r1.w);
+        float2* o = reinterpret_cast<float2*>(dx) + i;
+        if (accumulate) { const float2 p = *o; g.x += p.x; g.y += p.y; }
+        *o = g;
+    }
+}
+
 // dx[nc][y][x] = sum of the 2x2 block of dy; dy may be a channel slice of a wider tensor:
 // element (n, c, y, x) lives at dy[((n*Ctot + c0 + c)*OH + y)*OW + x]
 __global__ __launch_bounds__(TPB) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
@@ -245,6 +278,19 @@ __global__ __launch_bounds__(TPB) void copy_channels_kernel(const float* __restr
         const float v = src[(n * srcC + sc0 + c) * HW + p];
         float* q = dst + (n * dstC + dc0 + c) * HW + p;
         *q = accumulate ? *q + v : v;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void copy_channels_v4_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               unsigned total4, int C, int HW4, int srcC, int sc0,
+                                                               int dstC, int dc0, int accumulate) {
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total4; i += gridDim.x * TPB) {
+        const unsigned p = i % HW4, t = i / HW4;
+        const unsigned c = t % C, n = t / C;
+        float4 v = reinterpret_cast<const float4*>(src)[((size_t)n * srcC + sc0 + c) * HW4 + p];
+        float4* q = reinterpret_cast<float4*>(dst) + ((size_t)n * dstC + dc0 + c) * HW4 + p;
+        if (accumulate) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *q = v;
     }
 }
 
@@ -530,6 +576,11 @@ extern "C" int jp_upsample2x_fwd(const float* x, float* y, int N, int C, int H, 
     JP_CHECK_ARG(x && y && N > 0 && C > 0 && dc0 + C <= dstC, "upsample2x_fwd: bad args");
     JP_ST;
     const long total = (long)N * C * H * W * 4;
+    if (W % 4 == 0 && total / 16 < (1L << 31)) {
+        hipLaunchKernelGGL(upsample2x_fwd_v4_kernel, dim3(blocks_for(total / 16)), dim3(TPB), 0, st, x, y,
+                           (unsigned)(total / 16), C, H, W / 4, dstC, dc0);
+        JP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, x, y, total, C, H, W, dstC, dc0);
     JP_LAUNCH_CHECK();
 }
@@ -539,6 +590,11 @@ extern "C" int jp_upsample2x_bwd(const float* dy, float* dx, int N, int C, int H
     JP_CHECK_ARG(dy && dx && N > 0 && C > 0 && c0 + C <= Ctot, "upsample2x_bwd: bad args");
     JP_ST;
     const long total = (long)N * C * H * W;
+    if (W % 2 == 0 && total < (1L << 31)) {
+        hipLaunchKernelGGL(upsample2x_bwd_v2_kernel, dim3(blocks_for(total / 2)), dim3(TPB), 0, st, dy, dx,
+                           (unsigned)(total / 2), C, H, W / 2, Ctot, c0, accumulate);
+        JP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, dy, dx, total, C, H, W, Ctot,
                        c0, accumulate);
     JP_LAUNCH_CHECK();
@@ -549,6 +605,11 @@ extern "C" int jp_copy_channels(const float* src, float* dst, int N, int C, int 
     JP_CHECK_ARG(src && dst && N > 0 && C > 0 && sc0 + C <= srcC && dc0 + C <= dstC, "copy_channels: bad args");
     JP_ST;
     const long total = (long)N * C * HW;
+    if (HW % 4 == 0 && total < (1L << 32)) {
+        hipLaunchKernelGGL(copy_channels_v4_kernel, dim3(blocks_for(total / 4)), dim3(TPB), 0, st, src, dst,
+                           (unsigned)(total / 4), C, HW / 4, srcC, sc0, dstC, dc0, accumulate);
+        JP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, src, dst, total, C, HW, srcC,
                        sc0, dstC, dc0, accumulate);
     JP_LAUNCH_CHECK();

@@ -170,11 +170,12 @@ def test_maxpool(k, s, p, H, W):
     close(xv.g, xr.grad, rtol=1e-6)
 
 
-def test_upsample_cat_add_mask_act():
-    x = rnd(2, 6, 5, 7, seed=1)
+@pytest.mark.parametrize("H,W", [(5, 7), (6, 8), (3, 6)])   # scalar, float4 and float2 code paths
+def test_upsample_cat_add_mask_act(H, W):
+    x = rnd(2, 6, H, W, seed=1)
     xv = Var(x, True)
-    a, b = Var(rnd(2, 3, 10, 14, seed=2), True), Var(rnd(2, 4, 10, 14, seed=3), True)
-    m = (rnd(2, 6, 5, 7, seed=4) > 0).float()
+    a, b = Var(rnd(2, 3, 2 * H, 2 * W, seed=2), True), Var(rnd(2, 4, 2 * H, 2 * W, seed=3), True)
+    m = (rnd(2, 6, H, W, seed=4) > 0).float()
     tape = Tape()
     with recording(tape):
         u = ops.upsample2x(ops.mul_mask(xv, m, 2.0))

@@ -39,6 +39,14 @@ def timed(name, *a):
         key = "wgrad %4d->%4d k%d s%d @%4d fl=%.1f" % (a[1] + a[4] + a[7], a[14], a[15], a[16], a[12], 2e-9 * a[11] * (a[12] // a[16]) * (a[13] // a[16]) * a[14] * (a[1] + a[4] + a[7]) * a[15] ** 2)
     elif name in ("jp_maxpool_fwd", "jp_maxpool_bwd"):
         key = "%s NC=%d %dx%d k%d s%d" % (name, a[3], a[4], a[5], a[6], a[7])
+    elif name == "jp_bn_train_fwd":
+        key = "bn_fwd N=%d C=%d HW=%d res=%d MB=%.0f" % (a[10], a[11], a[12], a[3] is not None, 4e-6 * a[10] * a[11] * a[12])
+    elif name == "jp_bn_train_bwd":
+        key = "bn_bwd N=%d C=%d HW=%d res=%d MB=%.0f" % (a[11], a[12], a[13], a[7] is not None, 4e-6 * a[11] * a[12] * a[13])
+    elif name == "jp_axpby":
+        key = "axpby n=%.1fM b=%d" % (a[3] * 1e-6, a[1] is not None)
+    elif name == "jp_upsample2x_fwd":
+        key = "up2x_fwd N=%d C=%d %dx%d dstC=%d" % (a[2], a[3], a[4], a[5], a[6])
     rec.append((key, e0, e1))
 for m in (ops, ops_loss, netmod, rt, mods):
     if hasattr(m, "call"): m.call = timed
