@@ -516,7 +516,7 @@ struct DgradBorderEpi {  // dx[img][ci][y][x] += acc for the border pixel b
         return px.valid ? (long)px.img * Cin * H * W + px.y * W + px.x : -1;
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
-        if (base >= 0) dx[base + (size_t)m * H * W] += v;
+        if (base >= 0) atomicAdd(dx + base + (size_t)m * H * W, v);   // split-K partials meet here
     }
 };
 
@@ -788,7 +788,8 @@ struct WgradEpiWS {  // split-K partial tiles as plain stores into caller scratc
     float* ws;
     int M, Np;
     __device__ __forceinline__ St col(int n) const { return n; }
-    __device__ __forceinline__ void put(St n, int m, float v) const { ws[((size_t)blockIdx.z * M + m) * Np + n] = v; }
+    static constexpr bool WANTS_SLICE = true;
+    __device__ __forceinline__ void put(St n, int m, float v, int slice) const { ws[((size_t)slice * M + m) * Np + n] = v; }
 };
 
 // dw[m][c_off + ci][tap] += sum_s ws[s][m][n = tap*Cp + ci]
@@ -1043,7 +1044,11 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             const int Nb = N * (2 * W + 2 * H);
             DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
             DgradBorderEpi be{dx, Cin, H, W, Nb};
-            launch_auto(a, bb, be, Cin, Nb, Kp, 1, Kp, st);
+            // a few dozen tiles only: split K so the pass is not one workgroup's whole K loop long
+            const long btiles = (long)jp_cdiv(Cin, Cin <= 64 ? 64 : 128) * jp_cdiv(Nb, Cin <= 64 ? 256 : 128);
+            const int bsp = (int)std::max<long>(1, std::min<long>(jp_cdiv(768, btiles), Kp / KC / 4));
+            const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
+            launch_auto(a, bb, be, Cin, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
         }
     } else {
         const int K = Cout * KH * KH;

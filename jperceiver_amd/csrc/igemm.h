@@ -30,6 +30,8 @@
 
 template <class L, class = void> struct jp_has_post : std::false_type {};
 template <class L> struct jp_has_post<L, std::void_t<decltype(L::POST)>> : std::true_type {};
+template <class E, class = void> struct jp_epi_wants_slice : std::false_type {};   // put(st, m, v, k_slice)
+template <class E> struct jp_epi_wants_slice<E, std::void_t<decltype(E::WANTS_SLICE)>> : std::true_type {};
 template <class L, class = void> struct jp_has_split : std::false_type {};
 template <class L> struct jp_has_split<L, std::void_t<decltype(L::SPLIT)>> : std::true_type {};
 
@@ -52,25 +54,46 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), each with
-    // its own L2.  Remap so the gridDim.y M-tiles of one N-tile are consecutive dispatches *on the same XCD*: the
-    // gathered B rows (the big operand) are then fetched into that L2 once and shared, instead of once per M-tile
-    // from HBM / Infinity Cache a whole grid-row later.
-    int mt = blockIdx.y, nt = blockIdx.x;
-    if (gridDim.y > 1) {
-        const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
+    // its own 4 MiB L2.  Remap so that (a) every XCD owns a contiguous band of N tiles -- vertically adjacent pixel
+    // tiles, which share two of their three input rows, then hit the same L2 instead of each pulling the rows over
+    // the fabric -- and (b) the gridDim.y M-tiles of one N-tile are consecutive dispatches on that XCD and share
+    // the gathered B operand.
+    // (c) split-K launches (gridDim.z > 1): every XCD owns whole K slices -- all (m, n) tiles of a slice read the same
+    // pixel range of both operands in lock-step, so they share it through one L2 instead of 8.
+    int mt = blockIdx.y, nt = blockIdx.x, zs = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
         const int L = blockIdx.x + blockIdx.y * gx;
-        if (L < G * gy) {
-            const int j = L >> 3;
-            mt = j % gy;
-            nt = ((j / gy) << 3) + (L & 7);
+        if (gridDim.z > 1) {
+            const int T = gx * gy, SG = gridDim.z & ~7;
+            const int L3 = L + blockIdx.z * T;
+            int tile;
+            if (L3 < SG * T) {
+                const int idx = L3 >> 3;
+                zs = (idx / T) * 8 + (L3 & 7);
+                tile = idx % T;
+            } else {
+                const int r = L3 - SG * T;
+                zs = SG + r / T;
+                tile = r % T;
+            }
+            mt = tile % gy;
+            nt = tile / gy;
         } else {
-            const int i = L - G * gy;
-            mt = i % gy;
-            nt = G + i / gy;
+            const int G = gx & ~7;
+            if (L < G * gy) {
+                const int j = L >> 3;
+                mt = j % gy;
+                nt = (L & 7) * (G >> 3) + j / gy;
+            } else {
+                const int i = L - G * gy;
+                mt = i % gy;
+                nt = G + i / gy;
+            }
         }
     }
     const int m0 = mt * BM, n0 = nt * BN;
-    const int kbeg = blockIdx.z * k_per_split;
+    const int kbeg = zs * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
 
     // ---- loader thread mappings
@@ -239,7 +262,10 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < M) epi.put(se, m, acc[i][j][r]);
+                if (m < M) {
+                    if constexpr (jp_epi_wants_slice<Epi>::value) epi.put(se, m, acc[i][j][r], zs);
+                    else epi.put(se, m, acc[i][j][r]);
+                }
             }
         }
     }

@@ -48,6 +48,67 @@ __global__ __launch_bounds__(256) void kg(float* out, const float* __restrict__ 
     out[blockIdx.x * 256 + t] = s + ra[0] + rb[0];
 }
 
+// MODE 6: same loop, but the staging is LDS-direct (global_load_lds_dword, no VGPR round trip, no ds_write), double
+// buffered in LDS: chunk i+1 lands in the other stage while chunk i feeds the MFMAs; one barrier per chunk.
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+template <int HOT>
+__global__ __launch_bounds__(256) void kl(float* out, const float* __restrict__ src, int iters, size_t span) {
+    __shared__ float As[2][32 * 129], Bs[2][32 * 129];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto gload = [&](int it, int stage) {
+        const float* q = src + (HOT ? 0 : ((size_t)blockIdx.x * 8192 + (size_t)it * 8192 * 1024) % span);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* da = &As[stage][(r * 2 + (wave >> 1)) * 129 + (wave & 1) * 64];
+            float* db = &Bs[stage][(r * 2 + (wave >> 1)) * 129 + (wave & 1) * 64];
+            __builtin_amdgcn_global_load_lds((glb_ptr)(q + r * 256 + t), (lds_ptr)da, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(q + 4096 + r * 256 + t), (lds_ptr)db, 4, 0, 0);
+        }
+    };
+    gload(0, 0);
+    for (int it = 0; it < iters; ++it) {
+        const int st = it & 1;
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this stage has landed
+        __syncthreads();
+        gload(it + 1, st ^ 1);
+        const float* ap = As[st] + (lane >> 5) * 129 + (wave >> 1) * 64 + (lane & 31);
+        const float* bp = Bs[st] + (lane >> 5) * 129 + (wave & 1) * 64 + (lane & 31);
+        float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+#pragma unroll 4
+        for (int kk = 0; kk < 32; kk += 2) {
+            const int kn = kk + 2 < 32 ? kk + 2 : kk;
+            const float na0 = ap[kn * 129], na1 = ap[kn * 129 + 32], nb0 = bp[kn * 129], nb1 = bp[kn * 129 + 32];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + t] = s;
+}
+template <int HOT>
+void runl(const char* name, int blocks, int iters, float* out, const float* src, size_t span) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kl<HOT>, dim3(blocks), dim3(256), 0, 0, out, src, 4, span);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kl<HOT>, dim3(blocks), dim3(256), 0, 0, out, src, iters, span);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * iters * 64 * 4096.0;
+    printf("%-40s blocks=%5d (%.0f/CU)  %.3f ms  %.1f TF  (%.1f%% of 157.3)\n", name, blocks, blocks / 256.0, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3 * 100);
+}
+
 template <int MODE>
 void rung(const char* name, int blocks, int iters, float* out, const float* src, size_t span) {
     hipEvent_t e0, e1;
@@ -129,6 +190,10 @@ int main() {
     for (int bpc = 1; bpc <= 3; ++bpc) {
         rung<5>("igemm loop, L1/L2-hot source", 256 * bpc, 1000, out, src, span);
         rung<4>("igemm loop, streaming source", 256 * bpc, 1000, out, src, span);
+    }
+    for (int bpc = 1; bpc <= 2; ++bpc) {
+        runl<1>("lds-direct loop, hot source", 256 * bpc, 1000, out, src, span);
+        runl<0>("lds-direct loop, streaming source", 256 * bpc, 1000, out, src, span);
     }
     rung<5>("igemm loop hot, 12 rounds of blocks", 256 * 3 * 12, 72, out, src, span);
     rung<4>("igemm loop streaming, 12 rounds", 256 * 3 * 12, 72, out, src, span);
