@@ -140,6 +140,19 @@ __global__ void bias_act_nchw_kernel(float* __restrict__ y, const float* __restr
     }
 }
 
+// deterministic small-grid split-K: y[img][m][pix] = act(bias[m] + sum_s part[s][m][n]) in a fixed order
+__global__ void slice_reduce_nchw_kernel(const float* __restrict__ part, float* __restrict__ y,
+                                         const float* __restrict__ bias, int M, int Npix, int HW, int splits, int act) {
+    const long total = (long)M * Npix;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / Npix), n = (int)(i - (long)m * Npix);
+        float s = bias ? bias[m] : 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + i];
+        const int img = n / HW;
+        y[((size_t)img * M + m) * HW + (n - img * HW)] = jp_act(s, act);
+    }
+}
+
 struct MKSt {
     int m, kc;
 };
@@ -934,7 +947,7 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
 extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
                                   const float* x2, int c2, int up2, const float* w, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int KH, int stride, int pad, int pad_mode, int act,
-                                  float* ws, void* stream) {
+                                  float* ws, float* split_ws, void* stream) {
     JP_CHECK_ARG(x0 && w && y, "conv2d_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && c0 > 0 && stride >= 1, "conv2d_fwd: bad dims");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && (pad >= H || pad >= W)), "conv2d_fwd: reflect pad >= size");
@@ -957,6 +970,22 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         const int sp = small_grid_splits(Cout, npix, Kp);
         if (sp > 1) {
             const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
+            if (split_ws) {   // per-slice partial tiles + fixed-order reduction: bit-reproducible forward
+                WgradEpiWS es{split_ws, Cout, (int)npix};
+                JP_KH_SWITCH(KH, {
+                    if (pad_mode == JP_PAD_REFLECT) {
+                        FwdBT<KH_, true> b{src, Cp, (int)npix, OH, OW, stride, pad};
+                        launch_auto(a, b, es, Cout, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+                    } else {
+                        FwdBT<KH_, false> b{src, Cp, (int)npix, OH, OW, stride, pad};
+                        launch_auto(a, b, es, Cout, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+                    }
+                });
+                const long total = npix * Cout;
+                hipLaunchKernelGGL(slice_reduce_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0,
+                                   st, split_ws, y, bias, Cout, (int)npix, OH * OW, jp_cdiv(Kp, kps), act);
+                JP_LAUNCH_CHECK();
+            }
             JP_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)npix * Cout, st));
             AtomicEpi ea{y, Cout, OH * OW};
             JP_KH_SWITCH(KH, {
@@ -997,9 +1026,22 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
 
 extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
                              int W, int Cout, int KH, int stride, int pad, int pad_mode, int act, float* ws,
-                             void* stream) {
+                             float* split_ws, void* stream) {
     return jp_conv2d_fwd_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, w, bias, y, N, H, W, Cout, KH, stride, pad,
-                              pad_mode, act, ws, stream);
+                              pad_mode, act, ws, split_ws, stream);
+}
+
+// floats of optional caller scratch (`split_ws`) for the split-K forward of layers whose tile grid cannot fill the
+// chip: with it the K slices are reduced in a fixed order (bit-reproducible); without it they meet in atomics.
+extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
+    if (Cin < 32) return 0;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+    const long npix = (long)N * OH * OW;
+    const int Kp = KH * KH * pad32(Cin);
+    const int sp = small_grid_splits(Cout, npix, Kp);
+    if (sp <= 1) return 0;
+    const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
+    return (long)jp_cdiv(Kp, kps) * Cout * npix;
 }
 
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const float* __restric
 // gather-form backward over a 64x8 INPUT tile: the covering dy / argmax patch is staged in LDS
 __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                           const uint8_t* __restrict__ idx, float* __restrict__ dx,
-                                                          int H, int W, int OH, int OW, int k, int s, int p, int pw,
-                                                          int ph) {
+                                                          const float* __restrict__ addend, int H, int W, int OH,
+                                                          int OW, int k, int s, int p, int pw, int ph) {
     extern __shared__ float tile[];           // [ph*pw] dy  then  [ph*pw] idx (as int)
     int* itile = reinterpret_cast<int*>(tile + pw * ph);
     const size_t nc = blockIdx.z;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restric
                 if (itile[li] == ky * k + kx) g += tile[li];
             }
         }
+        if (addend) g += addend[nc * H * W + iy * W + ix];
         dx[nc * H * W + iy * W + ix] = g;
     }
 }
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(TPB) void maxpool_fwd_t_kernel(const float* __restr
 template <int K>
 __global__ __launch_bounds__(TPB) void maxpool_bwd_s1_kernel(const float* __restrict__ dy,
                                                              const uint8_t* __restrict__ idx, float* __restrict__ dx,
-                                                             int H, int W, int OH, int OW, int p) {
+                                                             const float* __restrict__ addend, int H, int W, int OH,
+                                                             int OW, int p) {
     constexpr int PW = MP_TW + K - 1, PH = MPF_TH + K - 1;
     __shared__ float tile[PW * PH];
     __shared__ int itile[PW * PH];
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_s1_kernel(const float* __rest
                 const int li = (ty + K - 1 - ky) * PW + tx + K - 1 - kx;
                 g += itile[li] == ky * K + kx ? tile[li] : 0.f;
             }
+        if (addend) g += addend[nc * H * W + iy * W + ix];
         dx[nc * H * W + iy * W + ix] = g;
     }
 }
@@ -553,20 +556,22 @@ extern "C" int jp_maxpool_fwd(const float* x, float* y, uint8_t* idx, int NC, in
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int NC, int H, int W, int k, int s,
-                              int p, void* stream) {
+// dx = (addend ? addend : 0) + scatter of dy through the saved argmax; `addend` (may be NULL, may not alias dx) lets a
+// residual branch's gradient be folded in without a separate accumulation pass (CRP chains, layers.py:193-198)
+extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, const float* addend, int NC, int H,
+                              int W, int k, int s, int p, void* stream) {
     JP_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_bwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
     if (k == 5 && s == 1) {
         hipLaunchKernelGGL((maxpool_bwd_s1_kernel<5>), dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MPF_TH), NC), dim3(TPB), 0, st,
-                           dy, idx, dx, H, W, OH, OW, p);
+                           dy, idx, dx, addend, H, W, OH, OW, p);
         JP_LAUNCH_CHECK();
     }
     // outputs that can cover a 64x8 input tile
     const int pw = (MP_TW + k - 2) / s + 2, ph = (MP_TH + k - 2) / s + 2;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MP_TH), NC), dim3(TPB),
-                       2 * sizeof(float) * pw * ph, st, dy, idx, dx, H, W, OH, OW, k, s, p, pw, ph);
+                       2 * sizeof(float) * pw * ph, st, dy, idx, dx, addend, H, W, OH, OW, k, s, p, pw, ph);
     JP_LAUNCH_CHECK();
 }
 

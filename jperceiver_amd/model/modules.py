@@ -96,12 +96,39 @@ class CRPBlock(nn.Module):
         self.n_stages = n_stages
 
     def _fwd(self, x):
-        top = x
-        for i in range(self.n_stages):
-            top = ops.maxpool(top, 5, 1, 2)
-            top = getattr(self, "{}_{}".format(i + 1, "pointwise"))._fwd(top)
-            x = ops.add(top, x)
-        return x
+        outer = ops.current_tape()
+        if outer is None or not x.rg:
+            top = x
+            for i in range(self.n_stages):
+                top = ops.maxpool(top, 5, 1, 2)
+                top = getattr(self, "{}_{}".format(i + 1, "pointwise"))._fwd(top)
+                x = ops.add(top, x)
+            return x
+        # Training: the output gradient G reaches every `top_i` and the block input unchanged through the adds, so
+        # the whole chain is ONE node of the outer tape.  Its backward replays a private tape of the pools and convs
+        # with G folded into each max-pool backward kernel (g(top_{i-1}) = G + pool_bwd(conv_dgrad(g(top_i)))):
+        # no per-stage gradient-accumulation pass.
+        private, G = ops.Tape(), [None]
+        acc, top = x.t, x
+        with ops.recording(private):
+            for i in range(self.n_stages):
+                top = ops.maxpool(top, 5, 1, 2, bwd_addend=lambda: G[0])
+                top = getattr(self, "{}_{}".format(i + 1, "pointwise"))._fwd(top)
+                nxt = torch.empty_like(acc)
+                ops.call("jp_axpby", top.t, acc, nxt, nxt.numel(), 1.0, 1.0)
+                acc = nxt
+        out = Var(acc, True)
+        last = top
+
+        def bwd():
+            if out.g is None:
+                return
+            G[0] = last.g = out.g
+            private.backward()
+            G[0] = out.g = None
+
+        outer.record(bwd)
+        return out
 
     def forward(self, x):
         return self._fwd(Var(x)).t

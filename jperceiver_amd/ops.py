@@ -130,8 +130,10 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
     bt = b.t if b is not None else None
     # scratch for the packed-weight (tap-major) fast path; None -> generic path (few reduction channels)
     ws_f = _new((_ws_floats(Cin, Cout, KH, 0),), w.t) if Cin >= 32 else None
-    call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act, ws_f)
-    del ws_f
+    nsp = int(_jplib().fn["jp_conv2d_fwd_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
+    ws_s = _new((nsp,), w.t) if nsp else None      # fixed-order split-K reduction of small-grid layers
+    call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act, ws_f, ws_s)
+    del ws_f, ws_s
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
 
     def bwd():
@@ -223,7 +225,13 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
 
 
 # ------------------------------------------------------------------------------------------- pooling etc.
-def maxpool(x: Var, k, s, p) -> Var:
+def current_tape():
+    return _TAPE
+
+
+def maxpool(x: Var, k, s, p, bwd_addend=None) -> Var:
+    """nn.MaxPool2d.  `bwd_addend` (callable -> tensor | None, evaluated at backward time) is added to the input
+    gradient inside the backward kernel: a residual branch's gradient without an accumulation pass."""
     N, C, H, W = x.t.shape
     OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     y = _new((N, C, OH, OW), x.t)
@@ -235,7 +243,7 @@ def maxpool(x: Var, k, s, p) -> Var:
         if out.g is None:
             return
         dx = torch.empty_like(x.t)
-        call("jp_maxpool_bwd", out.g, idx, dx, N * C, H, W, k, s, p)
+        call("jp_maxpool_bwd", out.g, idx, dx, bwd_addend() if bwd_addend is not None else None, N * C, H, W, k, s, p)
         x.add_grad(dx)
         out.g = None
 

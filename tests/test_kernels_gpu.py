@@ -170,6 +170,35 @@ def test_maxpool(k, s, p, H, W):
     close(xv.g, xr.grad, rtol=1e-6)
 
 
+def test_crp_block_single_node_backward():
+    """CRPBlock (layers.py:184-199) runs as one tape node whose backward folds the residual gradient into the
+    max-pool backward kernels; values and all gradients must match the plain autograd chain."""
+    from jperceiver_amd.model.modules import CRPBlock
+    torch.manual_seed(0)
+    blk = CRPBlock(32, 32, 4).to(DEV)
+    x = rnd(2, 32, 20, 28, seed=1)
+    x = torch.round(x * 4) / 4                       # ties in the 5x5 windows
+    xv = Var(x, True)
+    tape = Tape()
+    with recording(tape):
+        y = blk._fwd(ops.act(xv, ops.ACT_RELU))      # a producer node in front, as in the decoder
+    xr = x.clone().requires_grad_(True)
+    ws = [getattr(blk, f"{i + 1}_pointwise").conv.weight for i in range(4)]
+    wr = [w.detach().clone().requires_grad_(True) for w in ws]
+    top = acc = F.relu(xr)
+    for w in wr:
+        top = F.conv2d(F.max_pool2d(top, 5, 1, 2), w)
+        acc = top + acc
+    close(y.t, acc, msg="fwd")
+    gy = rnd(*acc.shape, seed=2)
+    y.g = gy.clone()
+    tape.backward()
+    acc.backward(gy)
+    close(xv.g, xr.grad, rtol=2e-4, msg="dx")
+    for w, r in zip(ws, wr):
+        close(w.grad, r.grad, rtol=3e-4, msg="dw")   # ops.param accumulates into .grad
+
+
 @pytest.mark.parametrize("H,W", [(5, 7), (6, 8), (3, 6)])   # scalar, float4 and float2 code paths
 def test_upsample_cat_add_mask_act(H, W):
     x = rnd(2, 6, H, W, seed=1)

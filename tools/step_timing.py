@@ -38,7 +38,8 @@ def timed(name, *a):
     elif name == "jp_conv2d_wgrad_src3":
         key = "wgrad %4d->%4d k%d s%d @%4d fl=%.1f" % (a[1] + a[4] + a[7], a[14], a[15], a[16], a[12], 2e-9 * a[11] * (a[12] // a[16]) * (a[13] // a[16]) * a[14] * (a[1] + a[4] + a[7]) * a[15] ** 2)
     elif name in ("jp_maxpool_fwd", "jp_maxpool_bwd"):
-        key = "%s NC=%d %dx%d k%d s%d" % (name, a[3], a[4], a[5], a[6], a[7])
+        o = 1 if name == "jp_maxpool_bwd" else 0
+        key = "%s NC=%d %dx%d k%d s%d" % (name, a[3 + o], a[4 + o], a[5 + o], a[6 + o], a[7 + o])
     elif name == "jp_bn_train_fwd":
         key = "bn_fwd N=%d C=%d HW=%d res=%d MB=%.0f" % (a[10], a[11], a[12], a[3] is not None, 4e-6 * a[10] * a[11] * a[12])
     elif name == "jp_bn_train_bwd":
