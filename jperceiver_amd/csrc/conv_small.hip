@@ -126,6 +126,85 @@ __global__ __launch_bounds__(TPB) void conv_small_wgrad_kernel(Src3s src, const 
     }
 }
 
+// Single full-resolution source: LDS-tiled wgrad.  grid (64-row bands, Cin, batch); a workgroup walks the 16x64 tiles
+// of its band, stages tile + halo once (padding resolved while staging) and every thread owns 4 vertically adjacent
+// pixels, so a staged row is read once from LDS for all the taps that use it; one reduction per workgroup at the end.
+template <int CO>
+__global__ __launch_bounds__(TPB) void conv_small_wgrad_tiled_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ dy,
+                                                                     float* __restrict__ dw, int Cin, int H, int W,
+                                                                     int reflect) {
+    constexpr int TW = 64, TH = 16, PW = TW + 2, PH = TH + 2, BAND = 64;
+    __shared__ float tile[PH * PW];
+    __shared__ float red[4][CO * 9];
+    const int ci = blockIdx.y, img = blockIdx.z;
+    const int HW = H * W;
+    const float* xp = x + ((size_t)img * Cin + ci) * HW;
+    const float* dp = dy + (size_t)img * CO * HW;
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float acc[CO * 9];
+#pragma unroll
+    for (int i = 0; i < CO * 9; ++i) acc[i] = 0.f;
+    const int yend = min(H, (int)(blockIdx.x + 1) * BAND);
+    for (int ty0 = blockIdx.x * BAND; ty0 < yend; ty0 += TH) {
+        for (int tx0 = 0; tx0 < W; tx0 += TW) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < PH * PW; i += TPB) {
+                const int ly = i / PW, lx = i - ly * PW;
+                int iy = ty0 - 1 + ly, ix = tx0 - 1 + lx;
+                float v = 0.f;
+                if (reflect) {
+                    iy = jp_reflect(min(iy, H), H);
+                    ix = jp_reflect(min(ix, W), W);
+                    v = xp[iy * W + ix];
+                } else if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    v = xp[iy * W + ix];
+                }
+                tile[i] = v;
+            }
+            __syncthreads();
+            const int xo = tx0 + tx;
+            float g[4][CO];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yo = ty0 + q * 4 + j;
+                const bool ok = yo < H && xo < W;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) g[j][c] = ok ? dp[(size_t)c * HW + yo * W + xo] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const float* row = tile + (q * 4 + r) * PW + tx;
+                const float v0 = row[0], v1 = row[1], v2 = row[2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ky = r - j;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        acc[c * 9 + ky * 3 + 0] = fmaf(g[j][c], v0, acc[c * 9 + ky * 3 + 0]);
+                        acc[c * 9 + ky * 3 + 1] = fmaf(g[j][c], v1, acc[c * 9 + ky * 3 + 1]);
+                        acc[c * 9 + ky * 3 + 2] = fmaf(g[j][c], v2, acc[c * 9 + ky * 3 + 2]);
+                    }
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < CO * 9; ++i) {
+        const float s = jp_wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < CO * 9) {
+        const int i = threadIdx.x;
+        const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        const int c = i / 9, t = i - c * 9;
+        atomicAdd(dw + ((size_t)c * Cin + ci) * 9 + t, s);
+    }
+}
+
 Src3s make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
                int H, int W) {
     Src3s s;
@@ -165,6 +244,18 @@ int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c
                         hipStream_t st) {
     const int Cin = c0 + c1 + c2;
     const Src3s src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
+    if (src.nseg == 1 && src.s[0].sh == 0 && H >= 2 && W >= 2) {   // single full-resolution source: LDS-tiled kernel
+        const dim3 gt(jp_cdiv(H, 64), Cin, N);
+#define JP_GT(CO) hipLaunchKernelGGL((conv_small_wgrad_tiled_kernel<CO>), gt, dim3(TPB), 0, st, src.s[0].p, dy, dw, Cin, H, W, reflect)
+        switch (Cout) {
+            case 1: JP_GT(1); break;
+            case 2: JP_GT(2); break;
+            case 3: JP_GT(3); break;
+            default: JP_GT(4); break;
+        }
+#undef JP_GT
+        return 0;
+    }
     // chunks so that ~2k blocks stream the input, >= 4k pixels each
     int chunks = std::max(1, 2048 / std::max(1, Cin * N));
     chunks = std::min(chunks, std::max(1, H * W / 4096));

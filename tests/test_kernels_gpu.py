@@ -61,6 +61,8 @@ CONV_CASES = [
     (2, 256, 16, 16, 128, 3, 1, 1, 0, 1, True),     # scalar-base uniform-tap wgrad, zero pad
     (5, 64, 6, 10, 64, 3, 1, 1, 0, 0, False),       # pixel tiles straddling several images (relative-image offsets)
     (5, 96, 6, 10, 160, 3, 1, 1, 1, 0, False),      # ... reflect
+    (2, 8, 70, 130, 1, 3, 1, 1, 1, 3, True),        # small-Cout head over several LDS tiles / row bands, reflect
+    (1, 5, 80, 66, 3, 3, 1, 1, 0, 0, True),         # ... zero pad, Cout=3
 ]
 
 
