@@ -464,6 +464,106 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
+// ---- 3x3 stride-2 pad-1 dgrad (ResNet downsampling convs), parity-class form.  An input pixel (y, x) is reached only
+// through taps with ty = y+1 (mod 2), tx = x+1 (mod 2): 1, 2, 2 or 4 of the 9.  Input pixels are enumerated class-major
+// n = (class (py,px), img, i, j) with y = 2i+py, x = 2j+px, so a pixel tile is class-uniform and the K loop runs over
+// 4 tap slots (r, s) instead of 9 taps; slots a class does not have are masked.  (H, W even; class size % 256 == 0.)
+struct PackAS2St {
+    const float* base;
+    unsigned voff;
+    int py, px;
+};
+struct PackAS2 {   // A[m=ci][k=(cc, slot, c)] = wp[(tap(slot, class)*M + m)*Cp + c]
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    static constexpr bool WANTS_TILE = true;
+    typedef PackAS2St St;
+    const float* wp;
+    int M, Cp, Nc;   // Nc = pixels per class
+    __device__ __forceinline__ void init(St& st, int, int, int, int n0) const {
+        st.base = wp;
+        st.voff = ((threadIdx.x >> 5) * Cp + (threadIdx.x & 31)) * 4u;
+        const int cls = n0 / Nc;
+        st.py = cls >> 1;
+        st.px = cls & 1;
+    }
+    __device__ __forceinline__ void fix(St& st, int k) const {
+        const int q = __builtin_amdgcn_readfirstlane(k >> 5);
+        const int cc = q >> 2, r = (q >> 1) & 1, c = q & 1;
+        const int ty = st.py ? 2 * r : 1, tx = st.px ? 2 * c : 1;   // masked slots read a valid (unused) tap
+        st.base = wp + (size_t)(ty * 3 + tx) * M * Cp + cc * 32;
+    }
+    __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
+        const float* rp = st.base + (size_t)m_u * Cp;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+};
+
+struct DgradS2St {
+    int img_rel, i, j, img0, py, px;
+    const float* rowp;
+    unsigned voff;
+    int nm1, ok;
+};
+struct DgradS2B {  // B[k=(cc, slot, co)][n=(class, img, i, j)]
+    static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
+    typedef DgradS2St St;
+    const float* dy;
+    int Cp, Nc, H2, W2, Cout, OH, OW;
+    __device__ __forceinline__ void init(St& st, int p, int p0) const {
+        const int cls = p0 / Nc;                 // tile-uniform
+        st.py = cls >> 1;
+        st.px = cls & 1;
+        const int hw2 = H2 * W2;
+        const int q = min(p - cls * Nc, Nc - 1), q0 = p0 - cls * Nc;
+        const int img = q / hw2, pix = q - img * hw2;
+        st.i = pix / W2;
+        st.j = pix - st.i * W2;
+        st.img0 = q0 / hw2;
+        st.img_rel = img - st.img0;
+        st.rowp = dy;
+        st.voff = 0;
+        st.nm1 = 0;
+        st.ok = 0;
+    }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int q = kc >> 5;
+        const int cc = q >> 2, r = (q >> 1) & 1, c = q & 1;
+        const int co0 = cc << 5;
+        // odd rows: taps 0 and 2 -> dY rows i+1 and i; even rows: tap 1 -> dY row i (slot r = 1 does not exist)
+        int oy = st.i + st.py - r, ox = st.j + st.px - c;
+        st.ok = (st.py || r == 0) && (st.px || c == 0) && oy < OH && ox < OW;
+        oy = min(max(oy, 0), OH - 1);
+        ox = min(max(ox, 0), OW - 1);
+        const int ohw = OH * OW;
+        st.voff = (unsigned)(st.img_rel * Cout * ohw + oy * OW + ox) * 4u;
+        st.rowp = dy + (size_t)(st.img0 * Cout + co0) * ohw;
+        st.nm1 = min(32, Cout - co0) - 1;
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (OH * OW);
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+    __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
+};
+struct DgradS2Epi {  // dx[img][ci][2i+py][2j+px] (= or +=) acc
+    typedef size_t St;
+    float* dx;
+    int Cin, Nc, H2, W2, accumulate;
+    __device__ __forceinline__ St col(int n) const {
+        const int cls = n / Nc, q = n - cls * Nc;
+        const int hw2 = H2 * W2;
+        const int img = q / hw2, pix = q - img * hw2;
+        const int i = pix / W2, j = pix - i * W2;
+        return (size_t)img * Cin * (4 * hw2) + (size_t)(2 * i + (cls >> 1)) * (2 * W2) + 2 * j + (cls & 1);
+    }
+    __device__ __forceinline__ void put(St base, int m, float v) const {
+        float* q = dx + base + (size_t)m * (4 * H2 * W2);
+        *q = accumulate ? (*q + v) : v;
+    }
+};
+
 // Border pass of the reflection-pad adjoint.  N enumerates the 2W+2H border-adjacent pixels of every image
 // (rows 1 and H-2, columns 1 and W-2; duplicates masked); the gather returns only the folded-in ("extra")
 // dY entries: row extras r1 = 0 (y==1, ty==0) / H-1 (y==H-2, ty==2), column extras likewise.
@@ -1059,6 +1159,16 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
         PackA a{ws, Cin, Kp, Cp, KH * KH};
         const int sp = small_grid_splits(Cin, npix, Kp);
+        const long Nc = (long)N * (H / 2) * (W / 2);
+        if (KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 && Nc % 256 == 0 &&
+            2 * OH == H && 2 * OW == W) {
+            // parity-class form: 4 tap slots instead of 9 taps per input pixel
+            PackAS2 a2{ws, Cin, Cp, (int)Nc};
+            DgradS2B b2{dy, Cp, (int)Nc, H / 2, W / 2, Cout, OH, OW};
+            DgradS2Epi e2{dx, Cin, (int)Nc, H / 2, W / 2, accumulate};
+            launch_auto(a2, b2, e2, Cin, (int)npix, 4 * Cp, 1, 4 * Cp, st);
+            JP_LAUNCH_CHECK();
+        }
         if (sp > 1) {
             const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
             if (!accumulate) JP_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)npix * Cin, st));

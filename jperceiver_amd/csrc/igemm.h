@@ -32,6 +32,8 @@ template <class L, class = void> struct jp_has_post : std::false_type {};
 template <class L> struct jp_has_post<L, std::void_t<decltype(L::POST)>> : std::true_type {};
 template <class E, class = void> struct jp_epi_wants_slice : std::false_type {};   // put(st, m, v, k_slice)
 template <class E> struct jp_epi_wants_slice<E, std::void_t<decltype(E::WANTS_SLICE)>> : std::true_type {};
+template <class L, class = void> struct jp_wants_tile : std::false_type {};   // init(st, first, step, m0, n0)
+template <class L> struct jp_wants_tile<L, std::void_t<decltype(L::WANTS_TILE)>> : std::true_type {};
 template <class L, class = void> struct jp_has_split : std::false_type {};
 template <class L> struct jp_has_split<L, std::void_t<decltype(L::SPLIT)>> : std::true_type {};
 
@@ -108,8 +110,10 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
     const int b_var_l = BLoad::ALONG_K ? (t / KC) : __builtin_amdgcn_readfirstlane(t / BN);
     typename ALoad::St sa;
     typename BLoad::St sb;
-    if constexpr (ALoad::ALONG_K) al.init(sa, m0 + a_var_l, A_ROWS);
-    else if constexpr (jp_has_post<ALoad>::value) al.init(sa, m0 + a_fix_l, m0);
+    if constexpr (ALoad::ALONG_K) {
+        if constexpr (jp_wants_tile<ALoad>::value) al.init(sa, m0 + a_var_l, A_ROWS, m0, n0);
+        else al.init(sa, m0 + a_var_l, A_ROWS);
+    } else if constexpr (jp_has_post<ALoad>::value) al.init(sa, m0 + a_fix_l, m0);
     else al.init(sa, m0 + a_fix_l);
     if constexpr (BLoad::ALONG_K) bl.init(sb, n0 + b_var_l, B_ROWS);
     else if constexpr (jp_has_post<BLoad>::value) bl.init(sb, n0 + b_fix_l, n0);
