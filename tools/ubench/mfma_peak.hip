@@ -17,15 +17,30 @@ __global__ __launch_bounds__(256) void kg(float* out, const float* __restrict__ 
     const float* ap = As + (lane >> 5) * 129 + (wave >> 1) * 64 + (lane & 31);
     const float* bp = Bs + (lane >> 5) * 129 + (wave & 1) * 64 + (lane & 31);
     float ra[16], rb[16];
+    float4 ra4[4];
     auto gload = [&](int it) {
         const float* q = src + (MODE == 4 ? ((size_t)blockIdx.x * 8192 + (size_t)it * 8192 * 1024) % span : 0);
+        if (MODE == 7) {   // A operand: 4 x dwordx4 per thread (pre-packed weights), B: 16 dword gathers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { ra[r] = q[r * 256 + t]; rb[r] = q[4096 + r * 256 + t]; }
+            for (int r = 0; r < 4; ++r) ra4[r] = reinterpret_cast<const float4*>(q)[r * 256 + t];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rb[r] = q[4096 + r * 256 + t];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ra[r] = q[r * 256 + t]; rb[r] = q[4096 + r * 256 + t]; }
+        }
     };
     gload(0);
     for (int it = 0; it < iters; ++it) {
+        if (MODE == 7) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) reinterpret_cast<float4*>(As)[r * 256 + t] = ra4[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = rb[r];
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { As[(r * 2 + (t >> 7)) * 129 + (t & 127)] = ra[r]; Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = rb[r]; }
+        }
         __syncthreads();
         gload(it + 1);
         float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
@@ -45,7 +60,7 @@ __global__ __launch_bounds__(256) void kg(float* out, const float* __restrict__ 
     }
     float s = 0.f;
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-    out[blockIdx.x * 256 + t] = s + ra[0] + rb[0];
+    out[blockIdx.x * 256 + t] = s + (MODE == 7 ? ra4[0].x : ra[0]) + rb[0];
 }
 
 // MODE 6: same loop, but the staging is LDS-direct (global_load_lds_dword, no VGPR round trip, no ds_write), double
@@ -190,6 +205,7 @@ int main() {
     for (int bpc = 1; bpc <= 3; ++bpc) {
         rung<5>("igemm loop, L1/L2-hot source", 256 * bpc, 1000, out, src, span);
         rung<4>("igemm loop, streaming source", 256 * bpc, 1000, out, src, span);
+        rung<7>("igemm loop hot, A as 4x dwordx4+b128", 256 * bpc, 1000, out, src, span);
     }
     for (int bpc = 1; bpc <= 2; ++bpc) {
         runl<1>("lds-direct loop, hot source", 256 * bpc, 1000, out, src, span);
