@@ -821,8 +821,9 @@ struct WgradBUS {
     __device__ __forceinline__ float post(const St& st, float v, int) const { return (REFLECT || st.ok) ? v : 0.f; }
 };
 
-// 64-channel inputs: a 64*TPT wide N tile holds TPT whole filter taps, and slot group r (8 columns) belongs to tap
-// slot r/8 at compile time -> one per-lane offset per tap per chunk, every element one scalar-base load.
+// CPT-channel inputs (CPT = 16, 32 or 64): a CPT*TPT wide N tile holds TPT whole filter taps, and slot group r (8
+// columns) belongs to tap slot 8r/CPT at compile time -> one per-lane offset per tap per chunk, every element one
+// scalar-base load.
 template <int TPT>
 struct WgradBMSSt {
     int tap0;            // uniform: first tap of the tile
@@ -830,17 +831,17 @@ struct WgradBMSSt {
     unsigned voff[TPT];  // per-lane: (channel within the slot group, pixel shifted by tap slot s)
     unsigned ok;         // per-lane bit s: tap slot s lies inside the image (zero padding)
 };
-template <int KH, bool REFLECT, int TPT>
+template <int KH, bool REFLECT, int TPT, int CPT>
 struct WgradBMS {
     static constexpr bool ALONG_K = true;
     static constexpr bool SPLIT = true;
     static constexpr bool POST = true;
     typedef WgradBMSSt<TPT> St;
-    const float* x;      // already offset to the first channel of the 64-channel sub-range
+    const float* x;      // already offset to the first channel of the CPT-channel sub-range
     int Ctot, H, W, OH, OW, stride, pad;
     __device__ __forceinline__ void init(St& st, int n_first, int) const {
         const int n0 = __builtin_amdgcn_readfirstlane(n_first - (int)(threadIdx.x >> 5));
-        st.tap0 = n0 >> 6;
+        st.tap0 = n0 / CPT;
         st.base = x;
         st.ok = ~0u;
 #pragma unroll
@@ -873,11 +874,11 @@ struct WgradBMS {
         st.base = x + (size_t)img * Ctot * H * W;
     }
     __device__ __forceinline__ float get_u(const St& st, int, int r) const {
-        const float* rp = st.base + (size_t)((8 * r) & 63) * H * W;
-        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[(8 * r) >> 6]);
+        const float* rp = st.base + (size_t)((8 * r) % CPT) * H * W;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[(8 * r) / CPT]);
     }
     __device__ __forceinline__ float post(const St& st, float v, int r) const {
-        return (REFLECT || ((st.ok >> ((8 * r) >> 6)) & 1u)) ? v : 0.f;
+        return (REFLECT || ((st.ok >> ((8 * r) / CPT)) & 1u)) ? v : 0.f;
     }
 };
 
@@ -916,6 +917,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
         dw[((size_t)m * Ctot + c_off + ci) * KHW + tap] += s;
+    }
+}
+
+// many slices, few outputs (narrow layers: 16x144 outputs x ~700 slices): 64 outputs x 16 slice lanes per workgroup
+__global__ __launch_bounds__(1024) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                 int M, int Np, int splits, int Cp, int Cin, int KHW,
+                                                                 int c_off, int Ctot) {
+    __shared__ float part[16][65];
+    const long total = (long)M * Np;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (i < total)
+        for (int k = ty; k < splits; k += 16) s += ws[(size_t)k * total + i];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += part[k][tx];
+        const int m = (int)(i / Np), n = (int)(i - (long)m * Np);
+        const int tap = n / Cp, ci = n - tap * Cp;
+        if (ci < Cin) dw[((size_t)m * Ctot + c_off + ci) * KHW + tap] += s;
     }
 }
 
@@ -1039,8 +1062,8 @@ static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
 // which: 0 forward, 1 dgrad, 2 wgrad
 extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
-    if (which == 0) return Cin >= 32 ? ((long)KH * KH * Cout + 256) * pad32(Cin) : 0;
-    if (which == 1) return Cout >= 32 ? ((long)KH * KH * Cin + 256) * pad32(Cout) : 0;
+    if (which == 0) return Cin >= 16 ? ((long)KH * KH * Cout + 256) * pad32(Cin) : 0;
+    if (which == 1) return Cout >= 16 ? ((long)KH * KH * Cin + 256) * pad32(Cout) : 0;
     return 0;
 }
 
@@ -1063,7 +1086,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         JP_LAUNCH_CHECK();
     }
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
-    if (ws && Cin >= 32 && seg_aligned(c0, c1, c2)) {   // tap-major fast path
+    if (ws && Cin >= 16 && seg_aligned(c0, c1, c2)) {   // tap-major fast path (16-channel inputs: half-empty K chunks)
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
         PackA a{ws, Cout, Kp, Cp, KH * KH};
@@ -1134,7 +1157,7 @@ extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, 
 // floats of optional caller scratch (`split_ws`) for the split-K forward of layers whose tile grid cannot fill the
 // chip: with it the K slices are reduced in a fixed order (bit-reproducible); without it they meet in atomics.
 extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
-    if (Cin < 32) return 0;
+    if (Cin < 16) return 0;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW;
     const int Kp = KH * KH * pad32(Cin);
@@ -1154,7 +1177,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     JP_CHECK_ARG(npix < (1L << 31), "conv2d_dgrad: tensor too large");
     hipStream_t st = (hipStream_t)stream;
     DgradEpi e{dx, Cin, H * W, accumulate};
-    if (ws && Cout >= 32) {
+    if (ws && Cout >= 16) {
         const int Cp = pad32(Cout), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
         PackA a{ws, Cin, Kp, Cp, KH * KH};
@@ -1246,8 +1269,12 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
             WgradEpiWS ew{ws, Cout, Np};
             launch<true, WM, WN>(a_, b_, ew, Cout, Np, (int)npix, p.splits, p.kps, st);
             const long total = (long)Cout * Np;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st,
-                               ws, dw, Cout, Np, p.splits, e.Cp, e.Cin, e.KHW, e.c_off, e.Ctot);
+            if (p.splits >= 32 && total <= (1L << 16))
+                hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((int)((total + 63) / 64)), dim3(1024), 0, st, ws, dw, Cout,
+                                   Np, p.splits, e.Cp, e.Cin, e.KHW, e.c_off, e.Ctot);
+            else
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st,
+                                   ws, dw, Cout, Np, p.splits, e.Cp, e.Cin, e.KHW, e.c_off, e.Ctot);
         } else {
             launch<true, WM, WN>(a_, b_, e, Cout, Np, (int)npix, p.splits, p.kps, st);
         }
@@ -1306,21 +1333,32 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
             const int rc = run_table(Cm, tail);
             if (rc) return rc;
         }
-    } else if (single && Cin == 64 && (OH * OW) % 32 == 0 && Cout % 8 == 0 && (long)8 * H * W * 4 < (1L << 31)) {
-        // 64 input channels (ResNet stem / layer1): whole taps per N tile, scalar-base loaders
-        const int Np = KH * KH * 64;
-        const unsigned magic = (unsigned)((1ULL << 32) / 64u) + 1u;
-        WgradEpiT e{dw, 64, 64, KH * KH, 0, Cin, magic};
+    } else if (single && (Cin == 64 || ((Cin == 16 || Cin == 32) && Cout <= 64)) && (OH * OW) % 32 == 0 && Cout % 8 == 0 &&
+               (long)8 * H * W * 4 < (1L << 31)) {
+        // 16 / 32 / 64 input channels (ResNet stem + layer1, BEV decoder): whole taps per N tile, scalar-base loaders
+        const int Np = KH * KH * Cin;
+        const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cin) + 1u;
+        WgradEpiT e{dw, Cin, Cin, KH * KH, 0, Cin, magic};
         WgradAS as{dy, Cout, (int)npix, OH * OW};
+#define JP_BMS(REFL, WMv, WNv, TPTv, CPTv)                                              \
+    {                                                                                   \
+        WgradBMS<KH_, REFL, TPTv, CPTv> b{x0, Cin, H, W, OH, OW, stride, pad};          \
+        go(std::integral_constant<int, WMv>{}, std::integral_constant<int, WNv>{}, as, b, e, Np); \
+    }
         JP_KH_SWITCH(KH, {
             if (pad_mode == JP_PAD_REFLECT) {
-                if (Cout <= 64) { WgradBMS<KH_, true, 4> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I1{}, I4{}, as, b, e, Np); }
-                else { WgradBMS<KH_, true, 2> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I2{}, I2{}, as, b, e, Np); }
+                if (Cin == 16) JP_BMS(true, 1, 4, 16, 16)
+                else if (Cin == 32) JP_BMS(true, 1, 4, 8, 32)
+                else if (Cout <= 64) JP_BMS(true, 1, 4, 4, 64)
+                else JP_BMS(true, 2, 2, 2, 64)
             } else {
-                if (Cout <= 64) { WgradBMS<KH_, false, 4> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I1{}, I4{}, as, b, e, Np); }
-                else { WgradBMS<KH_, false, 2> b{x0, Cin, H, W, OH, OW, stride, pad}; go(I2{}, I2{}, as, b, e, Np); }
+                if (Cin == 16) JP_BMS(false, 1, 4, 16, 16)
+                else if (Cin == 32) JP_BMS(false, 1, 4, 8, 32)
+                else if (Cout <= 64) JP_BMS(false, 1, 4, 4, 64)
+                else JP_BMS(false, 2, 2, 2, 64)
             }
         });
+#undef JP_BMS
     } else if (single) {
         const int rc = run_table(0, Cin);
         if (rc) return rc;
@@ -1349,9 +1387,9 @@ extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
 extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW, cap = 32L << 20;
-    if ((OH * OW) % 32 != 0 || Cout % 8 != 0 || Cin < 64) return 0;
-    const int Np = KH * KH * (Cin / 64 * 64);
-    const bool narrow = Cout <= 64 && Cin == 64;
+    if ((OH * OW) % 32 != 0 || Cout % 8 != 0 || Cin < 16) return 0;
+    const int Np = KH * KH * (Cin >= 64 ? Cin / 64 * 64 : Cin);
+    const bool narrow = Cout <= 64 && Cin <= 64;
     const WgradPlan p = wgrad_plan(Cout, Np, npix, narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
     return p.use_ws ? p.ws_need : 0;
 }

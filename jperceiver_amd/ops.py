@@ -129,7 +129,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             s3 += [None, 0, 0]
     bt = b.t if b is not None else None
     # scratch for the packed-weight (tap-major) fast path; None -> generic path (few reduction channels)
-    ws_f = _new((_ws_floats(Cin, Cout, KH, 0),), w.t) if Cin >= 32 else None
+    ws_f = _new((_ws_floats(Cin, Cout, KH, 0),), w.t) if Cin >= 16 else None
     nsp = int(_jplib().fn["jp_conv2d_fwd_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
     ws_s = _new((nsp,), w.t) if nsp else None      # fixed-order split-K reduction of small-grid layers
     call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act, ws_f, ws_s)
@@ -170,7 +170,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
                 del ws_w
         if any(v.rg for v, _ in srcs):
-            ws_d = _new((_ws_floats(Cin, Cout, KH, 1),), w.t) if Cout >= 32 else None
+            ws_d = _new((_ws_floats(Cin, Cout, KH, 1),), w.t) if Cout >= 16 else None
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()
                 call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc, ws_d)

@@ -63,6 +63,10 @@ CONV_CASES = [
     (5, 96, 6, 10, 160, 3, 1, 1, 1, 0, False),      # ... reflect
     (2, 8, 70, 130, 1, 3, 1, 1, 1, 3, True),        # small-Cout head over several LDS tiles / row bands, reflect
     (1, 5, 80, 66, 3, 3, 1, 1, 0, 0, True),         # ... zero pad, Cout=3
+    (2, 16, 16, 24, 16, 3, 1, 1, 0, 1, True),       # BEV decoder 16->16: half-empty K chunks, 16 taps slots / wgrad tile
+    (2, 32, 16, 24, 32, 3, 1, 1, 0, 0, False),      # 32->32
+    (2, 32, 16, 24, 16, 3, 1, 1, 1, 0, True),       # 32->16 reflect
+    (2, 16, 9, 11, 24, 3, 1, 1, 0, 0, False),       # 16 channels, odd map (table wgrad)
 ]
 
 
