@@ -495,7 +495,7 @@ extern "C" int jp_scale_loss_fwd(const float* disp, int hs, int ws, const float*
     JP_CHECK_ARG(disp && label && acc && B > 0, "scale_loss_fwd: bad args");
     JP_ST;
     JP_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2, st));
-    hipLaunchKernelGGL(scale_fwd_kernel, dim3(std::min(jp_cdiv((long)FH * FW, TPB), 2048), B), dim3(TPB), 0, st, disp, hs,
+    hipLaunchKernelGGL(scale_fwd_kernel, dim3(std::min(jp_cdiv((long)FH * FW, TPB), 96), B), dim3(TPB), 0, st, disp, hs,
                        ws, label, acc, FH, FW, 1.f / max_depth, 1.f / min_depth, y_lo, y_hi, x_lo, x_hi);
     JP_LAUNCH_CHECK();
 }

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(TPB) void cgt_warp_fwd_kernel(const float* __restri
 }
 
 // dpred (B,3,H,W) -> ddisp_up (B,1,H,W) (accumulated over source frames) and dP (B,12) doubles
+constexpr int CGT_PPT = 8;
 __global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restrict__ dpred,
                                                            const float* __restrict__ disp, int hs, int ws,
                                                            const float* __restrict__ invK,
@@ -209,11 +210,13 @@ __global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restri
                                                            int accumulate) {
     __shared__ float red[12][4];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * TPB + threadIdx.x;
     float dPl[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dPl[i] = 0.f;
-    if (p < H * W) {
+    // CGT_PPT pixels per thread: the 12 wave reductions + double atomics of dP are paid once per 2048 pixels
+    for (int it = 0; it < CGT_PPT; ++it) {
+        const int p = (blockIdx.x * CGT_PPT + it) * TPB + threadIdx.x;
+        if (p >= H * W) break;
         const int y = p / W, x = p - y * W;
         const float* Pb = Pm + 12 * b;
         const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pb, y, x, H, W, min_disp,
@@ -244,9 +247,9 @@ __global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restri
         const float dpx = du / zi, dpy = dv / zi;
         const float dpz = -(du * g.px + dv * g.py) / (zi * zi);
         const float X = g.depth * g.rx, Y = g.depth * g.ry, Z = g.depth * g.rz;
-        dPl[0] = dpx * X; dPl[1] = dpx * Y; dPl[2] = dpx * Z; dPl[3] = dpx;
-        dPl[4] = dpy * X; dPl[5] = dpy * Y; dPl[6] = dpy * Z; dPl[7] = dpy;
-        dPl[8] = dpz * X; dPl[9] = dpz * Y; dPl[10] = dpz * Z; dPl[11] = dpz;
+        dPl[0] += dpx * X; dPl[1] += dpx * Y; dPl[2] += dpx * Z; dPl[3] += dpx;
+        dPl[4] += dpy * X; dPl[5] += dpy * Y; dPl[6] += dpy * Z; dPl[7] += dpy;
+        dPl[8] += dpz * X; dPl[9] += dpz * Y; dPl[10] += dpz * Z; dPl[11] += dpz;
         const float dX = Pb[0] * dpx + Pb[4] * dpy + Pb[8] * dpz;
         const float dY = Pb[1] * dpx + Pb[5] * dpy + Pb[9] * dpz;
         const float dZ = Pb[2] * dpx + Pb[6] * dpy + Pb[10] * dpz;
@@ -516,7 +519,7 @@ extern "C" int jp_cgt_warp_bwd(const float* dpred, const float* disp, int hs, in
                                float min_depth, float max_depth, int accumulate, void* stream) {
     JP_CHECK_ARG(dpred && disp && invK && P && color && ddisp_up && dP && B > 0, "cgt_warp_bwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv((long)H * W, TPB), B), dim3(TPB), 0, st, dpred, disp, hs, ws,
+    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv((long)H * W, TPB * CGT_PPT), B), dim3(TPB), 0, st, dpred, disp, hs, ws,
                        invK, P, color, ddisp_up, dP, H, W, 1.f / max_depth, 1.f / min_depth, accumulate);
     JP_LAUNCH_CHECK();
 }
