@@ -206,7 +206,8 @@ def measure_roofline(runner, batch, _lib):
         e1.record()
         Cin = c0 + c1 + c2
         alg_bytes = 4.0 * (N * Cin * H * W + N * Cout * OH * OW + Cout * Cin * KH * KH)   # read x once, write y once, read w
-        rec.append((KH if a[19] == 1 else -KH, Cout, N * OH * OW, 2.0 * N * OH * OW * Cout * Cin * KH * KH, e0, e1, alg_bytes))
+        fused_up = (c0 and a[2]) or (c1 and a[5]) or (c2 and a[8])   # iconv layers run the parity-class kernel instead
+        rec.append((KH if (a[19] == 1 and not fused_up) else -KH, Cout, N * OH * OW, 2.0 * N * OH * OW * Cout * Cin * KH * KH, e0, e1, alg_bytes))
     from jperceiver_amd import ops
     ops.call = timed_call
     try:

@@ -464,6 +464,163 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
+// ---- Upsample-aware 3x3 reflect conv (iconv layers: cat(reduce, up2x(x), disp), depth_decoder.py:68,76-77).
+// For the nearest-2x upsampled segment U = up(X) an output pixel (2i+a, 2j+b) sees only a 2x2 patch of X through its
+// 9 taps: rows {i-1+a, i+a} x cols {j-1+b, j+b} (reflection padding of U == edge clamp on X).  Output pixels are
+// enumerated parity-class-major n = (class (a,b), img, i, j) so a tile is class-uniform; the K loop then runs 9 taps
+// over the full-resolution segments but only 4 slots (r, s) over the upsampled one, against weights pre-summed per
+// class:  W'_{ab}[r][s] = sum_{dy in Dy(a,r)} sum_{dx in Dx(b,s)} W[dy][dx],  Dy(0,.) = {0},{1,2}; Dy(1,.) = {0,1},{2}.
+// 27.7 % fewer MFMA FLOPs on the 513-channel layers.
+struct ParSeg {       // K-chunk layout of the three channel segments
+    int q0, q1;       // cumulative chunk counts after segment 0 / 1
+    int t0, t1, t2;   // taps (9) or slots (4) per channel chunk of each segment
+    int o0, o1, o2;   // float offset of each segment's packed weights in ws
+    int p0, p1, p2;   // padded channel count (row length) of each segment
+};
+struct PackAPSt {
+    const float* base;
+    unsigned rg, cl, Cp;   // row group (t>>5), channel in chunk (t&31), row length of the current segment
+    int cls;
+};
+struct PackAP {   // A[m=co][k] for the segment-piecewise K order; up segments hold [class][slot][co][Cp]
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    static constexpr bool WANTS_TILE = true;
+    typedef PackAPSt St;
+    const float* wp;
+    ParSeg ps;
+    int M, Nc;
+    __device__ __forceinline__ void init(St& st, int, int, int, int n0) const {
+        st.base = wp;
+        st.rg = threadIdx.x >> 5;
+        st.cl = threadIdx.x & 31;
+        st.Cp = 32;
+        st.cls = n0 / Nc;
+    }
+    __device__ __forceinline__ void fix(St& st, int k) const {
+        const int q = __builtin_amdgcn_readfirstlane(k >> 5);
+        const bool a = q < ps.q0, b = q < ps.q1;
+        const int ql = a ? q : (b ? q - ps.q0 : q - ps.q1);
+        const int T = a ? ps.t0 : (b ? ps.t1 : ps.t2);
+        const int off = a ? ps.o0 : (b ? ps.o1 : ps.o2);
+        const int Cp = a ? ps.p0 : (b ? ps.p1 : ps.p2);
+        const int cc = ql / T, t = ql - cc * T;
+        const int plane = T == 4 ? st.cls * 4 + t : t;      // [class][slot] or [tap]
+        st.base = wp + off + (size_t)plane * M * Cp + cc * 32;
+        st.Cp = Cp;
+    }
+    __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
+        const float* rp = st.base + (size_t)m_u * st.Cp;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + (st.rg * st.Cp + st.cl) * 4u);
+    }
+};
+
+struct FwdBPSt {
+    int img_rel, i, j, img0, a, b;
+    const float* rowp;
+    unsigned voff;
+    int hw, nm1;
+};
+struct FwdBP {  // B[k][n=(class, img, i, j)], 3x3 stride 1 reflection pad
+    static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
+    typedef FwdBPSt St;
+    Src3 src;
+    ParSeg ps;
+    int Nc, h2, w2;    // pixels per class, half-resolution size
+    __device__ __forceinline__ void init(St& st, int p, int p0) const {
+        const int cls = p0 / Nc;
+        st.a = cls >> 1;
+        st.b = cls & 1;
+        const int hw2 = h2 * w2;
+        const int q = min(p - cls * Nc, Nc - 1), q0 = p0 - cls * Nc;
+        const int img = q / hw2, pix = q - img * hw2;
+        st.i = pix / w2;
+        st.j = pix - st.i * w2;
+        st.img0 = q0 / hw2;
+        st.img_rel = img - st.img0;
+        st.rowp = src.p0;
+        st.voff = 0;
+        st.hw = 0;
+        st.nm1 = 0;
+    }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int q = kc >> 5;
+        const bool sa = q < ps.q0, sb = q < ps.q1;
+        const int ql = sa ? q : (sb ? q - ps.q0 : q - ps.q1);
+        const int T = sa ? ps.t0 : (sb ? ps.t1 : ps.t2);
+        const float* p = sa ? src.p0 : (sb ? src.p1 : src.p2);
+        const int Cs = sa ? src.e0 : (sb ? src.e1 - src.e0 : src.e2 - src.e1);
+        const int cc = ql / T, t = ql - cc * T;
+        int yy, xx, h, w;
+        if (T == 4) {      // upsampled segment: 2x2 patch of the half-resolution tensor, edge-clamped
+            h = h2; w = w2;
+            yy = min(max(st.i - 1 + st.a + (t >> 1), 0), h2 - 1);
+            xx = min(max(st.j - 1 + st.b + (t & 1), 0), w2 - 1);
+        } else {           // full-resolution segment: the usual 9 reflected taps
+            h = 2 * h2; w = 2 * w2;
+            const int dy = t / 3, dx = t - dy * 3;
+            yy = jp_reflect(2 * st.i + st.a - 1 + dy, h);
+            xx = jp_reflect(2 * st.j + st.b - 1 + dx, w);
+        }
+        st.hw = h * w;
+        st.voff = (unsigned)((st.img_rel * Cs * h + yy) * w + xx) * 4u;
+        st.rowp = p + (size_t)(st.img0 * Cs + cc * 32) * st.hw;
+        st.nm1 = min(32, Cs - cc * 32) - 1;
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        const float* rp = st.rowp + (size_t)min(kl, st.nm1) * st.hw;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+    __device__ __forceinline__ float post(const St&, float v, int) const { return v; }
+};
+struct FwdEpiP {  // y[img][co][2i+a][2j+b] = act(acc + bias[co])
+    typedef size_t St;
+    float* y;
+    const float* bias;
+    int Cout, Nc, h2, w2, act;
+    __device__ __forceinline__ St col(int n) const {
+        const int cls = n / Nc, q = n - cls * Nc;
+        const int hw2 = h2 * w2;
+        const int img = q / hw2, pix = q - img * hw2;
+        const int i = pix / w2, j = pix - i * w2;
+        return (size_t)img * Cout * (4 * hw2) + (size_t)(2 * i + (cls >> 1)) * (2 * w2) + 2 * j + (cls & 1);
+    }
+    __device__ __forceinline__ void put(St base, int m, float v) const {
+        if (bias) v += bias[m];
+        y[base + (size_t)m * (4 * h2 * w2)] = jp_act(v, act);
+    }
+};
+
+// packed weights of one channel segment [c_off, c_off + C): full-resolution -> wp[tap][co][Cp]; upsampled ->
+// wp[class][slot][co][Cp] with the taps each (class, slot) pair stands for summed
+__global__ void pack_weights_seg_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int c_off,
+                                        int C, int Cp, int up) {
+    const int planes = up ? 16 : 9;
+    const long total = (long)planes * Cout * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const long t = i / Cp;
+        const int co = (int)(t % Cout);
+        const int pl = (int)(t / Cout);
+        float v = 0.f;
+        if (c < C) {
+            const float* wc = w + ((size_t)co * Cin + c_off + c) * 9;
+            if (!up) {
+                v = wc[pl];
+            } else {
+                const int a = pl >> 3, b = (pl >> 2) & 1, r = (pl >> 1) & 1, sx = pl & 1;
+                // Dy(a, r): a=0 -> {0} / {1,2};  a=1 -> {0,1} / {2}
+                const int y0 = a ? (r ? 2 : 0) : (r ? 1 : 0), y1 = a ? (r ? 2 : 1) : (r ? 2 : 0);
+                const int x0 = b ? (sx ? 2 : 0) : (sx ? 1 : 0), x1 = b ? (sx ? 2 : 1) : (sx ? 2 : 0);
+                for (int dy = y0; dy <= y1; ++dy)
+                    for (int dx = x0; dx <= x1; ++dx) v += wc[dy * 3 + dx];
+            }
+        }
+        wp[i] = v;
+    }
+}
+
 // ---- 3x3 stride-2 pad-1 dgrad (ResNet downsampling convs), parity-class form.  An input pixel (y, x) is reached only
 // through taps with ty = y+1 (mod 2), tx = x+1 (mod 2): 1, 2, 2 or 4 of the 9.  Input pixels are enumerated class-major
 // n = (class (py,px), img, i, j) with y = 2i+py, x = 2j+px, so a pixel tile is class-uniform and the K loop runs over
@@ -1062,7 +1219,8 @@ static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
 // which: 0 forward, 1 dgrad, 2 wgrad
 extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
-    if (which == 0) return Cin >= 16 ? ((long)KH * KH * Cout + 256) * pad32(Cin) : 0;
+    // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
+    if (which == 0) return Cin >= 16 ? ((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96) : 0;
     if (which == 1) return Cout >= 16 ? ((long)KH * KH * Cin + 256) * pad32(Cout) : 0;
     return 0;
 }
@@ -1086,6 +1244,35 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         JP_LAUNCH_CHECK();
     }
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
+    {   // upsample-aware parity-class path (iconv layers)
+        const long Ncl = (long)N * (H / 2) * (W / 2);
+        const bool any_up = (c0 && up0) || (c1 && up1) || (c2 && up2);
+        if (ws && any_up && KH == 3 && stride == 1 && pad == 1 && pad_mode == JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 &&
+            Ncl % 256 == 0 && seg_aligned(c0, c1, c2) && Cin >= 32 && (long)jp_cdiv(Cout, 128) * (npix / 128) >= 192) {
+            const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
+            int T[3], P[3], O[3], nch[3];
+            long off = 0;
+            for (int i = 0; i < 3; ++i) {
+                T[i] = us[i] ? 4 : 9;
+                P[i] = pad32(cs[i]);
+                nch[i] = P[i] / 32;
+                O[i] = (int)off;
+                if (cs[i]) {
+                    const long tot = (long)(us[i] ? 16 : 9) * Cout * P[i];
+                    hipLaunchKernelGGL(pack_weights_seg_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0,
+                                       st, w, ws + off, Cout, Cin, (i == 0 ? 0 : (i == 1 ? c0 : c0 + c1)), cs[i], P[i], us[i]);
+                    off += tot;
+                }
+            }
+            ParSeg ps{nch[0] * T[0], nch[0] * T[0] + nch[1] * T[1], T[0], T[1], T[2], O[0], O[1], O[2], P[0], P[1], P[2]};
+            const int Q = ps.q1 + nch[2] * T[2];
+            PackAP a{ws, ps, Cout, (int)Ncl};
+            FwdBP b{src, ps, (int)Ncl, H / 2, W / 2};
+            FwdEpiP ep{y, bias, Cout, (int)Ncl, H / 2, W / 2, act};
+            launch_auto(a, b, ep, Cout, (int)npix, Q * KC, 1, Q * KC, st);
+            JP_LAUNCH_CHECK();
+        }
+    }
     if (ws && Cin >= 16 && seg_aligned(c0, c1, c2)) {   // tap-major fast path (16-channel inputs: half-empty K chunks)
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
         pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);

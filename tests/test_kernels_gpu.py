@@ -98,11 +98,15 @@ def test_conv2d_fwd_bwd(case):
         close(bv.g, br.grad, rtol=2e-4, msg="bias grad")
 
 
-def test_conv2d_fused_upsample_concat():
+@pytest.mark.parametrize("N,H,W,Cr,Cx,Cout", [
+    (2, 12, 20, 40, 24, 32),      # generic gather (unaligned segments)
+    (3, 64, 64, 64, 64, 160),     # upsample-aware parity-class forward (4 slots on the upsampled segment)
+    (3, 128, 128, 32, 96, 40),    # ... 64x256 tile, 3 channel chunks in the upsampled segment
+])
+def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
     """iconv_k(cat(reduce, up(x), disp)) and its three input gradients (depth_decoder.py:76-77)."""
-    N, H, W = 2, 12, 20
-    r, xh, d = rnd(N, 40, H, W, seed=1), rnd(N, 24, H // 2, W // 2, seed=2), rnd(N, 1, H, W, seed=3)
-    w, b = rnd(32, 65, 3, 3, seed=4, scale=0.05), rnd(32, seed=5)
+    r, xh, d = rnd(N, Cr, H, W, seed=1), rnd(N, Cx, H // 2, W // 2, seed=2), rnd(N, 1, H, W, seed=3)
+    w, b = rnd(Cout, Cr + Cx + 1, 3, 3, seed=4, scale=0.05), rnd(Cout, seed=5)
     rv, xv, dv, wv, bv = Var(r, True), Var(xh, True), Var(d, True), pvar(w), pvar(b)
     tape = Tape()
     with recording(tape):
