@@ -621,6 +621,101 @@ __global__ void pack_weights_seg_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// ---- wgrad of the upsampled segment in the same parity-class form: dW'_{class}[slot][co][c] = sum over the class's
+// output pixels of dY[co][2i+a][2j+b] * X[c][clamp(i-1+a+r)][clamp(j-1+b+s)]  (GEMM M=co, N=(class, slot, c), K = class
+// pixels; 4/9 of the plain wgrad's MFMA work), then dW[dy][dx] += the 4 (class, slot) pairs that contain the tap.
+// Preconditions: W/2 % 32 == 0 (a K chunk is 32 consecutive j of one row), Cx % 128 == 0, Cout % 8 == 0.
+struct WgradAPSt {
+    const float* base;
+    unsigned voff;
+    int a, b;
+};
+struct WgradAP {  // A[m=co][k=(img,i,j) of the tile's class] = dY[img][co][2i+a][2j+b]
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    static constexpr bool WANTS_TILE = true;
+    typedef WgradAPSt St;
+    const float* dy;
+    int Cout, h2, w2, ncls;    // ncls = columns per class = 4 * Cx
+    __device__ __forceinline__ void init(St& st, int, int, int, int n0) const {
+        const int cls = n0 / ncls;
+        st.a = cls >> 1;
+        st.b = cls & 1;
+        st.base = dy;
+        st.voff = ((threadIdx.x >> 5) * (4 * h2 * w2) + 2 * (threadIdx.x & 31)) * 4u;
+    }
+    __device__ __forceinline__ void fix(St& st, int p) const {
+        const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
+        const int hw2 = h2 * w2;
+        const int img = p0 / hw2, rem = p0 - img * hw2;
+        const int i = rem / w2, j0 = rem - i * w2;
+        st.base = dy + (size_t)img * Cout * (4 * hw2) + (size_t)(2 * i + st.a) * (2 * w2) + 2 * j0 + st.b;
+    }
+    __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
+        const float* rp = st.base + (size_t)min(m_u, Cout - 8) * (4 * h2 * w2);
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+};
+struct WgradBPSt {
+    const float* base;
+    unsigned voff;
+    int a, b, r, s, c0;
+};
+struct WgradBP {  // B[k=(img,i,j)][n=(class, slot, c)] = X[img][c][clamp(i-1+a+r)][clamp(j-1+b+s)]
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    static constexpr bool WANTS_TILE = true;
+    typedef WgradBPSt St;
+    const float* x;     // half-resolution source (N, Cx, h2, w2)
+    int Cx, h2, w2;
+    __device__ __forceinline__ void init(St& st, int, int, int, int n0) const {
+        const int q = n0 / Cx;           // (class, slot)
+        st.c0 = n0 - q * Cx;
+        const int cls = q >> 2, slot = q & 3;
+        st.a = cls >> 1; st.b = cls & 1; st.r = slot >> 1; st.s = slot & 1;
+        st.base = x;
+        st.voff = 0;
+    }
+    __device__ __forceinline__ void fix(St& st, int p) const {
+        const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
+        const int hw2 = h2 * w2;
+        const int img = p0 / hw2, rem = p0 - img * hw2;
+        const int i = rem / w2;
+        const int j = p - img * hw2 - i * w2;       // per lane
+        const int xi = min(max(i - 1 + st.a + st.r, 0), h2 - 1);
+        const int xj = min(max(j - 1 + st.b + st.s, 0), w2 - 1);
+        st.voff = (unsigned)((threadIdx.x >> 5) * hw2 + xj) * 4u;
+        st.base = x + (size_t)(img * Cx + st.c0) * hw2 + (size_t)xi * w2;
+    }
+    __device__ __forceinline__ float get_u(const St& st, int, int r) const {
+        const float* rp = st.base + (size_t)(8 * r) * (h2 * w2);
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+};
+// dw[m][c_off + c][tap] += sum over splits and over the 4 (class, slot) pairs containing the tap of ws[k][m][n]
+__global__ void wgrad_fold_parity_kernel(const float* __restrict__ ws, float* __restrict__ dw, int M, int Cx, int splits,
+                                         int c_off, int Ctot) {
+    const long total = (long)M * Cx * 9, plane = (long)M * 16 * Cx;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cx);
+        const long t = i / Cx;
+        const int tap = (int)(t % 9), m = (int)(t / 9);
+        const int dy = tap / 3, dx = tap - dy * 3;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int r = a ? (dy == 2) : (dy >= 1);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int sx = b ? (dx == 2) : (dx >= 1);
+                const long n = (long)(((a * 2 + b) * 4 + r * 2 + sx)) * Cx + c;
+                for (int k = 0; k < splits; ++k) s += ws[(size_t)k * plane + (size_t)m * 16 * Cx + n];
+            }
+        }
+        dw[((size_t)m * Ctot + c_off + c) * 9 + tap] += s;
+    }
+}
+
 // ---- 3x3 stride-2 pad-1 dgrad (ResNet downsampling convs), parity-class form.  An input pixel (y, x) is reached only
 // through taps with ty = y+1 (mod 2), tx = x+1 (mod 2): 1, 2, 2 or 4 of the 9.  Input pixels are enumerated class-major
 // n = (class (py,px), img, i, j) with y = 2i+py, x = 2j+px, so a pixel tile is class-uniform and the K loop runs over
@@ -1423,19 +1518,18 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
-                                    const float* x2, int c2, int up2, const float* dy, float* dw, int N, int H, int W,
-                                    int Cout, int KH, int stride, int pad, int pad_mode, int accumulate,
-                                    float* ws, long ws_floats, void* stream) {
-    JP_CHECK_ARG(x0 && dy && dw, "conv2d_wgrad: null pointer");
+// wgrad of the (virtually concatenated) sources into the dw columns [dw_coff, dw_coff + c0+c1+c2) of a filter bank with
+// dw_ctot input channels.  Sub-range calls (dw_coff > 0 or fewer channels than dw_ctot) must be single-source.
+static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
+                      const float* dy, float* dw, int N, int H, int W, int Cout, int KH, int stride, int pad,
+                      int pad_mode, float* ws, long ws_floats, hipStream_t st, int dw_ctot, int dw_coff) {
     const int Cin = c0 + c1 + c2;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW;
     JP_CHECK_ARG(npix < (1L << 31), "conv2d_wgrad: tensor too large");
     const int Kw = Cin * KH * KH;
-    hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) JP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Kw, st));
-    if (small_head(Cin, Cout, KH, stride, pad)) {
+    const bool whole = dw_coff == 0 && dw_ctot == Cin;
+    if (whole && small_head(Cin, Cout, KH, stride, pad)) {
         jp_conv_small_wgrad(x0, c0, up0, x1, c1, up1, x2, c2, up2, dy, dw, N, H, W, Cout, pad_mode == JP_PAD_REFLECT, st);
         JP_LAUNCH_CHECK();
     }
@@ -1476,7 +1570,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         const int Cp = cn, Np = KH * KH * Cp;    // the slot tables need no channel padding
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cp) + 1u;
         plan(Np, &splits, &kps);
-        WgradEpiT e{dw, Cp, cn, KH * KH, cb, Cin, magic};
+        WgradEpiT e{dw, Cp, cn, KH * KH, dw_coff + cb, dw_ctot, magic};
         JP_KH_SWITCH(KH, {
             WgradBT1<KH_> b{x0 + (size_t)cb * H * W, Np, Cp, cn, Cin, H, W, (int)npix, OH, OW, stride, pad,
                             pad_mode == JP_PAD_REFLECT, magic};
@@ -1484,6 +1578,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         });
         return 0;
     };
+    JP_CHECK_ARG(whole || single, "conv2d_wgrad: internal sub-range call must be single-source");
     if (!single && Cin < 32) {          // generic (channel-major) path: multi-source inputs with few channels
         WgradEpi e{dw, Kw};
         plan(Kw, &splits, &kps);
@@ -1491,13 +1586,16 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
             WgradB<KH_> b{src, Kw, (int)npix, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
             launch_auto<true>(a, b, e, Cout, Kw, (int)npix, splits, kps, st);
         });
+    } else if (!whole && Cin < 16) {    // a few channels of a wider filter bank (the disparity channel of the iconv input)
+        const int rc = run_table(0, Cin);
+        if (rc) return rc;
     } else if (single && Cout > 64 && Cin >= 128 && (Cin % 128 == 0 || Cin % 128 <= 32)) {
         // uniform-tap path on the 128-aligned part (+ a table pass for a short channel tail, e.g. 513 = 512 + 1)
         const int Cm = Cin / 128 * 128, tail = Cin - Cm;
         const int Np = KH * KH * Cm;
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cm) + 1u;
         const bool scalar_ok = (OH * OW) % 32 == 0 && Cout % 8 == 0 && (long)8 * H * W * 4 < (1L << 31);
-        WgradEpiT e{dw, Cm, Cm, KH * KH, 0, Cin, magic};
+        WgradEpiT e{dw, Cm, Cm, KH * KH, dw_coff, dw_ctot, magic};
         if (scalar_ok) {   // scalar-base loaders
             WgradAS as{dy, Cout, (int)npix, OH * OW};
             JP_KH_SWITCH(KH, {
@@ -1525,7 +1623,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         // 16 / 32 / 64 input channels (ResNet stem + layer1, BEV decoder): whole taps per N tile, scalar-base loaders
         const int Np = KH * KH * Cin;
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cin) + 1u;
-        WgradEpiT e{dw, Cin, Cin, KH * KH, 0, Cin, magic};
+        WgradEpiT e{dw, Cin, Cin, KH * KH, dw_coff, dw_ctot, magic};
         WgradAS as{dy, Cout, (int)npix, OH * OW};
 #define JP_BMS(REFL, WMv, WNv, TPTv, CPTv)                                              \
     {                                                                                   \
@@ -1560,6 +1658,92 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
         });
     }
     JP_LAUNCH_CHECK();
+}
+
+
+// one channel segment is eligible for the per-segment wgrad (no materialised concat): full-resolution segments run the
+// single-source paths on their own tensor, the upsampled one the parity-class kernels
+static bool wgrad_segments_ok(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W, int Cout, int KH,
+                              int stride, int pad, int pad_mode) {
+    const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
+    int nseg = 0, nup = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (!cs[i]) continue;
+        ++nseg;
+        if (us[i]) {
+            ++nup;
+            if (cs[i] % 128 || Cout % 8 || Cout <= 64) return false;
+        }
+    }
+    if (nseg < 2 || nup != 1) return false;
+    return KH == 3 && stride == 1 && pad == 1 && pad_mode == JP_PAD_REFLECT && H % 2 == 0 && (W / 2) % 32 == 0 && W % 2 == 0 &&
+           (long)N * H * W < (1L << 31);
+}
+
+extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
+                                    const float* x2, int c2, int up2, const float* dy, float* dw, int N, int H, int W,
+                                    int Cout, int KH, int stride, int pad, int pad_mode, int accumulate,
+                                    float* ws, long ws_floats, void* stream) {
+    JP_CHECK_ARG(x0 && dy && dw, "conv2d_wgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int Cin = c0 + c1 + c2;
+    if (!accumulate) JP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * KH * KH, st));
+    if (ws && wgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode)) {
+        const float* xs[3] = {x0, x1, x2};
+        const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
+        int coff = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (!cs[i]) continue;
+            if (!us[i]) {
+                const int rc = wgrad_impl(xs[i], cs[i], 0, nullptr, 0, 0, nullptr, 0, 0, dy, dw, N, H, W, Cout, KH, stride, pad,
+                                          pad_mode, ws, ws_floats, st, Cin, coff);
+                if (rc) return rc;
+            } else {
+                const int h2 = H / 2, w2 = W / 2, Cx = cs[i], Np = 16 * Cx;
+                const long Ncl = (long)N * h2 * w2;
+                WgradPlan p = wgrad_plan(Cout, Np, Ncl, 128, 128, 3, ws_floats);
+                if (!p.use_ws) {    // this path always reduces through scratch: take the largest split that fits
+                    long sp = std::max<long>(1, std::min<long>(ws_floats / ((long)Cout * Np), jp_cdiv(Ncl, KC) / 4));
+                    JP_CHECK_ARG(ws_floats >= (long)Cout * Np, "conv2d_wgrad: scratch too small (jp_conv2d_wgrad_src3_ws_floats)");
+                    sp = std::min<long>(sp, 64);
+                    p.kps = (int)(jp_cdiv(jp_cdiv(Ncl, KC), sp) * KC);
+                    p.splits = jp_cdiv(Ncl, p.kps);
+                }
+                WgradAP a{dy, Cout, h2, w2, 4 * Cx};
+                WgradBP b{xs[i], Cx, h2, w2};
+                WgradEpiWS ew{ws, Cout, Np};
+                launch<true, 2, 2>(a, b, ew, Cout, Np, (int)Ncl, p.splits, p.kps, st);
+                const long total = (long)Cout * Cx * 9;
+                hipLaunchKernelGGL(wgrad_fold_parity_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st,
+                                   ws, dw, Cout, Cx, p.splits, coff, Cin);
+            }
+            coff += cs[i];
+        }
+        JP_LAUNCH_CHECK();
+    }
+    return wgrad_impl(x0, c0, up0, x1, c1, up1, x2, c2, up2, dy, dw, N, H, W, Cout, KH, stride, pad, pad_mode, ws, ws_floats, st,
+                      Cin, 0);
+}
+
+// scratch floats for jp_conv2d_wgrad_src3 on a multi-source input (0 = use the single-source query / no benefit)
+extern "C" long jp_conv2d_wgrad_src3_ws_floats(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W,
+                                               int Cout, int KH, int stride, int pad, int pad_mode) {
+    if (!wgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode)) return 0;
+    const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
+    const long cap = 48L << 20;
+    long need = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (!cs[i]) continue;
+        if (us[i]) {
+            const WgradPlan p = wgrad_plan(Cout, 16 * cs[i], (long)N * (H / 2) * (W / 2), 128, 128, 3, cap);
+            need = std::max(need, p.use_ws ? p.ws_need : (long)Cout * 16 * cs[i]);
+        } else if (cs[i] >= 16) {
+            const int Np = KH * KH * (cs[i] >= 64 ? cs[i] / 64 * 64 : cs[i]);
+            const WgradPlan p = wgrad_plan(Cout, Np, (long)N * H * W, 128, 128, 3, cap);
+            if (p.use_ws) need = std::max(need, p.ws_need);
+        }
+    }
+    return need;
 }
 
 extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,

@@ -115,8 +115,10 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
         else al.init(sa, m0 + a_var_l, A_ROWS);
     } else if constexpr (jp_has_post<ALoad>::value) al.init(sa, m0 + a_fix_l, m0);
     else al.init(sa, m0 + a_fix_l);
-    if constexpr (BLoad::ALONG_K) bl.init(sb, n0 + b_var_l, B_ROWS);
-    else if constexpr (jp_has_post<BLoad>::value) bl.init(sb, n0 + b_fix_l, n0);
+    if constexpr (BLoad::ALONG_K) {
+        if constexpr (jp_wants_tile<BLoad>::value) bl.init(sb, n0 + b_var_l, B_ROWS, m0, n0);
+        else bl.init(sb, n0 + b_var_l, B_ROWS);
+    } else if constexpr (jp_has_post<BLoad>::value) bl.init(sb, n0 + b_fix_l, n0);
     else bl.init(sb, n0 + b_fix_l);
 
     float ra[NA], rb[NB];

@@ -147,7 +147,17 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
         if b is not None and b.rg:
             call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
         if w.rg:
-            if (len(srcs) > 1 or srcs[0][1]) and Cin >= 32:
+            nms = 0
+            if len(srcs) > 1:
+                nms = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout,
+                                                                         KH, stride, pad, pad_mode))
+            if nms:
+                # per-segment wgrad inside the library: full-resolution segments from their own tensors, the
+                # upsampled one in parity-class form -- no materialised concat
+                ws_w = _new((nms,), dy)
+                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nms)
+                del ws_w
+            elif (len(srcs) > 1 or srcs[0][1]) and Cin >= 32:
                 # materialise the virtual upsample+concat once: the single-source wgrad gather is ~2x faster
                 xc = _new((N, Cin, H, W), dy)
                 c0 = 0
