@@ -716,6 +716,149 @@ __global__ void wgrad_fold_parity_kernel(const float* __restrict__ ws, float* __
     }
 }
 
+// ---- dgrad of the upsampled segment, directly at half resolution:
+//   dX[c][i][j] = sum_{class (a,b), slot (r,s), co} W'_{ab}[r][s][co][c] * dY[co][2i'+a][2j'+b],
+//   (i', j') = (i+1-a-r, j+1-b-s) where it exists (GEMM M=c, N=half-res pixels, K=(co chunk, 16 (class,slot), co); 4/9 of
+//   the full-resolution dgrad + 2x2 sum it replaces).  The edge clamp of the forward adds, on the 4 boundary lines, the
+//   entries (i'=0 via a=0,r=0 | i'=h-1 via a=1,r=1, same for columns): a split-K border pass like the reflection one.
+struct DgradUPSt {
+    int img_rel, i, j, img0;
+    const float* rowp;
+    unsigned voff;
+    int nm1, ok;
+};
+struct DgradUPB {
+    static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
+    typedef DgradUPSt St;
+    const float* dy;
+    int Npix2, h2, w2, Cout;
+    __device__ __forceinline__ void init(St& st, int p, int p0) const {
+        const int hw2 = h2 * w2;
+        p = min(p, Npix2 - 1);
+        const int img = p / hw2, pix = p - img * hw2;
+        st.i = pix / w2;
+        st.j = pix - st.i * w2;
+        st.img0 = min(p0, Npix2 - 1) / hw2;
+        st.img_rel = img - st.img0;
+        st.rowp = dy;
+        st.voff = 0;
+        st.nm1 = 0;
+        st.ok = 0;
+    }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int qk = kc >> 5;
+        const int cc = qk >> 4, q = qk & 15;
+        const int a = q >> 3, b = (q >> 2) & 1, r = (q >> 1) & 1, s = q & 1;
+        const int co0 = cc << 5;
+        int ip = st.i + 1 - a - r, jp = st.j + 1 - b - s;
+        st.ok = (unsigned)ip < (unsigned)h2 && (unsigned)jp < (unsigned)w2;
+        ip = min(max(ip, 0), h2 - 1);
+        jp = min(max(jp, 0), w2 - 1);
+        const int HW = 4 * h2 * w2;
+        st.voff = (unsigned)(st.img_rel * Cout * HW + (2 * ip + a) * (2 * w2) + 2 * jp + b) * 4u;
+        st.rowp = dy + (size_t)(st.img0 * Cout + co0) * HW;
+        st.nm1 = min(32, Cout - co0) - 1;
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (4 * h2 * w2);
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+    __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
+};
+
+// boundary pixels of the half-resolution map: rows 0 / h-1, columns 0 / w-1 (duplicates masked)
+__device__ __forceinline__ InPixSt edge_pix(int b, int Nb, int h, int w) {
+    InPixSt px;
+    const int per = 2 * w + 2 * h;
+    px.valid = b < Nb;
+    px.img = b / per;
+    const int i = b - px.img * per;
+    int y, x;
+    bool dup = false;
+    if (i < w) { y = 0; x = i; }
+    else if (i < 2 * w) { y = h - 1; x = i - w; dup = (h == 1); }
+    else if (i < 2 * w + h) { y = i - 2 * w; x = 0; dup = (y == 0 || y == h - 1); }
+    else { y = i - 2 * w - h; x = w - 1; dup = (y == 0 || y == h - 1) || (w == 1); }
+    px.y = y; px.x = x;
+    if (dup) px.valid = 0;
+    return px;
+}
+struct DgradUPBorderSt {
+    InPixSt px;
+    const float* p;
+    int o1, o2, o3, n;
+};
+struct DgradUPBorderB {   // only the clamp-folded entries: (extra row, any column) and (regular row, extra column)
+    static constexpr bool ALONG_K = false;
+    typedef DgradUPBorderSt St;
+    const float* dy;
+    int Nb, h2, w2, Cout;
+    __device__ __forceinline__ void init(St& st, int b) const { st = St{edge_pix(b, Nb, h2, w2), nullptr, -1, -1, -1, 0}; }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int qk = kc >> 5;
+        const int cc = qk >> 4, q = qk & 15;
+        const int a = q >> 3, b = (q >> 2) & 1, r = (q >> 1) & 1, s = q & 1;
+        const int co0 = cc << 5;
+        st.n = 0;
+        if (!st.px.valid || co0 >= Cout) return;
+        const int i = st.px.y, j = st.px.x;
+        const int er = (i == 0 && a == 0 && r == 0) ? 0 : ((i == h2 - 1 && a == 1 && r == 1) ? h2 - 1 : -1);
+        const int ec = (j == 0 && b == 0 && s == 0) ? 0 : ((j == w2 - 1 && b == 1 && s == 1) ? w2 - 1 : -1);
+        if (er < 0 && ec < 0) return;
+        const int rr = i + 1 - a - r, rc = j + 1 - b - s;
+        const bool rrv = (unsigned)rr < (unsigned)h2, rcv = (unsigned)rc < (unsigned)w2;
+        const int W = 2 * w2;
+        st.o1 = (er >= 0 && rcv) ? (2 * er + a) * W + 2 * rc + b : -1;
+        st.o2 = (rrv && ec >= 0) ? (2 * rr + a) * W + 2 * ec + b : -1;
+        st.o3 = (er >= 0 && ec >= 0) ? (2 * er + a) * W + 2 * ec + b : -1;
+        st.p = dy + (size_t)(st.px.img * Cout + co0) * (4 * h2 * w2);
+        st.n = min(32, Cout - co0);
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int) const {
+        if (kl >= st.n) return 0.f;
+        const float* q = st.p + (size_t)kl * (4 * h2 * w2);
+        float v = 0.f;
+        if (st.o1 >= 0) v += q[st.o1];
+        if (st.o2 >= 0) v += q[st.o2];
+        if (st.o3 >= 0) v += q[st.o3];
+        return v;
+    }
+};
+struct DgradEdgeEpi {  // dx[img][c][y][x] += acc for the boundary pixel b of a (h, w) map
+    typedef long St;
+    float* dx;
+    int C, h, w, Nb;
+    __device__ __forceinline__ St col(int b) const {
+        const InPixSt px = edge_pix(b, Nb, h, w);
+        return px.valid ? (long)px.img * C * h * w + px.y * w + px.x : -1;
+    }
+    __device__ __forceinline__ void put(St base, int m, float v) const {
+        if (base >= 0) atomicAdd(dx + base + (size_t)m * h * w, v);
+    }
+};
+// wpT[(class, slot)][c][co_pad] = W'_{class}[slot][co][c]  (dgrad A operand of the upsampled segment)
+__global__ void pack_weights_up_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int c_off,
+                                             int Cx, int Cp) {
+    const long total = 16L * Cx * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cp);
+        const long t = i / Cp;
+        const int c = (int)(t % Cx);
+        const int pl = (int)(t / Cx);
+        float v = 0.f;
+        if (co < Cout) {
+            const float* wc = w + ((size_t)co * Cin + c_off + c) * 9;
+            const int a = pl >> 3, b = (pl >> 2) & 1, r = (pl >> 1) & 1, sx = pl & 1;
+            const int y0 = a ? (r ? 2 : 0) : (r ? 1 : 0), y1 = a ? (r ? 2 : 1) : (r ? 2 : 0);
+            const int x0 = b ? (sx ? 2 : 0) : (sx ? 1 : 0), x1 = b ? (sx ? 2 : 1) : (sx ? 2 : 0);
+            for (int dy = y0; dy <= y1; ++dy)
+                for (int dx = x0; dx <= x1; ++dx) v += wc[dy * 3 + dx];
+        }
+        wp[i] = v;
+    }
+}
+
 // ---- 3x3 stride-2 pad-1 dgrad (ResNet downsampling convs), parity-class form.  An input pixel (y, x) is reached only
 // through taps with ty = y+1 (mod 2), tx = x+1 (mod 2): 1, 2, 2 or 4 of the 9.  Input pixels are enumerated class-major
 // n = (class (py,px), img, i, j) with y = 2i+py, x = 2j+px, so a pixel tile is class-uniform and the K loop runs over
@@ -1316,7 +1459,8 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
     if (which == 0) return Cin >= 16 ? ((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96) : 0;
-    if (which == 1) return Cout >= 16 ? ((long)KH * KH * Cin + 256) * pad32(Cout) : 0;
+    // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled segment
+    if (which == 1) return Cout >= 16 ? ((long)(KH * KH + 16) * Cin + 512) * pad32(Cout) : 0;
     return 0;
 }
 
@@ -1514,6 +1658,74 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             DgradB<KH_> b{dy, K, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
             launch_auto(a, b, e, Cin, (int)npix, K, 1, jp_cdiv(K, KC) * KC, st);
         });
+    }
+    JP_LAUNCH_CHECK();
+}
+
+// per-source dgrad of a conv whose input is the channel concat of up to 3 sources, one of them read through the fused
+// nearest-2x upsample: gradients go straight into the sources' own buffers (dx_s: (N, c_s, H, W), or (N, c_s, H/2, W/2)
+// for the upsampled one; NULL = not needed; acc_s: add instead of overwrite) -- no concat-sized gradient tensor.
+static bool dgrad_segments_ok(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W, int Cout, int KH,
+                              int stride, int pad, int pad_mode) {
+    const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
+    int nup = 0;
+    for (int i = 0; i < 3; ++i)
+        if (cs[i] && us[i]) { ++nup; if (cs[i] < 32) return false; }
+    return nup == 1 && KH == 3 && stride == 1 && pad == 1 && pad_mode == JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 && H >= 4 &&
+           W >= 4 && Cout >= 16 && (long)N * H * W < (1L << 31) && (long)N * (H / 2) * (W / 2) / 128 >= 96;
+}
+extern "C" int jp_conv2d_dgrad_src3_ok(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W, int Cout,
+                                       int KH, int stride, int pad, int pad_mode) {
+    return dgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode) ? 1 : 0;
+}
+extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
+                                    int c1, int up1, int acc1, float* dx2, int c2, int up2, int acc2, int N, int H, int W,
+                                    int Cout, int KH, int stride, int pad, int pad_mode, float* ws, void* stream) {
+    JP_CHECK_ARG(dy && w && ws, "conv2d_dgrad_src3: null pointer");
+    JP_CHECK_ARG(dgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode),
+                 "conv2d_dgrad_src3: shape not supported (check jp_conv2d_dgrad_src3_ok)");
+    hipStream_t st = (hipStream_t)stream;
+    const int Cin = c0 + c1 + c2, Cp = pad32(Cout), Kp = 9 * Cp;
+    const long npix = (long)N * H * W;
+    float* dxs[3] = {dx0, dx1, dx2};
+    const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2}, accs[3] = {acc0, acc1, acc2};
+    pack_weights(w, ws, Cout, Cin, 9, Cp, 1, st);                 // [tap][ci][Cp] for the full-resolution segments
+    float* wsT = ws + ((size_t)9 * Cin + 256) * Cp;               // [16][Cx][Cp] for the upsampled one
+    DgradBT<3> b{dy, Cp, (int)npix, H, W, Cout, H, W, 1, 1, 1};
+    int coff = 0;
+    for (int sidx = 0; sidx < 3; ++sidx) {
+        const int C = cs[sidx];
+        if (!C) continue;
+        float* dx = dxs[sidx];
+        if (dx && !us[sidx]) {
+            PackA a{ws + (size_t)coff * Cp, Cin, Kp, Cp, 9};
+            DgradEpi e{dx, C, H * W, accs[sidx]};
+            launch_auto(a, b, e, C, (int)npix, Kp, 1, Kp, st);
+            const int Nb = N * (2 * W + 2 * H);
+            DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
+            DgradBorderEpi be{dx, C, H, W, Nb};
+            const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
+            const int bsp = (int)std::max<long>(1, std::min<long>(jp_cdiv(768, btiles), Kp / KC / 4));
+            const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
+            launch_auto(a, bb, be, C, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
+        } else if (dx) {
+            const int h2 = H / 2, w2 = W / 2, KpU = 16 * Cp;
+            const long tot = 16L * C * Cp, np2 = (long)N * h2 * w2;
+            hipLaunchKernelGGL(pack_weights_up_dgrad_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, w,
+                               wsT, Cout, Cin, coff, C, Cp);
+            PackA a{wsT, C, KpU, Cp, 16};
+            DgradUPB bu{dy, (int)np2, h2, w2, Cout};
+            DgradEpi e{dx, C, h2 * w2, accs[sidx]};
+            launch_auto(a, bu, e, C, (int)np2, KpU, 1, KpU, st);
+            const int Nb = N * (2 * w2 + 2 * h2);
+            DgradUPBorderB bb{dy, Nb, h2, w2, Cout};
+            DgradEdgeEpi be{dx, C, h2, w2, Nb};
+            const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
+            const int bsp = (int)std::max<long>(1, std::min<long>(jp_cdiv(768, btiles), KpU / KC / 4));
+            const int bkps = jp_cdiv(jp_cdiv(KpU, bsp), KC) * KC;
+            launch_auto(a, bb, be, C, Nb, KpU, jp_cdiv(KpU, bkps), bkps, st);
+        }
+        coff += C;
     }
     JP_LAUNCH_CHECK();
 }

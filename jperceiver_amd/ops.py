@@ -184,6 +184,18 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()
                 call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc, ws_d)
+            elif int(_jplib().fn["jp_conv2d_dgrad_src3_ok"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout, KH,
+                                                           stride, pad, pad_mode)):
+                # per-source dgrad inside the library: straight into each source's gradient buffer, the upsampled
+                # source at its own (half) resolution
+                ga = []
+                for i in range(3):
+                    if i < len(srcs) and srcs[i][0].rg:
+                        g, acc = srcs[i][0].grad_buf()
+                        ga += [g, s3[3 * i + 1], s3[3 * i + 2], acc]
+                    else:
+                        ga += [None, s3[3 * i + 1], s3[3 * i + 2], 0]
+                call("jp_conv2d_dgrad_src3", dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode, ws_d)
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
                 call("jp_conv2d_dgrad", dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0, ws_d)

@@ -100,7 +100,7 @@ def test_conv2d_fwd_bwd(case):
 
 @pytest.mark.parametrize("N,H,W,Cr,Cx,Cout", [
     (2, 12, 20, 40, 24, 32),      # generic gather (unaligned segments)
-    (3, 64, 64, 64, 64, 160),     # upsample-aware parity-class forward (4 slots on the upsampled segment)
+    (3, 128, 128, 64, 64, 160),   # upsample-aware parity-class forward + per-source dgrad (4 slots on the upsampled segment)
     (3, 128, 128, 32, 96, 40),    # ... 64x256 tile, 3 channel chunks in the upsampled segment
     (2, 32, 64, 32, 128, 72),     # per-segment wgrad: parity-class kernels on the upsampled segment (Cx % 128 == 0)
     (1, 64, 128, 128, 128, 136),  # ... + uniform-tap path on the reduce segment, two M tiles
