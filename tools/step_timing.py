@@ -35,6 +35,9 @@ def timed(name, *a):
         key = "fwd   %4d->%4d k%d s%d @%4d fl=%.1f" % (a[1] + a[4] + a[7], a[15], a[16], a[17], a[13], 2e-9 * a[12] * (a[13] // a[17]) * (a[14] // a[17]) * a[15] * (a[1] + a[4] + a[7]) * a[16] ** 2)
     elif name == "jp_conv2d_dgrad":
         key = "dgrad %4d->%4d k%d s%d @%4d fl=%.1f" % (a[4], a[7], a[8], a[9], a[5], 2e-9 * a[3] * (a[5] // a[9]) * (a[6] // a[9]) * a[7] * a[4] * a[8] ** 2)
+    elif name == "jp_conv2d_dgrad_src3":
+        cin = a[3] + a[7] + a[11]
+        key = "dgrad3 %4d->%4d k%d s%d @%4d fl=%.1f" % (cin, a[17], a[18], a[19], a[15], 2e-9 * a[14] * a[15] * a[16] * a[17] * cin * a[18] ** 2)
     elif name == "jp_conv2d_wgrad_src3":
         key = "wgrad %4d->%4d k%d s%d @%4d fl=%.1f" % (a[1] + a[4] + a[7], a[14], a[15], a[16], a[12], 2e-9 * a[11] * (a[12] // a[16]) * (a[13] // a[16]) * a[14] * (a[1] + a[4] + a[7]) * a[15] ** 2)
     elif name in ("jp_maxpool_fwd", "jp_maxpool_bwd"):
