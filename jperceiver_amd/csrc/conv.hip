@@ -1437,7 +1437,7 @@ void pack_weights(const float* w, float* wp, int Cout, int Cin, int KHW, int Cp,
 // conv_small.hip: direct kernels for <= 4 output channels (disparity / BEV logits heads)
 int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
                       const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act, int reflect,
-                      hipStream_t st);
+                      hipStream_t st, int accumulate = 0);
 int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
                         int up2, const float* dy, float* dw, int N, int H, int W, int Cout, int reflect,
                         hipStream_t st);
@@ -1460,7 +1460,7 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
     if (which == 0) return Cin >= 16 ? ((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96) : 0;
     // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled segment
-    if (which == 1) return Cout >= 16 ? ((long)(KH * KH + 16) * Cin + 512) * pad32(Cout) : 0;
+    if (which == 1) return Cout >= 16 ? ((long)(KH * KH + 16) * Cin + 512 + 64) * pad32(Cout) : 0;
     return 0;
 }
 
@@ -1662,6 +1662,15 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     JP_LAUNCH_CHECK();
 }
 
+// wf[c][co][t] = w[co][c_off + c][8 - t]: the dgrad of a few input channels as a direct small-Cout correlation of dY
+__global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin, int c_off, int C) {
+    const int total = C * Cout * 9;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % 9, co = (i / 9) % Cout, c = i / (9 * Cout);
+        wf[i] = w[((size_t)co * Cin + c_off + c) * 9 + 8 - t];
+    }
+}
+
 // per-source dgrad of a conv whose input is the channel concat of up to 3 sources, one of them read through the fused
 // nearest-2x upsample: gradients go straight into the sources' own buffers (dx_s: (N, c_s, H, W), or (N, c_s, H/2, W/2)
 // for the upsampled one; NULL = not needed; acc_s: add instead of overwrite) -- no concat-sized gradient tensor.
@@ -1691,6 +1700,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
     const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2}, accs[3] = {acc0, acc1, acc2};
     pack_weights(w, ws, Cout, Cin, 9, Cp, 1, st);                 // [tap][ci][Cp] for the full-resolution segments
     float* wsT = ws + ((size_t)9 * Cin + 256) * Cp;               // [16][Cx][Cp] for the upsampled one
+    const int cx_up = up0 ? c0 : (up1 ? c1 : c2);
     DgradBT<3> b{dy, Cp, (int)npix, H, W, Cout, H, W, 1, 1, 1};
     int coff = 0;
     for (int sidx = 0; sidx < 3; ++sidx) {
@@ -1699,8 +1709,17 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
         float* dx = dxs[sidx];
         if (dx && !us[sidx]) {
             PackA a{ws + (size_t)coff * Cp, Cin, Kp, Cp, 9};
-            DgradEpi e{dx, C, H * W, accs[sidx]};
-            launch_auto(a, b, e, C, (int)npix, Kp, 1, Kp, st);
+            if (C <= 4 && (long)C * Cout * 9 * 4 <= 48 * 1024) {
+                // a few channels (the disparity channel): direct zero-pad correlation of dY with the flipped taps
+                // instead of a 64-row MFMA tile; the reflection fold still comes from the border pass below
+                float* wf = wsT + (16L * cx_up + 256) * Cp;     // behind the upsampled segment's pack (+ its slack)
+                hipLaunchKernelGGL(flip_weights_kernel, dim3(jp_cdiv(C * Cout * 9, 256)), dim3(256), 0, st, w, wf, Cout, Cin, coff, C);
+                jp_conv_small_fwd(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, wf, nullptr, dx, N, H, W, C, JP_ACT_NONE, 0, st,
+                                  accs[sidx]);
+            } else {
+                DgradEpi e{dx, C, H * W, accs[sidx]};
+                launch_auto(a, b, e, C, (int)npix, Kp, 1, Kp, st);
+            }
             const int Nb = N * (2 * W + 2 * H);
             DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
             DgradBorderEpi be{dx, C, H, W, Nb};

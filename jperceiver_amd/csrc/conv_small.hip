@@ -41,7 +41,7 @@ __device__ __forceinline__ void tap_offsets(int y, int x, int H, int W, int sh, 
 template <int CO>
 __global__ __launch_bounds__(TPB) void conv_small_fwd_kernel(Src3s src, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
-                                                             int Cin, int act, int reflect) {
+                                                             int Cin, int act, int reflect, int accumulate) {
     extern __shared__ float ws[];   // [CO][Cin*9]
     for (int i = threadIdx.x; i < CO * Cin * 9; i += TPB) ws[i] = w[i];
     __syncthreads();
@@ -76,7 +76,11 @@ __global__ __launch_bounds__(TPB) void conv_small_fwd_kernel(Src3s src, const fl
         cbase += seg.C;
     }
 #pragma unroll
-    for (int c = 0; c < CO; ++c) y[((size_t)img * CO + c) * HW + p] = jp_act(acc[c], act);
+    for (int c = 0; c < CO; ++c) {
+        float* q = y + ((size_t)img * CO + c) * HW + p;
+        const float v = jp_act(acc[c], act);
+        *q = accumulate ? *q + v : v;
+    }
 }
 
 // dw[co][ci][t] += sum_{img, pix} dy[img][co][pix] * x[img][ci][pix + t];  grid (pixel chunks, Cin, batch)
@@ -223,12 +227,12 @@ Src3s make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up
 // internal entry points used by conv.hip's dispatcher (not part of the public ABI)
 int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
                       const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act, int reflect,
-                      hipStream_t st) {
+                      hipStream_t st, int accumulate) {
     const int Cin = c0 + c1 + c2;
     const Src3s src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
     const dim3 grid(jp_cdiv(H * W, TPB), N);
     const size_t lds = sizeof(float) * (size_t)Cout * Cin * 9;
-#define JP_GO(CO) hipLaunchKernelGGL((conv_small_fwd_kernel<CO>), grid, dim3(TPB), lds, st, src, w, bias, y, Cin, act, reflect)
+#define JP_GO(CO) hipLaunchKernelGGL((conv_small_fwd_kernel<CO>), grid, dim3(TPB), lds, st, src, w, bias, y, Cin, act, reflect, accumulate)
     switch (Cout) {
         case 1: JP_GO(1); break;
         case 2: JP_GO(2); break;
