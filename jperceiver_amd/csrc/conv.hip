@@ -464,6 +464,89 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
+// ---- Few input channels (the 7x7 stride-2 ResNet stems: 3 image channels, 6 for the pose pair): K = (tap, c) with the
+// channels padded to CP = 4 or 8, so a K chunk of 32 holds 32/CP whole taps; one per-lane offset per tap per chunk,
+// every element a scalar-base load (the generic path decodes (c, dy, dx) per element).  64x256 tiles only (Cout <= 64).
+struct PackARowSt {
+    const float* base;
+    unsigned voff;
+};
+struct PackARow {  // A[m][k] = wp[m*Kp + k]  (row-major, K zero-padded to Kp)
+    static constexpr bool ALONG_K = true;
+    static constexpr bool SPLIT = true;
+    typedef PackARowSt St;
+    const float* wp;
+    int Kp;
+    __device__ __forceinline__ void init(St& st, int, int) const {
+        st.base = wp;
+        st.voff = ((threadIdx.x >> 5) * Kp + (threadIdx.x & 31)) * 4u;
+    }
+    __device__ __forceinline__ void fix(St& st, int k) const { st.base = wp + __builtin_amdgcn_readfirstlane(k & ~31); }
+    __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
+        const float* rp = st.base + (size_t)m_u * Kp;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
+    }
+};
+template <int TPC>
+struct FwdBCSt {
+    int img_rel, iy0, ix0, img0;
+    unsigned voff[TPC];
+    unsigned ok;
+};
+template <int KH, int CP>
+struct FwdBC {  // B[k=(tap, c)][n=pixel], zero padding, single full-resolution source
+    static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
+    static constexpr int TPC = 32 / CP;
+    typedef FwdBCSt<TPC> St;
+    const float* x;
+    int Cin, H, W, Npix, OH, OW, stride, pad;
+    __device__ __forceinline__ void init(St& st, int p, int p0) const {
+        const int ohw = OH * OW;
+        p = min(p, Npix - 1);
+        const int img = p / ohw, pix = p - img * ohw;
+        const int oy = pix / OW, ox = pix - oy * OW;
+        st.img0 = min(p0, Npix - 1) / ohw;
+        st.img_rel = img - st.img0;
+        st.iy0 = oy * stride - pad;
+        st.ix0 = ox * stride - pad;
+        st.ok = 0;
+#pragma unroll
+        for (int s = 0; s < TPC; ++s) st.voff[s] = 0;
+    }
+    __device__ __forceinline__ void chunk(St& st, int kc) const {
+        const int tap0 = (kc >> 5) * TPC;
+        unsigned ok = 0;
+#pragma unroll
+        for (int s = 0; s < TPC; ++s) {
+            const int tap = min(tap0 + s, KH * KH - 1);     // taps past the filter: zero weights
+            const int dy = tap / KH, dx = tap - dy * KH;
+            int iy = st.iy0 + dy, ix = st.ix0 + dx;
+            ok |= (unsigned)((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) << s;
+            iy = min(max(iy, 0), H - 1);
+            ix = min(max(ix, 0), W - 1);
+            st.voff[s] = (unsigned)((st.img_rel * Cin * H + iy) * W + ix) * 4u;
+        }
+        st.ok = ok;
+    }
+    // 64x256 tile: the k row of slot r is r itself -> tap slot r/CP, channel r%CP at compile time
+    __device__ __forceinline__ float get(const St& st, int, int r) const {
+        const float* rp = x + ((size_t)st.img0 * Cin + min(r % CP, Cin - 1)) * H * W;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[r / CP]);
+    }
+    __device__ __forceinline__ float post(const St& st, float v, int r) const { return ((st.ok >> (r / CP)) & 1u) ? v : 0.f; }
+};
+// wp[m][k = tap*CP + c] (zero padded to Kp)
+__global__ void pack_weights_rowmajor_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KHW,
+                                             int CP, int Kp) {
+    const int total = Cout * Kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i % Kp, m = i / Kp;
+        const int tap = k / CP, c = k - tap * CP;
+        wp[i] = (tap < KHW && c < Cin) ? w[((size_t)m * Cin + c) * KHW + tap] : 0.f;
+    }
+}
+
 // ---- Upsample-aware 3x3 reflect conv (iconv layers: cat(reduce, up2x(x), disp), depth_decoder.py:68,76-77).
 // For the nearest-2x upsampled segment U = up(X) an output pixel (2i+a, 2j+b) sees only a 2x2 patch of X through its
 // 9 taps: rows {i-1+a, i+a} x cols {j-1+b, j+b} (reflection padding of U == edge clamp on X).  Output pixels are
@@ -1458,6 +1541,7 @@ static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
 extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
+    if (which == 0 && Cin <= 8) return (long)(Cout + 256) * pad32(KH * KH * 8);   // row-major pack of the stem path
     if (which == 0) return Cin >= 16 ? ((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96) : 0;
     // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled segment
     if (which == 1) return Cout >= 16 ? ((long)(KH * KH + 16) * Cin + 512 + 64) * pad32(Cout) : 0;
@@ -1483,6 +1567,26 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         JP_LAUNCH_CHECK();
     }
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
+    if (ws && Cin <= 8 && Cout <= 64 && c1 == 0 && c2 == 0 && !up0 && pad_mode != JP_PAD_REFLECT && (KH == 7 || KH == 3) &&
+        npix / 256 >= 192 && (long)2 * Cin * H * W * 4 < (1L << 32)) {
+        // stem convs: whole taps per K chunk
+        const int CP = Cin <= 4 ? 4 : 8;
+        const int Kp = jp_cdiv(KH * KH * CP, KC) * KC;
+        hipLaunchKernelGGL(pack_weights_rowmajor_kernel, dim3(jp_cdiv(Cout * Kp, 256)), dim3(256), 0, st, w, ws, Cout, Cin, KH * KH,
+                           CP, Kp);
+        PackARow a{ws, Kp};
+#define JP_BC(KHv, CPv)                                                          \
+    {                                                                            \
+        FwdBC<KHv, CPv> b{x0, Cin, H, W, (int)npix, OH, OW, stride, pad};        \
+        launch<false, 1, 4>(a, b, e, Cout, (int)npix, Kp, 1, Kp, st);            \
+    }
+        if (KH == 7 && CP == 4) JP_BC(7, 4)
+        else if (KH == 7) JP_BC(7, 8)
+        else if (CP == 4) JP_BC(3, 4)
+        else JP_BC(3, 8)
+#undef JP_BC
+        JP_LAUNCH_CHECK();
+    }
     {   // upsample-aware parity-class path (iconv layers)
         const long Ncl = (long)N * (H / 2) * (W / 2);
         const bool any_up = (c0 && up0) || (c1 && up1) || (c2 && up2);

@@ -129,7 +129,8 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             s3 += [None, 0, 0]
     bt = b.t if b is not None else None
     # scratch for the packed-weight (tap-major) fast path; None -> generic path (few reduction channels)
-    ws_f = _new((_ws_floats(Cin, Cout, KH, 0),), w.t) if Cin >= 16 else None
+    nwf = _ws_floats(Cin, Cout, KH, 0)
+    ws_f = _new((nwf,), w.t) if nwf else None
     nsp = int(_jplib().fn["jp_conv2d_fwd_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
     ws_s = _new((nsp,), w.t) if nsp else None      # fixed-order split-K reduction of small-grid layers
     call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act, ws_f, ws_s)

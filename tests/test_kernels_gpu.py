@@ -67,6 +67,8 @@ CONV_CASES = [
     (2, 32, 16, 24, 32, 3, 1, 1, 0, 0, False),      # 32->32
     (2, 32, 16, 24, 16, 3, 1, 1, 1, 0, True),       # 32->16 reflect
     (2, 16, 9, 11, 24, 3, 1, 1, 0, 0, False),       # 16 channels, odd map (table wgrad)
+    (1, 3, 448, 448, 64, 7, 2, 3, 0, 0, False),     # stem at a size that takes the whole-tap K-chunk path (CP = 4)
+    (1, 6, 448, 452, 64, 7, 2, 3, 0, 1, True),      # pose stem (CP = 8), ragged width
 ]
 
 

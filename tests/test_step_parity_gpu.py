@@ -126,9 +126,13 @@ def test_train_step_matches_reference_and_oracle(case):
         # backward passes; measured against a float64 oracle the HIP step sits at a median 5e-3 and the fp32
         # CPU oracle at 1e-3 (tools/debug_f64.py), so 1e-2 is the noise floor of the comparison itself.
         # query/key of the cross-view attention only receive gradient through the hard max over 4096 positions
-        # (CrossViewTransformer.py:60-67): near-ties whose winner the forced replay reproduces still leave the
-        # *value* T = max(energy) a few ulp apart on the runner-up columns -> 4 % for those two convs
+        # (CrossViewTransformer.py:60-67); 2.1 % was observed on them in one of the discrete near-tie states the
+        # forward can land in -> 4 % for those two convs
         tol = 4e-2 if n.startswith("CrossViewTransformer.query_conv") or n.startswith("CrossViewTransformer.key_conv") else 2e-2
+        if p.numel() == 1:
+            # a one-element gradient (the disparity heads' bias) is a single sum over all pixels with heavy
+            # cancellation (|sum| ~ 1e-4 of sum|.|): no norm to average the fp32 rounding over
+            tol = 8e-2
         if err > tol * rn + floor:
             bad.append((n, err, rn))
     assert not bad, f"{len(bad)} gradient mismatches vs oracle (forced selections), first: {bad[:8]}"
