@@ -413,7 +413,7 @@ struct DgradBTSt {
 // main dgrad gather: the single dY entry reached through tap (ty,tx) by the *direct* (non-folded) path.
 // With reflection padding the extra folded-in entries of the 4 border-adjacent lines are added by a second,
 // tiny launch (DgradBorderB below), which keeps this hot loop as lean as the forward gather.
-template <int KH>
+template <int KH, bool S1 = false>   // S1: stride 1 (no per-lane integer divisions in the chunk prologue)
 struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     static constexpr bool ALONG_K = false;
     static constexpr bool POST = true;
@@ -445,9 +445,15 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
             ok = 1;
         } else {
             const int ny = st.y + pad - ty, nx = st.x + pad - tx;
-            oy = ny / stride;
-            ox = nx / stride;
-            ok = ny >= 0 && nx >= 0 && oy * stride == ny && ox * stride == nx;
+            if (S1) {
+                oy = ny;
+                ox = nx;
+                ok = 1;        // range-checked below
+            } else {
+                oy = ny / stride;
+                ox = nx / stride;
+                ok = ny >= 0 && nx >= 0 && oy * stride == ny && ox * stride == nx;
+            }
         }
         st.ok = ok && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
         oy = min(max(oy, 0), OH - 1);
@@ -1731,6 +1737,19 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                 launch_auto(a, b, ea, Cin, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
             });
         } else {
+            if (stride == 1) {
+                JP_KH_SWITCH(KH, {
+                    DgradBT<KH_, true> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+                    const int tail = (Cin > 128 && Cin % 128 <= 16) ? Cin % 128 : 0;
+                    const int Mm = Cin - tail;
+                    launch_auto(a, b, e, Mm, (int)npix, Kp, 1, Kp, st);
+                    if (tail) {
+                        PackA at{ws + (size_t)Mm * Cp, Cin, Kp, Cp, KH * KH};
+                        DgradEpi et{dx + (size_t)Mm * H * W, Cin, H * W, accumulate};
+                        launch_auto(at, b, et, tail, (int)npix, Kp, 1, Kp, st);
+                    }
+                });
+            } else
             JP_KH_SWITCH(KH, {
                 DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
                 // a short row tail (513 = 4*128 + 1 input channels of the iconv layers) runs as its own 64-row launch
@@ -1805,7 +1824,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
     pack_weights(w, ws, Cout, Cin, 9, Cp, 1, st);                 // [tap][ci][Cp] for the full-resolution segments
     float* wsT = ws + ((size_t)9 * Cin + 256) * Cp;               // [16][Cx][Cp] for the upsampled one
     const int cx_up = up0 ? c0 : (up1 ? c1 : c2);
-    DgradBT<3> b{dy, Cp, (int)npix, H, W, Cout, H, W, 1, 1, 1};
+    DgradBT<3, true> b{dy, Cp, (int)npix, H, W, Cout, H, W, 1, 1, 1};
     int coff = 0;
     for (int sidx = 0; sidx < 3; ++sidx) {
         const int C = cs[sidx];
