@@ -1530,6 +1530,19 @@ int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1,
 int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
                         int up2, const float* dy, float* dw, int N, int H, int W, int Cout, int reflect,
                         hipStream_t st);
+int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
+                   hipStream_t st);
+int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, int h, int wd, int accumulate, hipStream_t st);
+int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st);
+// one-channel head on a single nearest-2x-upsampled source (the disparity heads): upsample-aware direct kernels
+static inline bool up_head(int c0, int up0, int c1, int c2, int Cout, int KH, int stride, int pad, int pad_mode, int H, int W) {
+    return Cout == 1 && c1 == 0 && c2 == 0 && up0 && c0 >= 8 && c0 <= 768 && KH == 3 && stride == 1 && pad == 1 &&
+           pad_mode == JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 4;
+}
+extern "C" int jp_conv2d_up_head_ok(int c0, int up0, int c1, int c2, int Cout, int KH, int stride, int pad, int pad_mode, int H,
+                                    int W) {
+    return up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W) ? 1 : 0;
+}
 static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
     return Cout <= 4 && KH == 3 && stride == 1 && pad == 1 && (long)Cout * Cin * 9 * 4 <= 48 * 1024;
 }
@@ -1567,6 +1580,10 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     JP_CHECK_ARG(npix < (1L << 31) && (long)N * Cin * H * W < (1L << 31) * 2, "conv2d_fwd: tensor too large");
     hipStream_t st = (hipStream_t)stream;
     FwdEpi e{y, bias, Cout, OH * OW, act};
+    if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
+        jp_up_head_fwd(x0, w, bias, y, N, c0, H / 2, W / 2, act, st);
+        JP_LAUNCH_CHECK();
+    }
     if (small_head(Cin, Cout, KH, stride, pad)) {
         jp_conv_small_fwd(x0, c0, up0, x1, c1, up1, x2, c2, up2, w, bias, y, N, H, W, Cout, act,
                           pad_mode == JP_PAD_REFLECT, st);
@@ -1808,12 +1825,18 @@ static bool dgrad_segments_ok(int c0, int up0, int c1, int up1, int c2, int up2,
 }
 extern "C" int jp_conv2d_dgrad_src3_ok(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W, int Cout,
                                        int KH, int stride, int pad, int pad_mode) {
+    if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) return 1;
     return dgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode) ? 1 : 0;
 }
 extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
                                     int c1, int up1, int acc1, float* dx2, int c2, int up2, int acc2, int N, int H, int W,
                                     int Cout, int KH, int stride, int pad, int pad_mode, float* ws, void* stream) {
-    JP_CHECK_ARG(dy && w && ws, "conv2d_dgrad_src3: null pointer");
+    JP_CHECK_ARG(dy && w, "conv2d_dgrad_src3: null pointer");
+    if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
+        if (dx0) jp_up_head_dgrad(dy, w, dx0, N, c0, H / 2, W / 2, acc0, (hipStream_t)stream);
+        JP_LAUNCH_CHECK();
+    }
+    JP_CHECK_ARG(ws != nullptr, "conv2d_dgrad_src3: null scratch");
     JP_CHECK_ARG(dgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode),
                  "conv2d_dgrad_src3: shape not supported (check jp_conv2d_dgrad_src3_ok)");
     hipStream_t st = (hipStream_t)stream;
@@ -1883,6 +1906,10 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     JP_CHECK_ARG(npix < (1L << 31), "conv2d_wgrad: tensor too large");
     const int Kw = Cin * KH * KH;
     const bool whole = dw_coff == 0 && dw_ctot == Cin;
+    if (whole && up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
+        jp_up_head_wgrad(x0, dy, dw, N, c0, H / 2, W / 2, st);
+        JP_LAUNCH_CHECK();
+    }
     if (whole && small_head(Cin, Cout, KH, stride, pad)) {
         jp_conv_small_wgrad(x0, c0, up0, x1, c1, up1, x2, c2, up2, dy, dw, N, H, W, Cout, pad_mode == JP_PAD_REFLECT, st);
         JP_LAUNCH_CHECK();

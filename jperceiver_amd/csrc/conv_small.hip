@@ -222,6 +222,146 @@ Src3s make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up
     return s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Disparity heads Conv3x3(up2x(x)) -> 1 channel (depth_decoder.py:36-39), upsample-aware: an output pixel (2i+a, 2j+b)
+// sees a 2x2 patch of the half-resolution x (reflection padding of up(x) == edge clamp on x), so all three kernels
+// work on the half-resolution grid with the 16 pre-summed (class, slot) weights
+//   W'[(a,b),(r,s)][c] = sum_{dy in Dy(a,r), dx in Dx(b,s)} w[c][dy][dx],  Dy(0,.) = {0},{1,2};  Dy(1,.) = {0,1},{2}.
+__device__ __forceinline__ void up_tap_range(int a, int r, int& lo, int& hi) {
+    lo = a ? (r ? 2 : 0) : (r ? 1 : 0);
+    hi = a ? (r ? 2 : 1) : (r ? 2 : 0);
+}
+// wq[q][c], q = a*8 + b*4 + r*2 + s
+__device__ __forceinline__ void up_build_weights(const float* __restrict__ w, float* wq, int C) {
+    for (int i = threadIdx.x; i < 16 * C; i += blockDim.x) {
+        const int c = i % C, q = i / C;
+        int y0, y1, x0, x1;
+        up_tap_range(q >> 3, (q >> 1) & 1, y0, y1);
+        up_tap_range((q >> 2) & 1, q & 1, x0, x1);
+        float v = 0.f;
+        for (int dy = y0; dy <= y1; ++dy)
+            for (int dx = x0; dx <= x1; ++dx) v += w[c * 9 + dy * 3 + dx];
+        wq[i] = v;
+    }
+}
+// D[q] = sum of the dY entries that reach x(i, j) through (class, slot) q: the regular one (i', j') = (i+1-a-r, j+1-b-s)
+// plus the clamp-folded ones on the 4 boundary lines.  dyp = one (2h x 2w) plane.
+__device__ __forceinline__ void up_gather_D(const float* __restrict__ dyp, int i, int j, int h, int w, float D[16]) {
+    const int W = 2 * w;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int a = q >> 3, b = (q >> 2) & 1, r = (q >> 1) & 1, s = q & 1;
+        const int ri = i + 1 - a - r, rj = j + 1 - b - s;
+        const int ei = (i == 0 && a == 0 && r == 0) ? 0 : ((i == h - 1 && a == 1 && r == 1) ? h - 1 : -1);
+        const int ej = (j == 0 && b == 0 && s == 0) ? 0 : ((j == w - 1 && b == 1 && s == 1) ? w - 1 : -1);
+        const bool rv = (unsigned)ri < (unsigned)h, cv = (unsigned)rj < (unsigned)w;
+        float v = 0.f;
+        if (rv && cv) v += dyp[(2 * ri + a) * W + 2 * rj + b];
+        if (ei >= 0 && cv) v += dyp[(2 * ei + a) * W + 2 * rj + b];
+        if (rv && ej >= 0) v += dyp[(2 * ri + a) * W + 2 * ej + b];
+        if (ei >= 0 && ej >= 0) v += dyp[(2 * ei + a) * W + 2 * ej + b];
+        D[q] = v;
+    }
+}
+
+// forward: one thread per half-resolution pixel -> its 2x2 output block
+__global__ __launch_bounds__(TPB) void up_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                          int h, int wd, int act) {
+    extern __shared__ float wq[];   // [16][C]
+    up_build_weights(w, wq, C);
+    __syncthreads();
+    const int img = blockIdx.y, hw = h * wd;
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    const int i = p / wd, j = p - i * wd;
+    const int r0 = max(i - 1, 0) * wd, r1 = i * wd, r2 = min(i + 1, h - 1) * wd;
+    const int c0 = max(j - 1, 0), c2 = min(j + 1, wd - 1);
+    float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+    const float* xp = x + (size_t)img * C * hw;
+    for (int c = 0; c < C; ++c) {
+        const float* q = xp + (size_t)c * hw;
+        const float v00 = q[r0 + c0], v01 = q[r0 + j], v02 = q[r0 + c2];
+        const float v10 = q[r1 + c0], v11 = q[r1 + j], v12 = q[r1 + c2];
+        const float v20 = q[r2 + c0], v21 = q[r2 + j], v22 = q[r2 + c2];
+        const float* wc = wq + c;
+        // class (a,b) reads v[a+r][b+s]
+        o00 += wc[0 * C] * v00 + wc[1 * C] * v01 + wc[2 * C] * v10 + wc[3 * C] * v11;
+        o01 += wc[4 * C] * v01 + wc[5 * C] * v02 + wc[6 * C] * v11 + wc[7 * C] * v12;
+        o10 += wc[8 * C] * v10 + wc[9 * C] * v11 + wc[10 * C] * v20 + wc[11 * C] * v21;
+        o11 += wc[12 * C] * v11 + wc[13 * C] * v12 + wc[14 * C] * v21 + wc[15 * C] * v22;
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    float* yo = y + (size_t)img * 4 * hw + (size_t)(2 * i) * (2 * wd) + 2 * j;
+    *reinterpret_cast<float2*>(yo) = make_float2(jp_act(o00 + bv, act), jp_act(o01 + bv, act));
+    *reinterpret_cast<float2*>(yo + 2 * wd) = make_float2(jp_act(o10 + bv, act), jp_act(o11 + bv, act));
+}
+
+// dgrad: dx[c][i][j] (= | +=) sum_q W'[q][c] * D_q(i, j), straight at half resolution
+__global__ __launch_bounds__(TPB) void up_head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int C, int h, int wd,
+                                                            int accumulate) {
+    extern __shared__ float wq[];
+    up_build_weights(w, wq, C);
+    __syncthreads();
+    const int img = blockIdx.y, hw = h * wd;
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    float D[16];
+    up_gather_D(dy + (size_t)img * 4 * hw, p / wd, p % wd, h, wd, D);
+    float* dp = dx + (size_t)img * C * hw + p;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v = fmaf(wq[q * C + c], D[q], v);
+        float* o = dp + (size_t)c * hw;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+// wgrad: dW'[q][c] = sum_{img, i, j} D_q(i, j) * x[c][i][j], folded into dw[c][tap] on the way out.
+// grid (C/8, pixel bands, batch); 8 channels x 16 (class, slot) accumulators per thread.
+constexpr int UP_CB = 8;
+__global__ __launch_bounds__(TPB) void up_head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dw, int C, int h, int wd, int band) {
+    __shared__ float red[4][UP_CB * 16];
+    const int c0 = blockIdx.x * UP_CB, img = blockIdx.z, hw = h * wd;
+    const float* xp = x + ((size_t)img * C + c0) * hw;
+    const float* dyp = dy + (size_t)img * 4 * hw;
+    float acc[UP_CB * 16];
+#pragma unroll
+    for (int i = 0; i < UP_CB * 16; ++i) acc[i] = 0.f;
+    const int pend = min(hw, (int)(blockIdx.y + 1) * band);
+    for (int p = blockIdx.y * band + threadIdx.x; p < pend; p += TPB) {
+        float D[16];
+        up_gather_D(dyp, p / wd, p % wd, h, wd, D);
+#pragma unroll
+        for (int k = 0; k < UP_CB; ++k) {
+            const float xv = (c0 + k < C) ? xp[(size_t)k * hw + p] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[k * 16 + q] = fmaf(xv, D[q], acc[k * 16 + q]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < UP_CB * 16; ++i) {
+        const float s = jp_wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < UP_CB * 16) {
+        const int k = threadIdx.x >> 4, q = threadIdx.x & 15;
+        if (c0 + k < C) {
+            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            int y0, y1, x0, x1;
+            up_tap_range(q >> 3, (q >> 1) & 1, y0, y1);
+            up_tap_range((q >> 2) & 1, q & 1, x0, x1);
+            for (int ty = y0; ty <= y1; ++ty)
+                for (int tx = x0; tx <= x1; ++tx) atomicAdd(dw + (size_t)(c0 + k) * 9 + ty * 3 + tx, s);
+        }
+    }
+}
+
 }  // namespace
 
 // internal entry points used by conv.hip's dispatcher (not part of the public ABI)
@@ -273,5 +413,28 @@ int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c
         default: JP_GO(4); break;
     }
 #undef JP_GO
+    return 0;
+}
+
+// upsample-aware disparity head (Cout = 1, one source read through the nearest-2x upsample, reflection padding);
+// x: (N, C, h, w), y / dy: (N, 1, 2h, 2w)
+int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(up_head_fwd_kernel, dim3(jp_cdiv(h * wd, TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w, bias, y,
+                       C, h, wd, act);
+    return 0;
+}
+int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, int h, int wd, int accumulate,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(up_head_dgrad_kernel, dim3(jp_cdiv(h * wd, TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, dy, w, dx, C,
+                       h, wd, accumulate);
+    return 0;
+}
+int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st) {
+    const int hw = h * wd;
+    const int bands = std::max(1, std::min(hw / (TPB * 16), 16));
+    const int band = jp_cdiv(jp_cdiv(hw, bands), TPB) * TPB;
+    hipLaunchKernelGGL(up_head_wgrad_kernel, dim3(jp_cdiv(C, UP_CB), jp_cdiv(hw, band), N), dim3(TPB), 0, st, x, dy, dw, C, h, wd,
+                       band);
     return 0;
 }

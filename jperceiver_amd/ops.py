@@ -152,7 +152,11 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             if len(srcs) > 1:
                 nms = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout,
                                                                          KH, stride, pad, pad_mode))
-            if nms:
+            up_head = len(srcs) == 1 and srcs[0][1] and int(_jplib().fn["jp_conv2d_up_head_ok"](
+                s3[1], s3[2], 0, 0, Cout, KH, stride, pad, pad_mode, H, W))
+            if up_head:     # disparity head on an upsampled source: upsample-aware direct kernel, nothing materialised
+                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, None, 0)
+            elif nms:
                 # per-segment wgrad inside the library: full-resolution segments from their own tensors, the
                 # upsampled one in parity-class form -- no materialised concat
                 ws_w = _new((nms,), dy)

@@ -45,3 +45,31 @@ def run_oracle(meta, backward=True, force=None):
     if backward:
         total.backward()
     return dict(P=P, Bf=Bf, out=out, L=L, total=total, opt=opt, inp=inp)
+
+
+def run_oracle_f64(meta, force, label):
+    """The oracle in float64 (same forced discrete selections, scale label given): the referee for gradients whose
+    fp32 evaluation is cancellation-limited.  -> {name: float64 gradient}"""
+    from oracle import jp_oracle as J
+    opt = oracle_opt(meta)
+    shapes = J.state_shapes(meta["occ"])
+    tmpl = {n: torch.empty(s, dtype=torch.long if n.endswith("num_batches_tracked") else torch.float32)
+            for n, s in shapes.items()}
+    state = syn.synth_state_dict(tmpl, seed=0)
+    P, Bf = {}, {}
+    for n in shapes:
+        t = state[n].clone()
+        if J.is_buffer(n):
+            Bf[n] = t.double() if t.dtype == torch.float32 else t
+        else:
+            P[n] = t.double().requires_grad_(True)
+    inp, masks, noise = case_inputs(meta)
+    inp64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in inp.items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        _, L = J.forward(P, Bf, opt, inp64, True, tuple(m.double() for m in masks),
+                         [[z.double() for z in per] for per in noise], label.double(), force)
+        J.total_loss(L).backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return {n: p.grad for n, p in P.items() if p.grad is not None}

@@ -127,6 +127,28 @@ def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
         close(got, ref.grad, rtol=2e-4, msg=nm)
 
 
+@pytest.mark.parametrize("N,C,h,w", [(2, 40, 6, 10), (1, 256, 20, 36), (3, 64, 2, 2), (1, 256, 64, 64)])
+def test_disparity_head_on_upsampled_source(N, C, h, w):
+    """disp_k = sigmoid(Conv3x3_reflect(up2x(x))) (depth_decoder.py:36-39,70-71): upsample-aware direct kernels."""
+    x = rnd(N, C, h, w, seed=1)
+    wt, b = rnd(1, C, 3, 3, seed=2, scale=0.1), rnd(1, seed=3)
+    xv, wv, bv = Var(x, True), pvar(wt), pvar(b)
+    tape = Tape()
+    with recording(tape):
+        y = ops.conv2d(None, wv, bv, 1, 1, 1, 3, srcs=[(xv, 1)])
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, wt, b))
+    up = F.interpolate(xr, scale_factor=2, mode="nearest")
+    yr = torch.sigmoid(F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), wr, br))
+    close(y.t, yr, msg="fwd")
+    gy = rnd(*yr.shape, seed=4)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy)
+    close(xv.g, xr.grad, rtol=2e-4, msg="dx (half resolution)")
+    close(wv.g, wr.grad, rtol=2e-4, msg="dw")
+    close(bv.g, br.grad, rtol=2e-4, msg="db")
+
+
 # ------------------------------------------------------------------------------------------- batch norm
 @pytest.mark.parametrize("relu,res,nup", [(True, False, 1), (True, True, 1), (False, False, 2)])
 def test_batchnorm_train(relu, res, nup):

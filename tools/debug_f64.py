@@ -56,6 +56,12 @@ worst.sort(reverse=True)
 print("rel. gradient error vs float64 oracle:  HIP   |  fp32 CPU oracle")
 for eh, ec, n in worst[:25]:
     print(f"  {eh:9.2e} | {ec:9.2e}  {n}")
+pat = os.environ.get("PAT")
+if pat:
+    print("-- parameters matching", pat)
+    for eh, ec, n in worst:
+        if pat in n:
+            print(f"  {eh:9.2e} | {ec:9.2e}  {n}")
 import statistics
 print("median HIP %.2e  median CPU32 %.2e" % (statistics.median(w[0] for w in worst), statistics.median(w[1] for w in worst)))
 for k in L:
