@@ -400,6 +400,8 @@ struct FwdBT {  // B[k=(tap,ci)][n=pixel]
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * st.hw;
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return REFLECT || __all(st.ok); }
     __device__ __forceinline__ float post(const St& st, float v, int) const { return (REFLECT || st.ok) ? v : 0.f; }
 };
 
@@ -467,6 +469,8 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (OH * OW);
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok); }
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
@@ -540,6 +544,8 @@ struct FwdBC {  // B[k=(tap, c)][n=pixel], zero padding, single full-resolution 
         const float* rp = x + ((size_t)st.img0 * Cin + min(r % CP, Cin - 1)) * H * W;
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[r / CP]);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok == ((1u << TPC) - 1u)); }
     __device__ __forceinline__ float post(const St& st, float v, int r) const { return ((st.ok >> (r / CP)) & 1u) ? v : 0.f; }
 };
 // wp[m][k = tap*CP + c] (zero padded to Kp)
@@ -661,6 +667,8 @@ struct FwdBP {  // B[k][n=(class, img, i, j)], 3x3 stride 1 reflection pad
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * st.hw;
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St&) const { return true; }
     __device__ __forceinline__ float post(const St&, float v, int) const { return v; }
 };
 struct FwdEpiP {  // y[img][co][2i+a][2j+b] = act(acc + bias[co])
@@ -853,6 +861,8 @@ struct DgradUPB {
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (4 * h2 * w2);
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok); }
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
@@ -1029,6 +1039,8 @@ struct DgradS2B {  // B[k=(cc, slot, co)][n=(class, img, i, j)]
         const float* rp = st.rowp + (size_t)min(kl, st.nm1) * (OH * OW);
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok); }
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 struct DgradS2Epi {  // dx[img][ci][2i+py][2j+px] (= or +=) acc
@@ -1302,6 +1314,8 @@ struct WgradBUS {
         const float* rp = st.base + (size_t)(8 * r) * H * W;
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return REFLECT || __all(st.ok); }
     __device__ __forceinline__ float post(const St& st, float v, int) const { return (REFLECT || st.ok) ? v : 0.f; }
 };
 
@@ -1361,6 +1375,8 @@ struct WgradBMS {
         const float* rp = st.base + (size_t)((8 * r) % CPT) * H * W;
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[(8 * r) / CPT]);
     }
+    static constexpr bool ALL_OK = true;
+    __device__ __forceinline__ bool all_ok(const St& st) const { return REFLECT || __all(st.ok == ((1u << TPT) - 1u)); }
     __device__ __forceinline__ float post(const St& st, float v, int r) const {
         return (REFLECT || ((st.ok >> ((8 * r) / CPT)) & 1u)) ? v : 0.f;
     }

@@ -32,6 +32,8 @@ template <class L, class = void> struct jp_has_post : std::false_type {};
 template <class L> struct jp_has_post<L, std::void_t<decltype(L::POST)>> : std::true_type {};
 template <class E, class = void> struct jp_epi_wants_slice : std::false_type {};   // put(st, m, v, k_slice)
 template <class E> struct jp_epi_wants_slice<E, std::void_t<decltype(E::WANTS_SLICE)>> : std::true_type {};
+template <class L, class = void> struct jp_has_all_ok : std::false_type {};   // bool all_ok(st): wave-uniform "nothing to mask"
+template <class L> struct jp_has_all_ok<L, std::void_t<decltype(L::ALL_OK)>> : std::true_type {};
 template <class L, class = void> struct jp_wants_tile : std::false_type {};   // init(st, first, step, m0, n0)
 template <class L> struct jp_wants_tile<L, std::void_t<decltype(L::WANTS_TILE)>> : std::true_type {};
 template <class L, class = void> struct jp_has_split : std::false_type {};
@@ -158,12 +160,23 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
             if (ALoad::ALONG_K) Ad[a_fix_l * LDA + a_var_l + A_ROWS * r] = v;
             else Ad[(a_var_l + A_ROWS * r) * LDA + a_fix_l] = v;
         }
+        // interior waves (every lane's taps inside the image) skip the per-element mask selects: one scalar branch
+        bool maskB = jp_has_post<BLoad>::value;
+        if constexpr (jp_has_all_ok<BLoad>::value) maskB = !bl.all_ok(sb);
+        if (maskB) {
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            float v = rb[r];
-            if constexpr (jp_has_post<BLoad>::value) v = bl.post(sb, v, r);
-            if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = v;
-            else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = v;
+            for (int r = 0; r < NB; ++r) {
+                float v = rb[r];
+                if constexpr (jp_has_post<BLoad>::value) v = bl.post(sb, v, r);
+                if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = v;
+                else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                if (BLoad::ALONG_K) Bd[b_fix_l * LDB + b_var_l + B_ROWS * r] = rb[r];
+                else Bd[(b_var_l + B_ROWS * r) * LDB + b_fix_l] = rb[r];
+            }
         }
     };
 
