@@ -1065,8 +1065,11 @@ struct DgradS2Epi {  // dx[img][ci][2i+py][2j+px] (= or +=) acc
 // dY entries: row extras r1 = 0 (y==1, ty==0) / H-1 (y==H-2, ty==2), column extras likewise.
 struct DgradBorderSt {
     InPixSt px;
-    const float* p;
-    int o1, o2, o3, n;
+    int img0;
+    const float* rowp;
+    unsigned v1, v2, v3;
+    float m1, m2, m3;
+    int nm1;
 };
 __device__ __forceinline__ InPixSt border_pix(int b, int Nb, int H, int W) {
     InPixSt px;
@@ -1086,34 +1089,46 @@ __device__ __forceinline__ InPixSt border_pix(int b, int Nb, int H, int W) {
 }
 
 template <int KH>
-struct DgradBorderB {
+struct DgradBorderB {   // scalar-base: uniform dY plane pointer + three per-lane byte offsets with 0/1 weights, no branches
     static constexpr bool ALONG_K = false;
+    static constexpr bool POST = true;
     typedef DgradBorderSt St;
     const float* dy;
     int Cp, Nb, H, W, Cout;
-    __device__ __forceinline__ void init(St& st, int b) const { st = St{border_pix(b, Nb, H, W), nullptr, -1, -1, -1, 0}; }
+    __device__ __forceinline__ void init(St& st, int b, int b0) const {
+        st.px = border_pix(min(b, Nb - 1), Nb, H, W);
+        if (b >= Nb) st.px.valid = 0;
+        st.img0 = border_pix(min(b0, Nb - 1), Nb, H, W).img;
+        st.rowp = dy;
+        st.v1 = st.v2 = st.v3 = 0;
+        st.m1 = st.m2 = st.m3 = 0.f;
+        st.nm1 = 0;
+    }
     __device__ __forceinline__ void chunk(St& st, int kc) const {
         const int q = kc >> 5;
         const int cc = q / (KH * KH), tap = q - cc * (KH * KH);
         const int co0 = cc << 5;
         const int ty = tap / KH, tx = tap - ty * KH;
-        st.n = 0;
-        if (!st.px.valid || co0 >= Cout) return;
         const DyOffs d = dy_offsets(st.px.y, st.px.x, ty, tx, H, W, H, W, 1, 1, 1);
-        if (d.o1 < 0 && d.o2 < 0 && d.o3 < 0) return;
-        st.o1 = d.o1; st.o2 = d.o2; st.o3 = d.o3;
-        st.p = dy + (size_t)(st.px.img * Cout + co0) * H * W;
-        st.n = min(32, Cout - co0);
+        const bool ok = st.px.valid;
+        const unsigned base = (unsigned)((st.px.img - st.img0) * Cout * H * W);
+        st.m1 = (ok && d.o1 >= 0) ? 1.f : 0.f;
+        st.m2 = (ok && d.o2 >= 0) ? 1.f : 0.f;
+        st.m3 = (ok && d.o3 >= 0) ? 1.f : 0.f;
+        st.v1 = (base + (unsigned)max(d.o1, 0)) * 4u;
+        st.v2 = (base + (unsigned)max(d.o2, 0)) * 4u;
+        st.v3 = (base + (unsigned)max(d.o3, 0)) * 4u;
+        st.rowp = dy + (size_t)(st.img0 * Cout + co0) * H * W;
+        st.nm1 = min(32, Cout - co0) - 1;
     }
     __device__ __forceinline__ float get(const St& st, int kl, int) const {
-        if (kl >= st.n) return 0.f;
-        const float* q = st.p + (size_t)kl * H * W;
-        float v = 0.f;
-        if (st.o1 >= 0) v += q[st.o1];
-        if (st.o2 >= 0) v += q[st.o2];
-        if (st.o3 >= 0) v += q[st.o3];
-        return v;
+        const char* rp = reinterpret_cast<const char*>(st.rowp + (size_t)min(kl, st.nm1) * H * W);
+        const float a = *reinterpret_cast<const float*>(rp + st.v1);
+        const float b = *reinterpret_cast<const float*>(rp + st.v2);
+        const float c = *reinterpret_cast<const float*>(rp + st.v3);
+        return fmaf(st.m1, a, fmaf(st.m2, b, st.m3 * c));
     }
+    __device__ __forceinline__ float post(const St&, float v, int) const { return v; }
 };
 
 struct DgradBorderEpi {  // dx[img][ci][y][x] += acc for the border pixel b
