@@ -31,10 +31,16 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__
     s += fs; q += fq;
     s = jp_block_sum_d(s, sm);
     q = jp_block_sum_d(q, sm);
-    if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * c], s);
-        atomicAdd(&sums[2 * c + 1], q);
+    if (threadIdx.x == 0) {   // per-workgroup partials, summed in a fixed order by the consumer: no memset, no atomics
+        sums[(size_t)(2 * c) * gridDim.y + blockIdx.y] = s;
+        sums[(size_t)(2 * c + 1) * gridDim.y + blockIdx.y] = q;
     }
+}
+
+__device__ __forceinline__ double bn_partial_sum(const double* __restrict__ sums, int row, int S) {
+    double t = 0.0;
+    for (int i = 0; i < S; ++i) t += sums[(size_t)row * S + i];
+    return t;
 }
 
 // C threads: mean / invstd and running-stat momentum update (applied n_updates times: the
@@ -42,11 +48,11 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, int C, double count, float momentum, float eps,
-                                   int n_updates) {
+                                   int n_updates, int S) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = sums[2 * c] / count;
-    double var = sums[2 * c + 1] / count - m * m;
+    const double m = bn_partial_sum(sums, 2 * c, S) / count;
+    double var = bn_partial_sum(sums, 2 * c + 1, S) / count - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -130,8 +136,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restr
     s = jp_block_sum_d(s, sm);
     q = jp_block_sum_d(q, sm);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * c], s);
-        atomicAdd(&sums[2 * c + 1], q);
+        sums[(size_t)(2 * c) * gridDim.y + blockIdx.y] = s;
+        sums[(size_t)(2 * c + 1) * gridDim.y + blockIdx.y] = q;
     }
 }
 
@@ -144,13 +150,26 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            const double* __restrict__ sums, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C, int HW, double count,
-                                                           int relu, int acc_param_grads) {
+                                                           int relu, int acc_param_grads, int S) {
     const int nc = blockIdx.y;
     const int c = nc % C;
     const float mu = mean[c], is = invstd[c], g = gamma[c];
-    const float k1 = (float)(sums[2 * c] / count), k2 = (float)(sums[2 * c + 1] / count);
+    __shared__ double tot[2];
+    if (threadIdx.x < 64) {   // one wave sums the partials (fixed order), the rest of the workgroup waits
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < S; i += 64) {
+            a += sums[(size_t)(2 * c) * S + i];
+            b += sums[(size_t)(2 * c + 1) * S + i];
+        }
+        a = jp_wave_sum_d(a);
+        b = jp_wave_sum_d(b);
+        if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
+    }
+    __syncthreads();
+    const double t1 = tot[0], t2 = tot[1];
+    const float k1 = (float)(t1 / count), k2 = (float)(t2 / count);
     if (nc < C && blockIdx.x == 0 && threadIdx.x == 0) {  // image 0 owns the parameter gradients
-        const float dg = (float)sums[2 * c + 1], db = (float)sums[2 * c];
+        const float dg = (float)t2, db = (float)t1;
         dgamma[c] = acc_param_grads ? dgamma[c] + dg : dg;
         dbeta[c] = acc_param_grads ? dbeta[c] + db : db;
     }
@@ -194,7 +213,14 @@ void chunking(int N, int C, int HW, int* CH, int* chunk) {
 
 }  // namespace
 
-// ws: 2*C doubles of caller-owned scratch (zeroed here).  Saves mean/invstd for backward.
+// ws: jp_bn_ws_doubles(N, C, HW) doubles of caller-owned scratch (per-workgroup partial sums, reduced in a fixed order:
+// no memset, no atomics, bit-reproducible statistics).  Saves mean/invstd for backward.
+extern "C" long jp_bn_ws_doubles(int N, int C, int HW) {
+    int CH, chunk;
+    chunking(N, C, HW, &CH, &chunk);
+    return 2L * C * N * CH;
+}
+
 extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                                float* y, float* running_mean, float* running_var, float* save_mean,
                                float* save_invstd, double* ws, int N, int C, int HW, float momentum, float eps,
@@ -202,12 +228,11 @@ extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* 
     JP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn_train_fwd: bad dims");
     hipStream_t st = (hipStream_t)stream;
-    JP_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
     int CH, chunk;
     chunking(N, C, HW, &CH, &chunk);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(jp_cdiv(C, 64)), dim3(64), 0, st, ws, save_mean, save_invstd,
-                       running_mean, running_var, C, (double)N * HW, momentum, eps, n_updates);
+                       running_mean, running_var, C, (double)N * HW, momentum, eps, n_updates, N * CH);
     const int gx = std::min(jp_cdiv(HW, TPB), 64);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, save_mean, save_invstd, gamma, beta,
                        residual, y, C, HW, relu);
@@ -221,14 +246,13 @@ extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, 
     JP_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
     JP_CHECK_ARG(!relu || y, "bn_train_bwd: relu needs the forward output");
     hipStream_t st = (hipStream_t)stream;
-    JP_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
     int CH, chunk;
     chunking(N, C, HW, &CH, &chunk);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, ws, C,
                        HW, CH, chunk, relu);
     const int gx = std::min(jp_cdiv(HW, TPB), 64);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, gamma,
-                       ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads);
+                       ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH);
     JP_LAUNCH_CHECK();
 }
 

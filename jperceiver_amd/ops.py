@@ -227,7 +227,8 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
     y = torch.empty_like(x.t)
     mean = _new((C,), x.t)
     invstd = _new((C,), x.t)
-    ws = _new((2 * C,), x.t, torch.float64)
+    nbw = int(_jplib().fn["jp_bn_ws_doubles"](N, C, H * W))
+    ws = _new((nbw,), x.t, torch.float64)
     call("jp_bn_train_fwd", x.t, gamma.t, beta.t, residual.t if residual is not None else None, y, running_mean,
          running_var, mean, invstd, ws, N, C, H * W, momentum, eps, int(relu), n_updates)
     out = Var(y, x.rg or gamma.rg or (residual is not None and residual.rg))
@@ -238,7 +239,7 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
         dx = torch.empty_like(x.t)
         need_res = residual is not None and residual.rg
         dres = torch.empty_like(x.t) if need_res else None
-        ws2 = _new((2 * C,), x.t, torch.float64)
+        ws2 = _new((nbw,), x.t, torch.float64)
         call("jp_bn_train_bwd", out.g, x.t, y if relu else None, gamma.t, mean, invstd, dx, dres, gamma.g, beta.g, ws2,
              N, C, H * W, int(relu), 1)
         if x.rg:
