@@ -1266,15 +1266,17 @@ struct WgradAS {  // A[m=co][k=pixel] = dY[img][co][pix]
     static constexpr bool SPLIT = true;
     typedef WgradASSt St;
     const float* dy;
-    int Cout, Npix, OHW;
+    int Cout, Npix, OHW, P;   // P = pixels per image padded to 32: K = (img, padded pixel), the padding is masked on B
     __device__ __forceinline__ void init(St& st, int, int) const {
         st.base = dy;
         st.voff = ((threadIdx.x >> 5) * OHW + (threadIdx.x & 31)) * 4u;
     }
     __device__ __forceinline__ void fix(St& st, int p) const {
         const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
-        const int img = p0 / OHW;
-        st.base = dy + (size_t)img * Cout * OHW + (p0 - img * OHW);
+        const int img = p0 / P, pix0 = p0 - img * P;
+        st.base = dy + (size_t)img * Cout * OHW + pix0;
+        // lanes in the per-image K padding re-read the last pixel (their B operand is zeroed)
+        st.voff = ((threadIdx.x >> 5) * OHW + min((int)(threadIdx.x & 31), OHW - 1 - pix0)) * 4u;
     }
     __device__ __forceinline__ float get_u(const St& st, int m_u, int) const {
         const float* rp = st.base + (size_t)min(m_u, Cout - 8) * OHW;   // rows >= Cout: duplicates, never stored
@@ -1296,7 +1298,7 @@ struct WgradBUS {
     static constexpr bool POST = true;
     typedef WgradBUSSt St;
     const float* x;
-    int Cpp, Ctot, H, W, OH, OW, stride, pad;
+    int Cpp, Ctot, H, W, OH, OW, stride, pad, P;
     __device__ __forceinline__ void init(St& st, int n_first, int) const {
         const int n0 = __builtin_amdgcn_readfirstlane(n_first - (int)(threadIdx.x >> 5));
         const int tap = n0 / Cpp;
@@ -1310,15 +1312,17 @@ struct WgradBUS {
     __device__ __forceinline__ void fix(St& st, int p) const {
         const int ohw = OH * OW;
         const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
-        const int img = p0 / ohw;                       // uniform
-        const int pix = p - img * ohw;
+        const int img = p0 / P;                         // uniform
+        const int pr = p - img * P;
+        const int pix = min(pr, ohw - 1);
         const int oy = pix / OW, ox = pix - oy * OW;
         int iy = oy * stride - pad + st.dy, ix = ox * stride - pad + st.dx;
+        st.ok = pr < ohw;                               // per-image K padding
         if (REFLECT) {
             iy = jp_reflect(iy, H);
             ix = jp_reflect(ix, W);
         } else {
-            st.ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            st.ok = st.ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             iy = min(max(iy, 0), H - 1);
             ix = min(max(ix, 0), W - 1);
         }
@@ -1330,8 +1334,8 @@ struct WgradBUS {
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff);
     }
     static constexpr bool ALL_OK = true;
-    __device__ __forceinline__ bool all_ok(const St& st) const { return REFLECT || __all(st.ok); }
-    __device__ __forceinline__ float post(const St& st, float v, int) const { return (REFLECT || st.ok) ? v : 0.f; }
+    __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok); }
+    __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
 // CPT-channel inputs (CPT = 16, 32 or 64): a CPT*TPT wide N tile holds TPT whole filter taps, and slot group r (8
@@ -1351,7 +1355,7 @@ struct WgradBMS {
     static constexpr bool POST = true;
     typedef WgradBMSSt<TPT> St;
     const float* x;      // already offset to the first channel of the CPT-channel sub-range
-    int Ctot, H, W, OH, OW, stride, pad;
+    int Ctot, H, W, OH, OW, stride, pad, P;
     __device__ __forceinline__ void init(St& st, int n_first, int) const {
         const int n0 = __builtin_amdgcn_readfirstlane(n_first - (int)(threadIdx.x >> 5));
         st.tap0 = n0 / CPT;
@@ -1363,8 +1367,9 @@ struct WgradBMS {
     __device__ __forceinline__ void fix(St& st, int p) const {
         const int ohw = OH * OW;
         const int p0 = __builtin_amdgcn_readfirstlane(p & ~31);
-        const int img = p0 / ohw;                       // uniform
-        const int pix = p - img * ohw;
+        const int img = p0 / P;                         // uniform
+        const int pr = p - img * P;
+        const int pix = min(pr, ohw - 1);
         const int oy = pix / OW, ox = pix - oy * OW;
         const int by = oy * stride - pad, bx = ox * stride - pad;
         unsigned ok = 0;
@@ -1374,6 +1379,7 @@ struct WgradBMS {
             const int dy = tap / KH, dx = tap - dy * KH;
             int iy = by + dy, ix = bx + dx;
             if (REFLECT) {
+                ok |= 1u << s;
                 iy = jp_reflect(iy, H);
                 ix = jp_reflect(ix, W);
             } else {
@@ -1383,7 +1389,7 @@ struct WgradBMS {
             }
             st.voff[s] = (unsigned)(((threadIdx.x >> 5) * H + iy) * W + ix) * 4u;
         }
-        st.ok = ok;
+        st.ok = pr < ohw ? ok : 0u;                     // per-image K padding
         st.base = x + (size_t)img * Ctot * H * W;
     }
     __device__ __forceinline__ float get_u(const St& st, int, int r) const {
@@ -1391,9 +1397,9 @@ struct WgradBMS {
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + st.voff[(8 * r) / CPT]);
     }
     static constexpr bool ALL_OK = true;
-    __device__ __forceinline__ bool all_ok(const St& st) const { return REFLECT || __all(st.ok == ((1u << TPT) - 1u)); }
+    __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok == ((1u << TPT) - 1u)); }
     __device__ __forceinline__ float post(const St& st, float v, int r) const {
-        return (REFLECT || ((st.ok >> ((8 * r) / CPT)) & 1u)) ? v : 0.f;
+        return ((st.ok >> ((8 * r) / CPT)) & 1u) ? v : 0.f;
     }
 };
 
@@ -1948,6 +1954,9 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     WgradA a{dy, Cout, (int)npix, OH * OW};
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
     if (!ws) ws_floats = 0;
+    // scalar-base loaders: K = (image, pixel padded to a multiple of 32) so a K chunk never straddles two images
+    const int Ppad = pad32(OH * OW);
+    const long kext = (long)N * Ppad;
     auto plan = [&](int Np, int* splits, int* kps, int per_cu = 2) {   // atomic-epilogue paths
         const bool narrow = Cout <= 64;
         const WgradPlan p = wgrad_plan(Cout, Np, npix, narrow ? 64 : 128, narrow ? 256 : 128, per_cu, 0);
@@ -1957,10 +1966,10 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     // scalar-base paths: scratch-reduced split-K when the caller provided scratch and the plan prefers it
     auto go = [&](auto wm, auto wn, auto a_, auto b_, const WgradEpiT& e, int Np) {
         constexpr int WM = decltype(wm)::value, WN = decltype(wn)::value;
-        const WgradPlan p = wgrad_plan(Cout, Np, npix, 64 * WM, 64 * WN, 3, ws_floats);
+        const WgradPlan p = wgrad_plan(Cout, Np, kext, 64 * WM, 64 * WN, 3, ws_floats);
         if (p.use_ws) {
             WgradEpiWS ew{ws, Cout, Np};
-            launch<true, WM, WN>(a_, b_, ew, Cout, Np, (int)npix, p.splits, p.kps, st);
+            launch<true, WM, WN>(a_, b_, ew, Cout, Np, (int)kext, p.splits, p.kps, st);
             const long total = (long)Cout * Np;
             if (p.splits >= 32 && total <= (1L << 16))
                 hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((int)((total + 63) / 64)), dim3(1024), 0, st, ws, dw, Cout,
@@ -1969,7 +1978,7 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
                 hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st,
                                    ws, dw, Cout, Np, p.splits, e.Cp, e.Cin, e.KHW, e.c_off, e.Ctot);
         } else {
-            launch<true, WM, WN>(a_, b_, e, Cout, Np, (int)npix, p.splits, p.kps, st);
+            launch<true, WM, WN>(a_, b_, e, Cout, Np, (int)kext, p.splits, p.kps, st);
         }
     };
     using I1 = std::integral_constant<int, 1>;
@@ -2006,16 +2015,16 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         const int Cm = Cin / 128 * 128, tail = Cin - Cm;
         const int Np = KH * KH * Cm;
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cm) + 1u;
-        const bool scalar_ok = (OH * OW) % 32 == 0 && Cout % 8 == 0 && (long)8 * H * W * 4 < (1L << 31);
+        const bool scalar_ok = Cout % 8 == 0 && (long)8 * H * W * 4 < (1L << 31);
         WgradEpiT e{dw, Cm, Cm, KH * KH, dw_coff, dw_ctot, magic};
         if (scalar_ok) {   // scalar-base loaders
-            WgradAS as{dy, Cout, (int)npix, OH * OW};
+            WgradAS as{dy, Cout, (int)kext, OH * OW, Ppad};
             JP_KH_SWITCH(KH, {
                 if (pad_mode == JP_PAD_REFLECT) {
-                    WgradBUS<KH_, true> b{x0, Cm, Cin, H, W, OH, OW, stride, pad};
+                    WgradBUS<KH_, true> b{x0, Cm, Cin, H, W, OH, OW, stride, pad, Ppad};
                     go(I2{}, I2{}, as, b, e, Np);
                 } else {
-                    WgradBUS<KH_, false> b{x0, Cm, Cin, H, W, OH, OW, stride, pad};
+                    WgradBUS<KH_, false> b{x0, Cm, Cin, H, W, OH, OW, stride, pad, Ppad};
                     go(I2{}, I2{}, as, b, e, Np);
                 }
             });
@@ -2030,16 +2039,16 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
             const int rc = run_table(Cm, tail);
             if (rc) return rc;
         }
-    } else if (single && (Cin == 64 || ((Cin == 16 || Cin == 32) && Cout <= 64)) && (OH * OW) % 32 == 0 && Cout % 8 == 0 &&
+    } else if (single && (Cin == 64 || ((Cin == 16 || Cin == 32) && Cout <= 64)) && Cout % 8 == 0 &&
                (long)8 * H * W * 4 < (1L << 31)) {
         // 16 / 32 / 64 input channels (ResNet stem + layer1, BEV decoder): whole taps per N tile, scalar-base loaders
         const int Np = KH * KH * Cin;
         const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cin) + 1u;
         WgradEpiT e{dw, Cin, Cin, KH * KH, dw_coff, dw_ctot, magic};
-        WgradAS as{dy, Cout, (int)npix, OH * OW};
+        WgradAS as{dy, Cout, (int)kext, OH * OW, Ppad};
 #define JP_BMS(REFL, WMv, WNv, TPTv, CPTv)                                              \
     {                                                                                   \
-        WgradBMS<KH_, REFL, TPTv, CPTv> b{x0, Cin, H, W, OH, OW, stride, pad};          \
+        WgradBMS<KH_, REFL, TPTv, CPTv> b{x0, Cin, H, W, OH, OW, stride, pad, Ppad};    \
         go(std::integral_constant<int, WMv>{}, std::integral_constant<int, WNv>{}, as, b, e, Np); \
     }
         JP_KH_SWITCH(KH, {
@@ -2170,9 +2179,9 @@ extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
 extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW, cap = 32L << 20;
-    if ((OH * OW) % 32 != 0 || Cout % 8 != 0 || Cin < 16) return 0;
+    if (Cout % 8 != 0 || Cin < 16) return 0;
     const int Np = KH * KH * (Cin >= 64 ? Cin / 64 * 64 : Cin);
     const bool narrow = Cout <= 64 && Cin <= 64;
-    const WgradPlan p = wgrad_plan(Cout, Np, npix, narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
+    const WgradPlan p = wgrad_plan(Cout, Np, (long)N * pad32(OH * OW), narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
     return p.use_ws ? p.ws_need : 0;
 }
