@@ -142,14 +142,16 @@ __global__ void bias_act_nchw_kernel(float* __restrict__ y, const float* __restr
 
 // deterministic small-grid split-K: y[img][m][pix] = act(bias[m] + sum_s part[s][m][n]) in a fixed order
 __global__ void slice_reduce_nchw_kernel(const float* __restrict__ part, float* __restrict__ y,
-                                         const float* __restrict__ bias, int M, int Npix, int HW, int splits, int act) {
+                                         const float* __restrict__ bias, int M, int Npix, int HW, int splits, int act,
+                                         int accumulate) {
     const long total = (long)M * Npix;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / Npix), n = (int)(i - (long)m * Npix);
         float s = bias ? bias[m] : 0.f;
         for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + i];
         const int img = n / HW;
-        y[((size_t)img * M + m) * HW + (n - img * HW)] = jp_act(s, act);
+        float* q = y + ((size_t)img * M + m) * HW + (n - img * HW);
+        *q = accumulate ? *q + jp_act(s, act) : jp_act(s, act);
     }
 }
 
@@ -1696,7 +1698,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                 });
                 const long total = npix * Cout;
                 hipLaunchKernelGGL(slice_reduce_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0,
-                                   st, split_ws, y, bias, Cout, (int)npix, OH * OW, jp_cdiv(Kp, kps), act);
+                                   st, split_ws, y, bias, Cout, (int)npix, OH * OW, jp_cdiv(Kp, kps), act, 0);
                 JP_LAUNCH_CHECK();
             }
             JP_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)npix * Cout, st));
@@ -1744,6 +1746,18 @@ extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, 
                               pad_mode, act, ws, split_ws, stream);
 }
 
+// same for jp_conv2d_dgrad's `split_ws`
+extern "C" long jp_conv2d_dgrad_split_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
+    if (Cout < 16) return 0;
+    const long npix = (long)N * H * W;
+    const int Kp = KH * KH * pad32(Cout);
+    if (KH == 3 && stride == 2) return 0;          // parity-class path, no split
+    const int sp = small_grid_splits(Cin, npix, Kp);
+    if (sp <= 1) return 0;
+    const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
+    return (long)jp_cdiv(Kp, kps) * Cin * npix;
+}
+
 // floats of optional caller scratch (`split_ws`) for the split-K forward of layers whose tile grid cannot fill the
 // chip: with it the K slices are reduced in a fixed order (bit-reproducible); without it they meet in atomics.
 extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
@@ -1758,7 +1772,8 @@ extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cou
 }
 
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
-                               int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, void* stream) {
+                               int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, float* split_ws,
+                               void* stream) {
     JP_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && !(KH == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2)),
                  "conv2d_dgrad: reflect mode supports 3x3 stride 1 pad 1 only");
@@ -1782,7 +1797,17 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             launch_auto(a2, b2, e2, Cin, (int)npix, 4 * Cp, 1, 4 * Cp, st);
             JP_LAUNCH_CHECK();
         }
-        if (sp > 1) {
+        if (sp > 1 && split_ws) {   // small grids: K slices to scratch, fixed-order reduction (no memset, no atomics)
+            const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
+            WgradEpiWS es{split_ws, Cin, (int)npix};
+            JP_KH_SWITCH(KH, {
+                DgradBT<KH_> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
+                launch_auto(a, b, es, Cin, (int)npix, Kp, jp_cdiv(Kp, kps), kps, st);
+            });
+            const long total = npix * Cin;
+            hipLaunchKernelGGL(slice_reduce_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st,
+                               split_ws, dx, (const float*)nullptr, Cin, (int)npix, H * W, jp_cdiv(Kp, kps), JP_ACT_NONE, accumulate);
+        } else if (sp > 1) {
             const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
             if (!accumulate) JP_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)npix * Cin, st));
             AtomicEpi ea{dx, Cin, H * W};

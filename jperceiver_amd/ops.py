@@ -188,7 +188,10 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             ws_d = _new((_ws_floats(Cin, Cout, KH, 1),), w.t) if Cout >= 16 else None
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()
-                call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc, ws_d)
+                nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
+                ws_s = _new((nsd,), dy) if nsd else None
+                call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc, ws_d, ws_s)
+                del ws_s
             elif int(_jplib().fn["jp_conv2d_dgrad_src3_ok"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout, KH,
                                                            stride, pad, pad_mode)):
                 # per-source dgrad inside the library: straight into each source's gradient buffer, the upsampled
@@ -203,7 +206,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 call("jp_conv2d_dgrad_src3", dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode, ws_d)
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
-                call("jp_conv2d_dgrad", dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0, ws_d)
+                call("jp_conv2d_dgrad", dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0, ws_d, None)
                 c0 = 0
                 for v, u in srcs:
                     C = v.t.shape[1]

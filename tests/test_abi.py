@@ -26,7 +26,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
     rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, None, None)
     assert rc == -1 and "null" in L.last_error()
-    rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, None)
+    rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, None, None)
     assert rc == -1
 
 
