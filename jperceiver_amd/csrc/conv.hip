@@ -476,6 +476,66 @@ struct DgradBT {  // B[k=(tap,co)][n=input pixel]
     __device__ __forceinline__ float post(const St& st, float v, int) const { return st.ok ? v : 0.f; }
 };
 
+// ---- B loader of the row-tile kernel (igemm.h jp_igemm_r3_kernel): 3x3 stride 1 pad 1, the pixel tile is BN consecutive
+// pixels of ONE image row.  REV = dgrad (row y+1-ty of dY, taps mirrored, zero fill -- the reflection fold is the border
+// pass's job); otherwise forward with reflection or zero padding.  Sources must be stored at full resolution.
+struct FwdBR3St {
+    int img, y, x0;          // uniform: the tile's image, row, first column
+    const float* rowp;       // uniform: (segment, image, first channel of the chunk, source row, x0)
+    int hw, nm1, rowok;      // uniform
+};
+template <bool REFLECT, bool REV, int BN>
+struct FwdBR3 {
+    static constexpr bool REVERSE = REV;
+    typedef FwdBR3St St;
+    Src3 src;
+    int H, W;
+    __device__ __forceinline__ void init(St& st, int n0) const {
+        const int hw = H * W;
+        st.img = n0 / hw;
+        const int rem = n0 - st.img * hw;
+        st.y = rem / W;
+        st.x0 = rem - st.y * W;
+        st.rowp = src.p0;
+        st.hw = hw;
+        st.nm1 = 0;
+        st.rowok = 0;
+    }
+    __device__ __forceinline__ void row(St& st, int kc) const {
+        const int q = kc >> 5;
+        const int cc = q / 9, tap = q - cc * 9;
+        const int dy = tap / 3;
+        int iy = REV ? st.y + 1 - dy : st.y - 1 + dy;
+        if (REFLECT) {
+            iy = jp_reflect(iy, H);
+            st.rowok = 1;
+        } else {
+            st.rowok = (unsigned)iy < (unsigned)H;
+            iy = min(max(iy, 0), H - 1);
+        }
+        const int ci0 = cc << 5;
+        const bool a = ci0 < src.e0, b = ci0 < src.e1;
+        const float* p = a ? src.p0 : (b ? src.p1 : src.p2);
+        const int c0 = a ? 0 : (b ? src.e0 : src.e1);
+        const int ce = a ? src.e0 : (b ? src.e1 : src.e2);
+        st.rowp = p + ((size_t)(st.img * (ce - c0) + (ci0 - c0)) * H + iy) * W + st.x0;
+        st.nm1 = min(32, ce - ci0) - 1;
+    }
+    __device__ __forceinline__ float get(const St& st, int kl, int n_l) const {    // kl wave-uniform, n_l = lane's column
+        const float* rp = st.rowp + (size_t)min(kl, st.nm1) * st.hw;
+        const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + (unsigned)n_l * 4u);
+        return st.rowok ? v : 0.f;
+    }
+    __device__ __forceinline__ float halo(const St& st, int kl, int side) const {   // column x0-1 / x0+BN
+        int x = side ? st.x0 + BN : st.x0 - 1;
+        bool ok = st.rowok;
+        if (REFLECT) x = jp_reflect(x, W);
+        else { ok = ok && (unsigned)x < (unsigned)W; x = min(max(x, 0), W - 1); }
+        const float v = st.rowp[(size_t)min(kl, st.nm1) * st.hw + (x - st.x0)];
+        return ok ? v : 0.f;
+    }
+};
+
 // ---- Few input channels (the 7x7 stride-2 ResNet stems: 3 image channels, 6 for the pose pair): K = (tap, c) with the
 // channels padded to CP = 4 or 8, so a K chunk of 32 holds 32/CP whole taps; one per-lane offset per tap per chunk,
 // every element a scalar-base load (the generic path decodes (c, dy, dx) per element).  64x256 tiles only (Cout <= 64).
@@ -1527,6 +1587,12 @@ void launch_auto(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStr
     else launch<IL, 2, 2>(a, b, e, M, N, K, splits, kps, st);
 }
 
+template <int WM, int WN, class A, class B, class E>
+void launch_r3(A a, B b, E e, int M, int N, int K, hipStream_t st) {
+    dim3 grid(N / (64 * WN), jp_cdiv(M, 64 * WM), 1);
+    hipLaunchKernelGGL((jp_igemm_r3_kernel<WM, WN, KC, A, B, E>), grid, dim3(256), 0, st, a, b, e, M, N, K);
+}
+
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
               int up2, int H, int W) {
     Src3 s;
@@ -1719,6 +1785,19 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             }
             JP_LAUNCH_CHECK();
         }
+        const bool no_up = !((c0 && up0) || (c1 && up1) || (c2 && up2));
+        const int bn3 = Cout <= 64 ? 256 : 128;
+        if (KH == 3 && stride == 1 && pad == 1 && no_up && Cin >= 32 && W % bn3 == 0 && npix > 64) {
+            // row-tile kernel: the three dx taps share one staged input row segment
+            if (pad_mode == JP_PAD_REFLECT) {
+                if (Cout <= 64) { FwdBR3<true, false, 256> b{src, H, W}; launch_r3<1, 4>(a, b, e, Cout, (int)npix, Kp, st); }
+                else { FwdBR3<true, false, 128> b{src, H, W}; launch_r3<2, 2>(a, b, e, Cout, (int)npix, Kp, st); }
+            } else {
+                if (Cout <= 64) { FwdBR3<false, false, 256> b{src, H, W}; launch_r3<1, 4>(a, b, e, Cout, (int)npix, Kp, st); }
+                else { FwdBR3<false, false, 128> b{src, H, W}; launch_r3<2, 2>(a, b, e, Cout, (int)npix, Kp, st); }
+            }
+            JP_LAUNCH_CHECK();
+        }
         JP_KH_SWITCH(KH, {
             if (pad_mode == JP_PAD_REFLECT) {
                 FwdBT<KH_, true> b{src, Cp, (int)npix, OH, OW, stride, pad};
@@ -1821,6 +1900,13 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                     DgradBT<KH_, true> b{dy, Cp, (int)npix, H, W, Cout, OH, OW, stride, pad, pad_mode == JP_PAD_REFLECT};
                     const int tail = (Cin > 128 && Cin % 128 <= 16) ? Cin % 128 : 0;
                     const int Mm = Cin - tail;
+                    const int bn3 = Mm <= 64 ? 256 : 128;
+                    if (KH == 3 && pad == 1 && Cout >= 32 && W % bn3 == 0 && npix > 64) {
+                        // row-tile kernel on dY (taps mirrored, zero fill; the reflection fold stays with the border pass)
+                        const Src3 sdy = make_src(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, H, W);
+                        if (Mm <= 64) { FwdBR3<false, true, 256> b3{sdy, H, W}; launch_r3<1, 4>(a, b3, e, Mm, (int)npix, Kp, st); }
+                        else { FwdBR3<false, true, 128> b3{sdy, H, W}; launch_r3<2, 2>(a, b3, e, Mm, (int)npix, Kp, st); }
+                    } else
                     launch_auto(a, b, e, Mm, (int)npix, Kp, 1, Kp, st);
                     if (tail) {
                         PackA at{ws + (size_t)Mm * Cp, Cin, Kp, Cp, KH * KH};
@@ -1926,7 +2012,14 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
                                   accs[sidx]);
             } else {
                 DgradEpi e{dx, C, H * W, accs[sidx]};
-                launch_auto(a, b, e, C, (int)npix, Kp, 1, Kp, st);
+                const int bn3 = C <= 64 ? 256 : 128;
+                if (W % bn3 == 0 && Cout >= 32) {     // row-tile kernel, see jp_conv2d_dgrad
+                    const Src3 sdy = make_src(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, H, W);
+                    if (C <= 64) { FwdBR3<false, true, 256> b3{sdy, H, W}; launch_r3<1, 4>(a, b3, e, C, (int)npix, Kp, st); }
+                    else { FwdBR3<false, true, 128> b3{sdy, H, W}; launch_r3<2, 2>(a, b3, e, C, (int)npix, Kp, st); }
+                } else {
+                    launch_auto(a, b, e, C, (int)npix, Kp, 1, Kp, st);
+                }
             }
             const int Nb = N * (2 * W + 2 * H);
             DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};

@@ -289,3 +289,117 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-tile variant for 3x3 stride-1 pad-1 convolutions whose pixel tile is one segment of an image row (W % BN == 0):
+// K order (channel chunk, dy, dx, c), and the three dx taps of one (chunk, dy) read the SAME input row segment shifted
+// by one pixel.  The segment (+ one halo pixel on each side) is staged in LDS once per (chunk, dy) and the MFMA B
+// fragments of tap dx are read at column offset dx (forward) / 2 - dx (dgrad): a third of the B gathers and B LDS
+// stores of the generic kernel, all of them aligned, with wave-uniform row pointers and a per-lane offset that is
+// constant for the whole kernel.
+// BLoad protocol:  init(st, n0) | row(st, kc) per (chunk, dy) | get(st, kl) centre element of k row kl |
+//                  halo(st, kl, side) column -1 / BN of k row kl | REVERSE: tap dx reads column offset 2 - dx
+template <int WM, int WN, int KC, class ALoad, class BLoad, class Epi>
+__global__ __launch_bounds__(64 * WM * WN) void jp_igemm_r3_kernel(ALoad al, BLoad bl, Epi epi, int M, int N, int K) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(ALoad::ALONG_K && jp_has_split<ALoad>::value, "A: packed weights, scalar-base");
+    constexpr int NT = 256, BM = 64 * WM, BN = 64 * WN;
+    constexpr int LDA = BM + 1, LDB = BN + 3;            // B rows: [halo | BN pixels | halo], odd stride
+    constexpr int NA = BM * KC / NT, NB = BN * KC / NT;
+    constexpr int A_ROWS = NT / KC, B_ROWS = NT / BN;
+    __shared__ float As[KC * LDA];
+    __shared__ float Bs[KC * LDB];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    {   // XCD band order, see jp_igemm_kernel
+        const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
+        const int L = blockIdx.x + blockIdx.y * gx;
+        if (L < G * gy) {
+            const int j = L >> 3;
+            mt = j % gy;
+            nt = (L & 7) * (G >> 3) + j / gy;
+        } else {
+            const int i = L - G * gy;
+            mt = i % gy;
+            nt = G + i / gy;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int a_fix_l = t % KC, a_var_l = t / KC;
+    const int b_fix_l = t % BN, b_var_l = __builtin_amdgcn_readfirstlane(t / BN);
+    typename ALoad::St sa;
+    typename BLoad::St sb;
+    al.init(sa, m0 + a_var_l, A_ROWS);
+    bl.init(sb, n0);
+    float ra[NA], rb[NB], rh = 0.f;
+    auto gload = [&](int kc) {
+        al.fix(sa, kc + a_fix_l);
+#pragma unroll
+        for (int r = 0; r < NA; ++r) ra[r] = al.get_u(sa, m0 + A_ROWS * r, r);
+        if ((kc / KC) % 3 == 0) {      // first dx tap of a (chunk, dy): fetch the row segment
+            bl.row(sb, kc);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) rb[r] = bl.get(sb, b_var_l + B_ROWS * r, b_fix_l);
+            if (wave == 0) rh = bl.halo(sb, lane >> 1, lane & 1);
+        }
+    };
+    auto lstore = [&](int kc) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) As[a_fix_l * LDA + a_var_l + A_ROWS * r] = ra[r];
+        if ((kc / KC) % 3 == 0) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) Bs[(b_var_l + B_ROWS * r) * LDB + 1 + b_fix_l] = rb[r];
+            if (wave == 0) Bs[(lane >> 1) * LDB + ((lane & 1) ? BN + 1 : 0)] = rh;
+        }
+    };
+    jp_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const float* ap = As + lhi * LDA + wm * 64 + l31;
+    const float* bp = Bs + lhi * LDB + wn * 64 + l31;
+    gload(0);
+    for (int kc = 0; kc < K; kc += KC) {
+        lstore(kc);
+        __syncthreads();
+        if (kc + KC < K) gload(kc + KC);
+        const int dx = (kc / KC) % 3;
+        const float* bq = bp + (BLoad::REVERSE ? 2 - dx : dx);
+        float a0 = ap[0], a1 = ap[32], b0 = bq[0], b1 = bq[32];
+#pragma unroll 4
+        for (int kk = 0; kk < KC; kk += 2) {
+            const int kn = kk + 2 < KC ? kk + 2 : kk;
+            const float na0 = ap[kn * LDA], na1 = ap[kn * LDA + 32];
+            const float nb0 = bq[kn * LDB], nb1 = bq[kn * LDB + 32];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= N) continue;
+        const typename Epi::St se = epi.col(n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < M) epi.put(se, m, acc[i][j][r]);
+            }
+        }
+    }
+}

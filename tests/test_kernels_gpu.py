@@ -67,6 +67,9 @@ CONV_CASES = [
     (2, 32, 16, 24, 32, 3, 1, 1, 0, 0, False),      # 32->32
     (2, 32, 16, 24, 16, 3, 1, 1, 1, 0, True),       # 32->16 reflect
     (2, 16, 9, 11, 24, 3, 1, 1, 0, 0, False),       # 16 channels, odd map (table wgrad)
+    (1, 64, 8, 256, 64, 3, 1, 1, 0, 0, False),      # row-tile kernel (W % 256 == 0, Cout <= 64), zero pad
+    (2, 96, 6, 128, 160, 3, 1, 1, 1, 2, True),      # row-tile kernel, 128-wide tiles, reflect + bias + leaky
+    (2, 72, 5, 128, 72, 3, 1, 1, 0, 1, True),       # row-tile kernel, channel tail chunk, zero pad
     (1, 3, 448, 448, 64, 7, 2, 3, 0, 0, False),     # stem at a size that takes the whole-tap K-chunk path (CP = 4)
     (1, 6, 448, 452, 64, 7, 2, 3, 0, 1, True),      # pose stem (CP = 8), ragged width
 ]
@@ -106,6 +109,7 @@ def test_conv2d_fwd_bwd(case):
     (3, 128, 128, 32, 96, 40),    # ... 64x256 tile, 3 channel chunks in the upsampled segment
     (2, 32, 64, 32, 128, 72),     # per-segment wgrad: parity-class kernels on the upsampled segment (Cx % 128 == 0)
     (1, 64, 128, 128, 128, 136),  # ... + uniform-tap path on the reduce segment, two M tiles
+    (1, 192, 256, 128, 64, 136),  # per-source dgrad with the row-tile kernel on the full-resolution segment (W % 128 == 0)
 ])
 def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
     """iconv_k(cat(reduce, up(x), disp)) and its three input gradients (depth_decoder.py:76-77)."""

@@ -25,6 +25,13 @@ __global__ __launch_bounds__(256) void kg(float* out, const float* __restrict__ 
             for (int r = 0; r < 4; ++r) ra4[r] = reinterpret_cast<const float4*>(q)[r * 256 + t];
 #pragma unroll
             for (int r = 0; r < 16; ++r) rb[r] = q[4096 + r * 256 + t];
+        } else if (MODE == 8) {   // B row tile shared by the 3 dx taps: B is gathered on every third chunk only
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ra[r] = q[r * 256 + t];
+            if (it % 3 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rb[r] = q[4096 + r * 256 + t];
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ra[r] = q[r * 256 + t]; rb[r] = q[4096 + r * 256 + t]; }
@@ -37,6 +44,13 @@ __global__ __launch_bounds__(256) void kg(float* out, const float* __restrict__ 
             for (int r = 0; r < 4; ++r) reinterpret_cast<float4*>(As)[r * 256 + t] = ra4[r];
 #pragma unroll
             for (int r = 0; r < 16; ++r) Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = rb[r];
+        } else if (MODE == 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) As[(r * 2 + (t >> 7)) * 129 + (t & 127)] = ra[r];
+            if (it % 3 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = rb[r];
+            }
         } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { As[(r * 2 + (t >> 7)) * 129 + (t & 127)] = ra[r]; Bs[(r * 2 + (t >> 7)) * 129 + (t & 127)] = rb[r]; }
@@ -206,6 +220,7 @@ int main() {
         rung<5>("igemm loop, L1/L2-hot source", 256 * bpc, 1000, out, src, span);
         rung<4>("igemm loop, streaming source", 256 * bpc, 1000, out, src, span);
         rung<7>("igemm loop hot, A as 4x dwordx4+b128", 256 * bpc, 1000, out, src, span);
+        rung<8>("igemm loop hot, B every 3rd chunk", 256 * bpc, 999, out, src, span);
     }
     for (int bpc = 1; bpc <= 2; ++bpc) {
         runl<1>("lds-direct loop, hot source", 256 * bpc, 1000, out, src, span);
