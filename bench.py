@@ -207,7 +207,8 @@ def measure_roofline(runner, batch, _lib):
         Cin = c0 + c1 + c2
         alg_bytes = 4.0 * (N * Cin * H * W + N * Cout * OH * OW + Cout * Cin * KH * KH)   # read x once, write y once, read w
         fused_up = (c0 and a[2]) or (c1 and a[5]) or (c2 and a[8])   # iconv layers run the parity-class kernel instead
-        rec.append((KH if (a[19] == 1 and not fused_up) else -KH, Cout, N * OH * OW, 2.0 * N * OH * OW * Cout * Cin * KH * KH, e0, e1, alg_bytes))
+        row_tile = stride == 1 and W % 128 == 0       # runs jp_igemm_r3_kernel (the pixel tile is one image-row segment)
+        rec.append((KH if (a[19] == 1 and not fused_up and row_tile) else -KH, Cout, N * OH * OW, 2.0 * N * OH * OW * Cout * Cin * KH * KH, e0, e1, alg_bytes))
     from jperceiver_amd import ops
     ops.call = timed_call
     try:
@@ -215,7 +216,7 @@ def measure_roofline(runner, batch, _lib):
         torch.cuda.synchronize()
     finally:
         ops.call = orig
-    # dominant kernel = ONE instantiation: 3x3, reflection padding, 128x128 block tile (Cout > 64), direct epilogue
+    # dominant kernel = ONE instantiation: 3x3, reflection padding, 128x128 block tile (Cout > 64), row-tile kernel, direct epilogue
     # (>= 192 tiles, i.e. no small-grid split-K)
     dom = [(f, e0.elapsed_time(e1), ab) for KH, Cout, npix, f, e0, e1, ab in rec
            if KH == 3 and Cout > 64 and npix > 64 and ((Cout + 127) // 128) * ((npix + 127) // 128) >= 192]
@@ -232,7 +233,7 @@ def measure_roofline(runner, batch, _lib):
     except Exception:
         pass
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-            "traffic": traffic, "algorithmic_bytes_per_launch": round(sum(ab for _, _, ab in dom) / max(1, len(dom))), "kernel": "jp_igemm_kernel<2,2,32,PackA,FwdBT<3,true>,FwdEpi> (3x3 reflection-pad conv forward, Cout>64; the event pair also spans the ~6 us weight-pack launch)",
+            "traffic": traffic, "algorithmic_bytes_per_launch": round(sum(ab for _, _, ab in dom) / max(1, len(dom))), "kernel": "jp_igemm_r3_kernel<2,2,32,PackA,FwdBR3<true,false,128>,FwdEpi> (3x3 reflection-pad conv forward, Cout>64, row-tile variant; the event pair also spans the ~6 us weight-pack launch)",
             "launches": len(dom), "avg_launch_ms": round(ms / max(1, len(dom)), 4),
             "avg_launch_gflop": round(flops / max(1, len(dom)) / 1e9, 2)}
 

@@ -29,7 +29,7 @@ def main(fetch_db, write_db, out_json):
     known = 4.0 * n
     kf = known / (sum(v for v, _ in cf) / len(cf) * 1024.0)
     kw = known / (sum(v for v, _ in cw) / len(cw) * 1024.0)
-    dom = [k for k in F if re.search(r"jp_igemm_kernel<2, 2, 32.*PackA.*FwdBT<3, true>.*FwdEpi", k)]
+    dom = [k for k in F if re.search(r"jp_igemm_r3_kernel<2, 2, 32.*PackA.*FwdBR3<true, false, 128>.*FwdEpi", k)]
     assert len(dom) == 1, dom
     fv = [v for v, _ in F[dom[0]]]
     wv = [v for v, _ in W[dom[0]]]
