@@ -129,21 +129,26 @@ __global__ __launch_bounds__(TPB) void maxpool_fwd_t_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0; }
     const float* base = tile + (q * 4 * S) * PW + tx * S;
     constexpr int R = 3 * S + K;
+    // separable with the scan-order tie rule kept: per staged row the first maximum over kx (once, shared by the up
+    // to K/S windows that contain the row), then per window the first maximum over ky of those row results
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        float v[K];
+        float rv = base[r * PW];
+        int rk = 0;
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) v[kx] = base[r * PW + kx];
+        for (int kx = 1; kx < K; ++kx) {
+            const float v = base[r * PW + kx];
+            const bool take = v > rv || v != v;     // PyTorch's rule: first maximum, a NaN always takes over
+            rv = take ? v : rv;
+            rk = take ? kx : rk;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ky = r - j * S;
             if (ky < 0 || ky >= K) continue;
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const bool take = v[kx] > best[j] || v[kx] != v[kx];
-                best[j] = take ? v[kx] : best[j];
-                bi[j] = take ? ky * K + kx : bi[j];
-            }
+            const bool take = ky == 0 || rv > best[j] || rv != rv;
+            best[j] = take ? rv : best[j];
+            bi[j] = take ? ky * K + rk : bi[j];
         }
     }
     const int ox = ox0 + tx;
