@@ -9,14 +9,19 @@
 //             padding, stride, and optional fused nearest-2x-upsample + channel-concat sources)
 //   dgrad   : M = Cin,   N = batch*H*W  pixels,   K = taps*Cout   (B gathers dY; the adjoint of
 //             reflection padding is folded into the gather, no workspace)
-//   wgrad   : M = Cout,  N = taps*Cin,            K = batch*OH*OW (split-K, fp32 atomics)
+//   wgrad   : M = Cout,  N = taps*Cin,            K = batch*OH*OW (split-K; partial tiles reduced
+//             through caller scratch, or fp32 atomics without it)
 //
-// Two loader families.  "T" (tap-major, the fast path): K is ordered (tap, channel) with the channel
-// count padded to a multiple of 32 = the K-chunk, so the filter tap, the bounds/reflection logic and
-// the source pointer are computed ONCE per chunk per thread and each gathered element costs one
-// strided load; weights are re-packed to [tap][row][channel_padded] (a 1-2 MB, L2-resident buffer) so
-// their loads are coalesced.  "G" (generic, K ordered (channel, tap)): any channel count, used when
-// the reduction channels are few (stems with 3/6 inputs, dgrad of the 1/2/6/16-channel heads).
+// Loader families (DESIGN.md §4.1 has the measurements behind each):
+//   "T"  tap-major fast path: K ordered (channel chunk of 32, tap, channel); tap decode, bounds / reflection and source
+//        selection once per chunk; scalar-base addressing (wave-uniform 64-bit base + per-lane 32-bit offset); weights
+//        re-packed per launch to [tap][row][channel_pad32] (L2-resident) so the A loads are coalesced.
+//   "R3" row-tile kernel for 3x3 stride-1 layers whose pixel tile is one image-row segment: the three dx taps share one
+//        staged row segment (forward and dgrad main pass).
+//   "P"  parity-class kernels for inputs read through the fused nearest-2x upsample (iconv layers, disparity heads):
+//        4 pre-summed weight slots per output parity instead of 9 taps, in forward, dgrad and wgrad.
+//   "S2" parity-class dgrad of the 3x3 stride-2 convs; "C" whole-tap K chunks for the 3/6-channel stems.
+//   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
 #include "igemm.h"
 #include <algorithm>
 #include <cstdlib>
