@@ -96,6 +96,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > torch.cuda.device_count():
+        # several ranks time-slicing one GPU (only the 1-GPU gloo smoke test of the N>1 code path does this): the pose
+        # branch's side stream turns into cross-process queue ping-pong there, so keep the step single-stream
+        os.environ["JP_POSE_STREAM"] = "0"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local % torch.cuda.device_count())

@@ -16,6 +16,8 @@ same `outputs` / `loss_dict` keys.  Differences that are deliberate (SURVEY.md Â
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -60,6 +62,9 @@ class _StepFn(torch.autograd.Function):
         dvec = dvec.contiguous()
         call("jp_axpby", dvec, None, ctx.lv.grads, dvec.numel(), 1.0, 0.0)
         ctx.tape.backward()
+        side = getattr(ctx.tape, "side_stream", None)
+        if side is not None:       # the pose branch's backward ran on its own stream: rejoin before the optimizer
+            torch.cuda.current_stream().wait_stream(side)
         return None, None, None
 
 
@@ -82,6 +87,9 @@ def _broadcast_scalar(s, out):
     """out[i] = s[0] (device scalar broadcast without a host sync): out = 0; out += bias(s) per row."""
     call("jp_fill", out, out.numel(), 0.0)
     call("jp_bias_act_rows", out, s, out.numel(), 1, 0)
+
+
+_POSE_STREAM = os.environ.get("JP_POSE_STREAM", "1") != "0"
 
 
 @MONO.register_module
@@ -126,6 +134,12 @@ class Baseline(nn.Module):
             self._hook = torch.zeros(1, device=dev, requires_grad=True)
         vec = _StepFn.apply(self._hook, tape, lv)
         return outputs, LossDict({n: vec[i] for i, n in enumerate(lv.names)}, lv, vec)
+
+    def _pose_stream(self):
+        st = getattr(self, "_side_stream", None)
+        if st is None:
+            st = self._side_stream = torch.cuda.Stream()
+        return st
 
     def _layout_head(self, sfx, F, f4, n_updates):
         cvp = getattr(self, "CycledViewProjection" + sfx)
@@ -179,6 +193,34 @@ class Baseline(nn.Module):
         dev = inputs[("color_aug", 0, 0)].device
         lv = ops_loss.LossVec(names, dev)
 
+        # ---- poses (net.py:630-642).  The pose branch (3 resizes, 2 x PoseEncoder + PoseDecoder on 192x640 maps) only
+        # meets the rest of the step in the photometric losses, and its kernels are far too small to fill the chip:
+        # it runs on a second HIP stream, forward and backward, underneath the depth / layout branches.
+        K, invK = inputs[("K", 0)], inputs[("inv_K", 0)]
+        main = torch.cuda.current_stream()
+        outer = ops.current_tape()
+        side = self._pose_stream() if (_POSE_STREAM and outer is not None) else None
+        pose_tape = ops.Tape() if side is not None else None
+        poses, pose_out = [], {}
+
+        def pose_branch():
+            pf = {f: ops.bilinear_resize(Var(inputs[("color_aug", f, 0)]), 192, 640) for f in o.frame_ids}
+            for f in src_frames:
+                pair = [pf[f], pf[0]] if f < 0 else [pf[0], pf[f]]
+                pfe = self.PoseEncoder._fwd(ops.cat_channels(pair))
+                at = self.PoseDecoder._fwd(pfe)                            # (B,6)
+                aa, tr = _split6(at)
+                pp = ops_loss.pose(aa, tr, K, invert=(f < 0))
+                poses.append(pp)
+                pose_out[("cam_T_cam", 0, f)] = pp.T
+                pose_out[("axisangle", 0, f)] = aa.t.view(B, 1, 1, 3)
+                pose_out[("translation", 0, f)] = tr.t.view(B, 1, 1, 3)
+
+        if side is not None:
+            side.wait_stream(main)                      # inputs (and last step's parameter update) are visible
+            with torch.cuda.stream(side), ops.recording(pose_tape):
+                pose_branch()
+
         # ---- networks
         img = Var(inputs[("color_aug", 0, 0)])
         feats = self.DepthEncoder._fwd(img)
@@ -198,20 +240,27 @@ class Baseline(nn.Module):
             self._publish_head(outputs, sfx, tag, h)
         outputs["origin_features"] = F.t
 
-        # ---- poses (net.py:630-642)
-        pf = {f: ops.bilinear_resize(Var(inputs[("color_aug", f, 0)]), 192, 640) for f in o.frame_ids}
-        K, invK = inputs[("K", 0)], inputs[("inv_K", 0)]
-        poses = []
-        for f in src_frames:
-            pair = [pf[f], pf[0]] if f < 0 else [pf[0], pf[f]]
-            pfe = self.PoseEncoder._fwd(ops.cat_channels(pair))
-            at = self.PoseDecoder._fwd(pfe)                            # (B,6)
-            aa, tr = _split6(at)
-            pp = ops_loss.pose(aa, tr, K, invert=(f < 0))
-            poses.append(pp)
-            outputs[("cam_T_cam", 0, f)] = pp.T
-            outputs[("axisangle", 0, f)] = aa.t.view(B, 1, 1, 3)
-            outputs[("translation", 0, f)] = tr.t.view(B, 1, 1, 3)
+        if side is None:
+            pose_branch()
+        else:
+            # join: the losses below read the poses on the main stream; the branch's backward is ONE node of the main
+            # tape, placed here so that it is replayed right after the loss nodes -- on the side stream again
+            main.wait_stream(side)
+            for pp in poses:
+                for t in (pp.T, pp.P, pp.dP):
+                    if t is not None:
+                        t.record_stream(main)
+            for t in pose_out.values():
+                t.record_stream(main)
+
+            def pose_bwd():
+                side.wait_stream(torch.cuda.current_stream())       # dP accumulated by the loss nodes
+                with torch.cuda.stream(side):
+                    pose_tape.backward()
+
+            outer.record(pose_bwd)
+            outer.side_stream = side
+        outputs.update(pose_out)
 
         # ---- layout losses (net.py:107-138 with root-net.py conditionals)
         lw = o.get("loss_weightS", o["loss_weight"])
