@@ -224,27 +224,77 @@ class Baseline(nn.Module):
         # ---- networks
         img = Var(inputs[("color_aug", 0, 0)])
         feats = self.DepthEncoder._fwd(img)
+        F = self.LayoutEncoder._fwd(img, n_updates=2)                 # net.py:73-74 runs this branch twice (N4)
+        outputs = {"origin_features": F.t}
+
+        lw = o.get("loss_weightS", o["loss_weight"])
+        l2w = o.get("loss2_weightS", o["loss2_weight"])
+        lsum = o["loss_sum"]
+        use_ce = 0.0 if lsum in (1, 2) else 1.0
+        use_bd = 0.0 if lsum == 1 else 1.0
+
+        def layout_heads(Fv, f4):
+            """CVP / CCT / BEV decoders of both heads + the layout losses (net.py:107-138 with root-net.py conditionals):
+            small maps (32x32 ... 256x256 x 16 channels), dozens of launches that cannot fill the chip."""
+            heads = {}
+            # the S head is always evaluated (and BN-updated twice) by the reference; B once
+            for sfx, tag, nup in (("", "road", 2), ("B", "car", 1)):
+                h = self._layout_head(sfx, Fv, f4, nup)
+                heads[sfx] = h
+                outputs["topview" + sfx] = h["top"].t
+                outputs["transform_topview" + sfx] = h["ttop"].t
+                self._publish_head(outputs, sfx, tag, h)
+            for sfx, lab_key, cw, a_, b2, on in (("", ("bothS", 0, 0), o.static_weight, lw, l2w, do_S),
+                                                 ("B", ("bothD", 0, 0), o.dynamic_weight, o["loss_weight"], o["loss2_weight"], do_B)):
+                if not on:
+                    continue
+                label = inputs[lab_key]
+                sdf = ops_loss.signed_distance(label) if use_bd else None
+                h = heads[sfx]
+                ops_loss.layout_loss(lv, "topview_loss" + sfx, h["top"], label, sdf, 1.0, cw, a_, use_ce, b2 * use_bd)
+                ops_loss.layout_loss(lv, "transform_topview_loss" + sfx, h["ttop"], label, sdf, 1.0, cw, a_, use_ce, b2 * use_bd)
+                ops_loss.l1_loss(lv, "transform_loss" + sfx, h["feats"], h["r"])
+                ops_loss.combine(lv, "layout_loss" + sfx, [("topview_loss" + sfx, 1.0), ("transform_loss" + sfx, 0.001),
+                                                          ("transform_topview_loss" + sfx, 1.0)])
+
+        if side is None:
+            layout_heads(F, feats[-1])
+        else:
+            # The heads follow the pose branch on the side stream.  They read F and the deepest depth feature through
+            # private Vars, so their gradients land in side-stream buffers; `graft` (a main-tape node that is replayed
+            # AFTER the depth decoder's backward, i.e. well after the side stream was started) adds them to the real ones.
+            F_s, f4_s = Var(F.t, True), Var(feats[-1].t, True)
+            f4_main = feats[-1]
+
+            def graft():
+                torch.cuda.current_stream().wait_stream(side)
+                for src, dst in ((F_s, F), (f4_s, f4_main)):
+                    if src.g is not None:
+                        src.g.record_stream(torch.cuda.current_stream())
+                        dst.add_grad(src.g)
+                        src.g = None
+
+            outer.record(graft)
+            n_out = set(outputs)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), ops.recording(pose_tape):
+                layout_heads(F_s, f4_s)
+            for k in set(outputs) - n_out:
+                if torch.is_tensor(outputs[k]):
+                    outputs[k].record_stream(main)
+
         masks = None
         if ("dropout_mask", 0) in inputs:
             masks = (inputs[("dropout_mask", 0)], inputs[("dropout_mask", 1)])
         disp = self.DepthDecoder._fwd(feats, masks)
-        outputs = {k: v.t for k, v in disp.items()}
-        F = self.LayoutEncoder._fwd(img, n_updates=2)                 # net.py:73-74 runs this branch twice (N4)
-        heads = {}
-        # the S head is always evaluated (and BN-updated twice) by the reference; B once
-        for sfx, tag, nup in (("", "road", 2), ("B", "car", 1)):
-            h = self._layout_head(sfx, F, feats[-1], nup)
-            heads[sfx] = h
-            outputs["topview" + sfx] = h["top"].t
-            outputs["transform_topview" + sfx] = h["ttop"].t
-            self._publish_head(outputs, sfx, tag, h)
-        outputs["origin_features"] = F.t
+        outputs.update({k: v.t for k, v in disp.items()})
 
         if side is None:
             pose_branch()
         else:
-            # join: the losses below read the poses on the main stream; the branch's backward is ONE node of the main
-            # tape, placed here so that it is replayed right after the loss nodes -- on the side stream again
+            # join: the losses below read the poses (and the loss vector) on the main stream; the side work's backward is
+            # ONE node of the main tape, placed here so that it is replayed right after the photometric loss nodes --
+            # on the side stream again: layout losses, heads, then the pose branch
             main.wait_stream(side)
             for pp in poses:
                 for t in (pp.T, pp.P, pp.dP):
@@ -253,33 +303,14 @@ class Baseline(nn.Module):
             for t in pose_out.values():
                 t.record_stream(main)
 
-            def pose_bwd():
-                side.wait_stream(torch.cuda.current_stream())       # dP accumulated by the loss nodes
+            def side_bwd():
+                side.wait_stream(torch.cuda.current_stream())       # loss-vector gradients, dP of the photometric nodes
                 with torch.cuda.stream(side):
                     pose_tape.backward()
 
-            outer.record(pose_bwd)
+            outer.record(side_bwd)
             outer.side_stream = side
         outputs.update(pose_out)
-
-        # ---- layout losses (net.py:107-138 with root-net.py conditionals)
-        lw = o.get("loss_weightS", o["loss_weight"])
-        l2w = o.get("loss2_weightS", o["loss2_weight"])
-        lsum = o["loss_sum"]
-        use_ce = 0.0 if lsum in (1, 2) else 1.0
-        use_bd = 0.0 if lsum == 1 else 1.0
-        for sfx, lab_key, cw, a, b2, on in (("", ("bothS", 0, 0), o.static_weight, lw, l2w, do_S),
-                                            ("B", ("bothD", 0, 0), o.dynamic_weight, o["loss_weight"], o["loss2_weight"], do_B)):
-            if not on:
-                continue
-            label = inputs[lab_key]
-            sdf = ops_loss.signed_distance(label) if use_bd else None
-            h = heads[sfx]
-            ops_loss.layout_loss(lv, "topview_loss" + sfx, h["top"], label, sdf, 1.0, cw, a, use_ce, b2 * use_bd)
-            ops_loss.layout_loss(lv, "transform_topview_loss" + sfx, h["ttop"], label, sdf, 1.0, cw, a, use_ce, b2 * use_bd)
-            ops_loss.l1_loss(lv, "transform_loss" + sfx, h["feats"], h["r"])
-            ops_loss.combine(lv, "layout_loss" + sfx, [("topview_loss" + sfx, 1.0), ("transform_loss" + sfx, 0.001),
-                                                      ("transform_topview_loss" + sfx, 1.0)])
 
         # ---- photometric / scale / smoothness per scale (net.py:139-190)
         scale_label = inputs.get(("scale_label", 0, 0))
