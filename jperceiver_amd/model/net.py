@@ -90,6 +90,7 @@ def _broadcast_scalar(s, out):
 
 
 _POSE_STREAM = os.environ.get("JP_POSE_STREAM", "1") != "0"
+_LAYOUT_ENC_SIDE = os.environ.get("JP_LAYOUT_ENC_SIDE", "1") != "0"
 
 
 @MONO.register_module
@@ -223,8 +224,16 @@ class Baseline(nn.Module):
 
         # ---- networks
         img = Var(inputs[("color_aug", 0, 0)])
-        feats = self.DepthEncoder._fwd(img)
-        F = self.LayoutEncoder._fwd(img, n_updates=2)                 # net.py:73-74 runs this branch twice (N4)
+        if side is not None and _LAYOUT_ENC_SIDE:
+            # the layout encoder follows the pose branch on the side stream: while one encoder is in its small-map
+            # layers (64x64 / 32x32: a few hundred workgroups) the other one usually is not
+            with torch.cuda.stream(side), ops.recording(pose_tape):
+                F = self.LayoutEncoder._fwd(img, n_updates=2)
+            F.t.record_stream(main)
+            feats = self.DepthEncoder._fwd(img)
+        else:
+            feats = self.DepthEncoder._fwd(img)
+            F = self.LayoutEncoder._fwd(img, n_updates=2)             # net.py:73-74 runs this branch twice (N4)
         outputs = {"origin_features": F.t}
 
         lw = o.get("loss_weightS", o["loss_weight"])
@@ -263,13 +272,14 @@ class Baseline(nn.Module):
             # The heads follow the pose branch on the side stream.  They read F and the deepest depth feature through
             # private Vars, so their gradients land in side-stream buffers; `graft` (a main-tape node that is replayed
             # AFTER the depth decoder's backward, i.e. well after the side stream was started) adds them to the real ones.
-            F_s, f4_s = Var(F.t, True), Var(feats[-1].t, True)
+            F_s = F if _LAYOUT_ENC_SIDE else Var(F.t, True)          # F itself lives on the side stream in that mode
+            f4_s = Var(feats[-1].t, True)
             f4_main = feats[-1]
 
             def graft():
                 torch.cuda.current_stream().wait_stream(side)
                 for src, dst in ((F_s, F), (f4_s, f4_main)):
-                    if src.g is not None:
+                    if src is not dst and src.g is not None:
                         src.g.record_stream(torch.cuda.current_stream())
                         dst.add_grad(src.g)
                         src.g = None
