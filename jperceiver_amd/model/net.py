@@ -276,8 +276,12 @@ class Baseline(nn.Module):
             f4_s = Var(feats[-1].t, True)
             f4_main = feats[-1]
 
+            heads_done = torch.cuda.Event()
+
             def graft():
-                torch.cuda.current_stream().wait_stream(side)
+                # wait only for the heads' backward (event recorded by the side tape), not for the layout encoder and
+                # pose backward queued behind it: the depth encoder's backward overlaps those
+                torch.cuda.current_stream().wait_event(heads_done)
                 for src, dst in ((F_s, F), (f4_s, f4_main)):
                     if src is not dst and src.g is not None:
                         src.g.record_stream(torch.cuda.current_stream())
@@ -288,6 +292,7 @@ class Baseline(nn.Module):
             n_out = set(outputs)
             side.wait_stream(main)
             with torch.cuda.stream(side), ops.recording(pose_tape):
+                pose_tape.record(lambda: heads_done.record(torch.cuda.current_stream()))   # replayed after the heads' backward
                 layout_heads(F_s, f4_s)
             for k in set(outputs) - n_out:
                 if torch.is_tensor(outputs[k]):
