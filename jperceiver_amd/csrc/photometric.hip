@@ -483,6 +483,83 @@ __global__ void scalar_finalize_kernel(const double* __restrict__ in, float* __r
     if (i < n) out[i] = (float)(in[i] * scale);
 }
 
+// ------------------------------------------------------------------------------ standalone §8b callables
+// SSIM()(x, y) (layers.py:85-107): per-channel (B,C,H,W) loss map clamp((1 - SSIM_n/SSIM_d)/2, 0, 1) with
+// ReflectionPad2d(1) + AvgPool2d(3,1).  The train step uses the fused SSIM+L1 kernels above; this is the
+// module's public forward.  One thread per pixel, taps through the L1/L2 (not a hot path).
+__global__ __launch_bounds__(TPB) void ssim_map_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       float* __restrict__ out, long total, int H, int W) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int px = (int)(i % W);
+        const long t = i / W;
+        const int py = (int)(t % H);
+        const long plane = (t / H) * (long)H * W;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = jp_reflect(py + dy, H);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = jp_reflect(px + dx, W);
+                const float a = x[plane + (long)yy * W + xx], b = y[plane + (long)yy * W + xx];
+                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        }
+        const float k = 1.f / 9.f;
+        const float mx = sx * k, my = sy * k;
+        const float vx = sxx * k - mx * mx, vy = syy * k - my * my, cxy = sxy * k - mx * my;
+        const float n = (2.f * mx * my + SSIM_C1) * (2.f * cxy + SSIM_C2);
+        const float d = (mx * mx + my * my + SSIM_C1) * (vx + vy + SSIM_C2);
+        out[i] = fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
+    }
+}
+
+// Backproject(B,H,W)(depth, inv_K) (layers.py:41-61): cam_points (B,4,H*W) = [depth * invK[:3,:3] @ (x, y, 1); 1]
+__global__ __launch_bounds__(TPB) void backproject_kernel(const float* __restrict__ depth, const float* __restrict__ invK,
+                                                          float* __restrict__ out, int B, int H, int W) {
+    const long HW = (long)H * W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < B * HW; i += (long)gridDim.x * TPB) {
+        const int b = (int)(i / HW);
+        const long p = i - b * HW;
+        const float fx = (float)(p % W), fy = (float)(p / W);
+        const float* k = invK + 16 * b;
+        const float d = depth[i];
+        float* o = out + (long)b * 4 * HW + p;
+        o[0] = d * (k[0] * fx + k[1] * fy + k[2]);
+        o[HW] = d * (k[4] * fx + k[5] * fy + k[6]);
+        o[2 * HW] = d * (k[8] * fx + k[9] * fy + k[10]);
+        o[3 * HW] = 1.f;
+    }
+}
+
+// Project(B,H,W)(points, K, T) (layers.py:64-82): pix (B,H,W,2) = ((P @ points)[:2] / (z + eps)) / (W-1, H-1), then
+// (x - 0.5) * 2 with P = (K @ T)[:3]
+__global__ __launch_bounds__(TPB) void project_kernel(const float* __restrict__ pts, const float* __restrict__ K,
+                                                      const float* __restrict__ T, float* __restrict__ out, int B, int H,
+                                                      int W, float eps) {
+    const long HW = (long)H * W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < B * HW; i += (long)gridDim.x * TPB) {
+        const int b = (int)(i / HW);
+        const long p = i - b * HW;
+        const float* k = K + 16 * b;
+        const float* t = T + 16 * b;
+        float P[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                P[4 * r + c] = k[4 * r] * t[c] + k[4 * r + 1] * t[4 + c] + k[4 * r + 2] * t[8 + c] + k[4 * r + 3] * t[12 + c];
+        const float* q = pts + (long)b * 4 * HW + p;
+        const float X = q[0], Y = q[HW], Z = q[2 * HW], Wc = q[3 * HW];
+        const float cx = P[0] * X + P[1] * Y + P[2] * Z + P[3] * Wc;
+        const float cy = P[4] * X + P[5] * Y + P[6] * Z + P[7] * Wc;
+        const float cz = P[8] * X + P[9] * Y + P[10] * Z + P[11] * Wc;
+        const float inv = 1.f / (cz + eps);
+        out[2 * i] = (cx * inv / (float)(W - 1) - 0.5f) * 2.f;
+        out[2 * i + 1] = (cy * inv / (float)(H - 1) - 0.5f) * 2.f;
+    }
+}
+
 }  // namespace
 
 #define JP_ST hipStream_t st = (hipStream_t)stream
@@ -558,5 +635,33 @@ extern "C" int jp_scalar_finalize(const double* in, float* out, int n, double sc
     JP_CHECK_ARG(in && out && n > 0, "scalar_finalize: bad args");
     JP_ST;
     hipLaunchKernelGGL(scalar_finalize_kernel, dim3(jp_cdiv(n, 64)), dim3(64), 0, st, in, out, n, scale);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_ssim_map(const float* x, const float* y, float* out, int NC, int H, int W, void* stream) {
+    JP_CHECK_ARG(x && y && out && NC > 0 && H >= 2 && W >= 2, "ssim_map: bad args");
+    JP_ST;
+    const long total = (long)NC * H * W;
+    hipLaunchKernelGGL(ssim_map_kernel, dim3((int)std::min<long>((total + TPB - 1) / TPB, 65535)), dim3(TPB), 0, st, x, y, out,
+                       total, H, W);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_backproject(const float* depth, const float* invK, float* out, int B, int H, int W, void* stream) {
+    JP_CHECK_ARG(depth && invK && out && B > 0 && H > 0 && W > 0, "backproject: bad args");
+    JP_ST;
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(backproject_kernel, dim3((int)std::min<long>((total + TPB - 1) / TPB, 65535)), dim3(TPB), 0, st, depth,
+                       invK, out, B, H, W);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_project(const float* points, const float* K, const float* T, float* out, int B, int H, int W, float eps,
+                          void* stream) {
+    JP_CHECK_ARG(points && K && T && out && B > 0 && H > 1 && W > 1, "project: bad args");
+    JP_ST;
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(project_kernel, dim3((int)std::min<long>((total + TPB - 1) / TPB, 65535)), dim3(TPB), 0, st, points, K,
+                       T, out, B, H, W, eps);
     JP_LAUNCH_CHECK();
 }

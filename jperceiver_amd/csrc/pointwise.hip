@@ -505,29 +505,160 @@ __global__ __launch_bounds__(TPB) void disp_to_depth_kernel(const float* __restr
         depth[i] = 1.f / (min_disp + (max_disp - min_disp) * disp[i]);
 }
 
-// CGT scale label assembly (net.py:291-309 static / :474-475 both):
-//   out = zwarp * [laywarp passes]  (* [pixel inside the convex quad q (4 integer corners, any winding)])
-// mode 0: out = zwarp * laywarp (Argo_both); mode 1: laywarp is binarised like `.type_as(uint8)` (== 1)
-// and intersected with the filled quad (cv2.fillConvexPoly, boundary inclusive).
+// cv2.fillConvexPoly(img, pts, color, lineType=1) as the reference calls it (net.py:300-305,394-399): OpenCV 4.x
+// drawing.cpp `FillConvexPoly` restated (third party, absent from the reference tree -> parity unpinned; the CPU
+// restatement this kernel is tested against pixel-exactly is oracle/cv2_restated.py):
+//   (1) every edge is drawn as a 4-connected Bresenham line (`Line(..., connectivity 1 -> 4)`, left-to-right,
+//       clipped to the image by cv::clipLine);
+//   (2) two-edge scan conversion in 16.16 fixed point, span of row y = [(xl + 0.5) >> 16, (xr + 0.5) >> 16].
+// One workgroup-independent formulation: threads 0..npts-1 of block 0 walk one edge each; EVERY thread replays the
+// (cheap, <= H iterations of integer arithmetic) scan-conversion state machine and emits only the rows dealt to it.
+// mask (H x W bytes) must be zero on entry (the launcher clears it on the same stream).
+__device__ inline bool cv_clip_line(long right, long bottom, long& x1, long& y1, long& x2, long& y2) {
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+constexpr int POLY_MAX = 8;
+__global__ __launch_bounds__(TPB) void fill_convex_poly_kernel(const int* __restrict__ pts, int npts,
+                                                               uint8_t* __restrict__ mask, int H, int W) {
+    long vx[POLY_MAX], vy[POLY_MAX];
+#pragma unroll
+    for (int i = 0; i < POLY_MAX; ++i) {
+        vx[i] = i < npts ? pts[2 * i] : 0;
+        vy[i] = i < npts ? pts[2 * i + 1] : 0;
+    }
+    const int gt = blockIdx.x * TPB + threadIdx.x, nthreads = gridDim.x * TPB;
+    if (gt < npts) {   // edge gt: v[gt-1] -> v[gt], LineIterator(connectivity 4, leftToRight)
+        const int i0 = gt == 0 ? npts - 1 : gt - 1;
+        long x1 = vx[i0], y1 = vy[i0], x2 = vx[gt], y2 = vy[gt];
+        bool ok = true;
+        if ((unsigned long)x1 >= (unsigned long)W || (unsigned long)x2 >= (unsigned long)W ||
+            (unsigned long)y1 >= (unsigned long)H || (unsigned long)y2 >= (unsigned long)H)
+            ok = cv_clip_line(W - 1, H - 1, x1, y1, x2, y2);
+        if (ok) {
+            long dx = x2 - x1, dy = y2 - y1, step_x = 1, step_y = 1;
+            if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
+            if (dy < 0) { dy = -dy; step_y = -1; }
+            const bool vert = dy > dx;
+            if (vert) { const long t = dx; dx = dy; dy = t; }
+            long err = 0;
+            const long plus = 2 * dx + 2 * dy, minus = -2 * dy, count = dx + dy + 1;
+            long x = x1, y = y1;
+            for (long k = 0; k < count; ++k) {
+                mask[y * W + x] = 1;
+                const bool m = err < 0;
+                err += minus + (m ? plus : 0);
+                // 4-connected: minor-axis step when the error went negative, else major-axis step
+                if (vert) { if (m) x += step_x; else y += step_y; }
+                else      { if (m) y += step_y; else x += step_x; }
+            }
+        }
+    }
+    if (npts < 3) return;
+    long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+    int imin = 0;
+    for (int i = 0; i < npts; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        ymax = vy[i] > ymax ? vy[i] : ymax;
+        xmax = vx[i] > xmax ? vx[i] : xmax;
+        xmin = vx[i] < xmin ? vx[i] : xmin;
+    }
+    if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+    if (ymax > H - 1) ymax = H - 1;
+    int e_idx[2] = {imin, imin};
+    const int e_di[2] = {1, npts - 1};
+    long e_x[2] = {-65536, -65536}, e_dx[2] = {0, 0}, e_ye[2] = {ymin, ymin};
+    int edges = npts;
+    long y = ymin;
+    do {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (y >= e_ye[i]) {
+                int idx0 = e_idx[i], idx = idx0 + e_di[i];
+                if (idx >= npts) idx -= npts;
+                for (; edges-- > 0;) {
+                    long ty = 0, xs = 0, xe = 0;
+#pragma unroll
+                    for (int q = 0; q < POLY_MAX; ++q) {      // register-array select (no scratch indexing)
+                        if (q == idx) { ty = vy[q]; xe = vx[q]; }
+                        if (q == idx0) xs = vx[q];
+                    }
+                    if (ty > y) {
+                        xs <<= 16;
+                        xe <<= 16;
+                        e_ye[i] = ty;
+                        e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));   // C division truncates like OpenCV's
+                        e_x[i] = xs;
+                        e_idx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += e_di[i];
+                    if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0 && (int)((y - (ymin < 0 ? 0 : ymin)) % nthreads) == gt) {
+            const int l = e_x[0] > e_x[1] ? 1 : 0;
+            long xx1 = (e_x[l] + 32768) >> 16, xx2 = (e_x[1 - l] + 32768) >> 16;
+            if (xx2 >= 0 && xx1 < W) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= W) xx2 = W - 1;
+                for (long x = xx1; x <= xx2; ++x) mask[y * W + x] = 1;
+            }
+        }
+        e_x[0] += e_dx[0];
+        e_x[1] += e_dx[1];
+    } while (++y <= ymax);
+}
+
+// CGT scale label assembly (net.py:291-309 static / :394-401 dynamic / :474-475 both):
+//   mode 0: out = zwarp * laywarp                                   (Argo_both)
+//   mode 1: out = zwarp * uint8(laywarp) * polymask                 (static; laywarp == NULL -> dynamic)
+// `.type_as(uint8)` keeps the pixels whose bilinearly warped {0,1} layout reaches 1.0; the interpolation weights
+// sum to 1 only up to fp32 rounding (platform-dependent in the reference itself), so "reaches 1" is taken with a
+// 1e-6 guard band.  polymask = the H x W byte mask of jp_fill_convex_poly (shared by the whole batch, like the
+// reference's batch-item-0 polygon).
 __global__ __launch_bounds__(TPB) void scale_label_kernel(const float* __restrict__ zw, const float* __restrict__ lw,
-                                                          const int* __restrict__ quad, float* __restrict__ out,
-                                                          long total, int H, int W, int mode) {
+                                                          const uint8_t* __restrict__ polymask, float* __restrict__ out,
+                                                          long total, long HW, int mode) {
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
         float m = lw ? lw[i] : 1.f;
         if (mode == 1) {
             m = (lw == nullptr || m >= 0.999999f) ? 1.f : 0.f;
-            const int p = (int)(i % ((long)H * W));
-            const int y = p / W, x = p - y * W;
-            int pos = 0, neg = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ax = quad[2 * k], ay = quad[2 * k + 1];
-                const int bx = quad[2 * ((k + 1) & 3)], by = quad[2 * ((k + 1) & 3) + 1];
-                const long cr = (long)(bx - ax) * (y - ay) - (long)(by - ay) * (x - ax);
-                pos += cr > 0;
-                neg += cr < 0;
-            }
-            if (pos > 0 && neg > 0) m = 0.f;
+            if (!polymask[i % HW]) m = 0.f;
         }
         out[i] = zw[i] * m;
     }
@@ -730,12 +861,20 @@ extern "C" int jp_disp_to_depth(const float* disp, float* depth, long n, float m
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_scale_label_assemble(const float* zwarp, const float* laywarp, const int* quad, float* out, int B,
-                                       int H, int W, int mode, void* stream) {
-    JP_CHECK_ARG(zwarp && out && B > 0 && (mode == 0 || quad), "scale_label_assemble: bad args");
+extern "C" int jp_fill_convex_poly(const int* pts, int npts, uint8_t* mask, int H, int W, void* stream) {
+    JP_CHECK_ARG(pts && mask && npts >= 1 && npts <= POLY_MAX && H > 0 && W > 0, "fill_convex_poly: bad args");
+    JP_ST;
+    JP_HIP(hipMemsetAsync(mask, 0, (size_t)H * W, st));
+    hipLaunchKernelGGL(fill_convex_poly_kernel, dim3(8), dim3(TPB), 0, st, pts, npts, mask, H, W);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_scale_label_assemble(const float* zwarp, const float* laywarp, const uint8_t* polymask, float* out,
+                                       int B, int H, int W, int mode, void* stream) {
+    JP_CHECK_ARG(zwarp && out && B > 0 && (mode == 0 || polymask), "scale_label_assemble: bad args");
     JP_ST;
     const long total = (long)B * H * W;
-    hipLaunchKernelGGL(scale_label_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, zwarp, laywarp, quad, out, total,
-                       H, W, mode);
+    hipLaunchKernelGGL(scale_label_kernel, dim3(blocks_for(total)), dim3(TPB), 0, st, zwarp, laywarp, polymask, out,
+                       total, (long)H * W, mode);
     JP_LAUNCH_CHECK();
 }

@@ -135,27 +135,60 @@ class CRPBlock(nn.Module):
 
 
 class SSIM(nn.Module):
-    """layers.py:85-107.  Standalone forward returns the (B,3,H,W) SSIM loss map like the reference;
-    the train step uses the fused SSIM+L1 kernel instead."""
+    """layers.py:85-107: `SSIM()(x, y)` -> per-channel loss map clamp((1 - SSIM)/2, 0, 1) of the inputs' shape
+    (ReflectionPad2d(1) + 3x3 average pooling).  Standalone forward = `jp_ssim_map`; the train step uses the fused
+    SSIM+L1 kernels (`ops_loss.ssim_l1`, forward and backward) instead."""
 
     def forward(self, x, y):
-        raise NotImplementedError("per-channel SSIM map is only produced fused with L1 (ops_loss.ssim_l1)")
+        if x.shape != y.shape or x.dim() != 4:
+            raise ValueError("SSIM expects two (B,C,H,W) tensors of equal shape")
+        if x.requires_grad or y.requires_grad:
+            raise NotImplementedError("standalone SSIM is forward-only; gradients come from the fused SSIM+L1 train-step kernels")
+        B, C, H, W = x.shape
+        x, y = x.contiguous().float(), y.contiguous().float()
+        out = torch.empty_like(x)
+        ops.call("jp_ssim_map", x, y, out, B * C, H, W)
+        return out
 
 
 class Backproject(nn.Module):
-    """layers.py:41-61 — constructor kept for API parity; the geometry is fused into jp_cgt_warp_*."""
+    """layers.py:41-61: `Backproject(B,H,W)(depth, inv_K)` -> homogeneous camera points (B,4,H*W).  The pixel grid the
+    reference keeps as a buffer is generated in the kernel.  In the train step the geometry is fused into
+    `jp_cgt_warp_*`; this is the module's public forward (`jp_backproject`)."""
 
     def __init__(self, batch_size, height, width):
         super().__init__()
         self.batch_size, self.height, self.width = batch_size, height, width
 
+    def forward(self, depth, inv_K):
+        B, H, W = self.batch_size, self.height, self.width
+        if depth.numel() != B * H * W or tuple(inv_K.shape) != (B, 4, 4):
+            raise ValueError("Backproject: depth must hold batch_size*height*width values and inv_K be (B,4,4)")
+        if depth.requires_grad:
+            raise NotImplementedError("standalone Backproject is forward-only; the train step differentiates jp_cgt_warp_*")
+        out = torch.empty((B, 4, H * W), device=depth.device, dtype=torch.float32)
+        ops.call("jp_backproject", depth.contiguous().float(), inv_K.contiguous().float(), out, B, H, W)
+        return out
+
 
 class Project(nn.Module):
-    """layers.py:64-82 — see Backproject."""
+    """layers.py:64-82: `Project(B,H,W)(points, K, T)` -> normalised sampling grid (B,H,W,2) for F.grid_sample
+    (`jp_project`); fused into `jp_cgt_warp_*` in the train step."""
 
     def __init__(self, batch_size, height, width, eps=1e-7):
         super().__init__()
         self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
+
+    def forward(self, points, K, T):
+        B, H, W = self.batch_size, self.height, self.width
+        if tuple(points.shape) != (B, 4, H * W) or tuple(K.shape) != (B, 4, 4) or tuple(T.shape) != (B, 4, 4):
+            raise ValueError("Project: points must be (B,4,H*W), K and T (B,4,4)")
+        if points.requires_grad or T.requires_grad:
+            raise NotImplementedError("standalone Project is forward-only; the train step differentiates jp_cgt_warp_*")
+        out = torch.empty((B, H, W, 2), device=points.device, dtype=torch.float32)
+        ops.call("jp_project", points.contiguous().float(), K.contiguous().float(), T.contiguous().float(), out, B, H, W,
+                 float(self.eps))
+        return out
 
 
 # ------------------------------------------------------------------------------------------- resnet.py

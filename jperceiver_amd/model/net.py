@@ -376,21 +376,26 @@ class Baseline(nn.Module):
             dev = inputs[("color", 0, 0)].device
             Hm, quad = Hm_c.to(dev), quad_c.to(dev)
         B = Hm.shape[0]
-        lay_key = ("both_dynamic", 0, 0) if ty == "Argo_both" else ("bothS", 0, 0)
-        lay = rot270(inputs[lay_key])
-        off = 1.9 if o.split == "argo" else 0.27
+        dynamic = ty in ("dynamic", "Argo_dynamic")
+        # net.py:225-229 / 416-420 subtract the sensor offset; get_scale_label_dynamic only does for Argoverse
+        # (net.py:326-328: the KITTI "- 0.27" is commented out there)
+        off = 1.9 if o.split == "argo" else (0.0 if dynamic else 0.27)
         z = _distance_map(B, occ, off, Hm.device)
         zw = torch.empty((B, 1, FH, FW), device=Hm.device)
-        lw = torch.empty_like(zw)
         call("jp_warp_perspective", z, Hm, zw, B, occ, occ, FH, FW)
-        call("jp_warp_perspective", lay, Hm, lw, B, occ, occ, FH, FW)
+        lw = None
+        if not dynamic:
+            lay_key = ("both_dynamic", 0, 0) if ty == "Argo_both" else ("bothS", 0, 0)
+            lw = torch.empty_like(zw)
+            call("jp_warp_perspective", rot270(inputs[lay_key]), Hm, lw, B, occ, occ, FH, FW)
         out = torch.empty_like(zw)
         if ty == "Argo_both":
             call("jp_scale_label_assemble", zw, lw, None, out, B, FH, FW, 0)
-        elif ty in ("dynamic", "Argo_dynamic"):
-            call("jp_scale_label_assemble", zw, None, quad, out, B, FH, FW, 1)
         else:
-            call("jp_scale_label_assemble", zw, lw, quad, out, B, FH, FW, 1)
+            # the "assumption region" polygon of batch item 0, rasterised like cv2.fillConvexPoly(lineType=1)
+            mask = torch.empty((FH, FW), device=Hm.device, dtype=torch.uint8)
+            call("jp_fill_convex_poly", quad, 4, mask, FH, FW)
+            call("jp_scale_label_assemble", zw, lw, mask, out, B, FH, FW, 1)
         return out
 
 

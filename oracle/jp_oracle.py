@@ -622,6 +622,90 @@ def scale_label_both(opt, inputs):
     return warp_perspective(z, M, (H, W)) * warp_perspective(lay, M, (H, W))
 
 
+def transform_points(T, pts):
+    """torchgeometry 0.1.2 `transform_points` (unpinned third party): homogeneous matmul + perspective divide."""
+    ph = F.pad(pts, (0, 1), value=1.0)
+    out = torch.matmul(T.unsqueeze(1), ph.unsqueeze(-1)).squeeze(-1)
+    return out[..., :-1] / out[..., -1:]
+
+
+def _assumption_quad(opt, M):
+    """net.py:235-248,292-299 (static) == :329-341,386-393 (dynamic): the 4 m x 2 m "assumption region" in front
+    of the ego car, rotated into the BEV frame, projected with batch item 0's homography, rounded (half-to-even,
+    torch.round) and re-ordered to the polygon order [0, 2, 3, 1] the reference hands to cv2.fillConvexPoly."""
+    mapsize = opt.occ_map_size
+    r1 = mapsize / 40
+    pr = [(round(18 * r1), round(31 * r1)), (round(22 * r1), round(31 * r1)),
+          (round(18 * r1), round(33 * r1)), (round(22 * r1), round(33 * r1))]
+    rot = [[mapsize - pr[3][1] - 1, pr[0][0] - 1],
+           [mapsize - pr[3][1] + (pr[2][1] - pr[1][1]) - 1, pr[0][0] - 1],
+           [mapsize - pr[3][1] - 1, pr[1][0] - 1],
+           [mapsize - pr[3][1] + (pr[2][1] - pr[1][1]) - 1, pr[1][0] - 1]]
+    B = M.shape[0]
+    pts = torch.tensor(np.asarray(rot), dtype=torch.float32).repeat(B, 1, 1)
+    new = torch.round(transform_points(M, pts)).int()
+    p = new[0]
+    return np.array([[p[0][0], p[0][1]], [p[2][0], p[2][1]], [p[3][0], p[3][1]], [p[1][0], p[1][1]]]).astype(np.int32)
+
+
+def _assumption_mask(opt, M, H, W):
+    """net.py:300-305: fillConvexPoly(zeros(H,W,3) uint8, pts, (0,255,255), lineType=1) -> RGB2GRAY -> > 0."""
+    from . import cv2_restated as cv2
+    pts = _assumption_quad(opt, M).reshape((-1, 1, 2))
+    img = cv2.fillConvexPoly(np.zeros((H, W, 3), np.uint8), pts, (0, 255, 255), 1)
+    return cv2.cvtColor(img, cv2.COLOR_RGB2GRAY) > 0
+
+
+def _distance_label(opt, B, offset):
+    mapsize = opt.occ_map_size
+    z = torch.arange(mapsize, 0, step=-1).view(1, 1, mapsize, 1).repeat(B, 1, 1, mapsize) * (40 / mapsize) - offset
+    return torch.rot90(z, 3, (-2, -1))     # fliplr on dim 1 (size 1) is a no-op; rotate(270) == rot90(k=3)
+
+
+def scale_label_static(opt, inputs, return_parts=False):
+    """net.py:212-310 (`get_scale_label_static`): warped distance label x uint8(warped road layout) & filled
+    assumption quad.  `.type_as(uint8)` truncates the bilinearly warped {0,1} layout, i.e. keeps the pixels whose
+    interpolated value reaches 1.0 in the evaluating platform's fp32 arithmetic (rounding-sensitive, see
+    tests/test_scale_label.py for the band that is treated as ambiguous)."""
+    H, W = inputs[("color", 0, -1)].shape[2:4]
+    lay = inputs[("bothS", 0, 0)]
+    B = lay.shape[0]
+    off = 1.9 if opt.split == "argo" else 0.27
+    z = _distance_label(opt, B, off)
+    lay = torch.rot90(lay, 3, (-2, -1))
+    M = scale_label_homography(opt, inputs)
+    zw = warp_perspective(z, M, (H, W))
+    lw = warp_perspective(lay, M, (H, W))
+    tri = torch.from_numpy(_assumption_mask(opt, M, H, W).astype(np.uint8) * 255).repeat(B, 1, 1).unsqueeze(1)
+    a_and_b = torch.bitwise_and(lw.type_as(tri), tri)
+    out = zw * a_and_b
+    return (out, zw, lw, tri) if return_parts else out
+
+
+def scale_label_dynamic(opt, inputs, return_parts=False):
+    """net.py:311-399 (`get_scale_label_dynamic`): warped distance label x filled assumption quad.  Note the
+    non-Argo distance label carries NO -0.27 offset here (net.py:328, commented out in the reference)."""
+    H, W = inputs[("color", 0, -1)].shape[2:4]
+    B = inputs[("bothS", 0, 0)].shape[0]
+    off = 1.9 if opt.split == "argo" else 0.0
+    z = _distance_label(opt, B, off)
+    M = scale_label_homography(opt, inputs)
+    zw = warp_perspective(z, M, (H, W))
+    tri = torch.from_numpy(_assumption_mask(opt, M, H, W).astype(np.uint8)).repeat(B, 1, 1).unsqueeze(1)
+    out = zw * tri
+    return (out, zw, None, tri) if return_parts else out
+
+
+def make_scale_label(opt, inputs):
+    """net.py:139-144 dispatch on opt.type."""
+    ty = opt["type"]
+    if ty == "Argo_both":
+        return scale_label_both(opt, inputs)
+    if ty in ("dynamic", "Argo_dynamic"):
+        return scale_label_dynamic(opt, inputs)
+    return scale_label_static(opt, inputs)
+
+
 # ----------------------------------------------------------------------------------
 # the step
 # ----------------------------------------------------------------------------------
@@ -654,7 +738,7 @@ def compute_losses(opt, inputs, outputs, automask_noise=None, scale_label=None, 
     do_S = ty in ("static_raw", "static", "Argo_static", "Argo_both", "static_eigen")
     do_B = ty in ("dynamic", "Argo_dynamic", "Argo_both")
     if scale_label is None:
-        scale_label = scale_label_both(opt, inputs)
+        scale_label = make_scale_label(opt, inputs)
     if do_S:
         L["topview_loss"] = topview_loss(opt, outputs["topview"], inputs[("bothS", 0, 0)], opt.static_weight, True)
         L["transform_topview_loss"] = topview_loss(opt, outputs["transform_topview"], inputs[("bothS", 0, 0)], opt.static_weight, True)

@@ -1,0 +1,148 @@
+"""One full train step per BASELINE.json config, on that config's own flags (type / loss_sum / frame_ids / split /
+per-GPU batch / full-resolution frame), through the product path exactly as bench.py drives it:
+`change_input_variable` -> `Baseline.forward` (which GENERATES the CGT scale label on the device — nothing is fed
+in) -> backward -> clip + Adam, checked against the CPU oracle on the same seeded inputs.
+
+  configs[0] cfg_kitti_baseline_odometry_boundary_ce_iou_1024_20_B1   static, [0,-1],   B=1, 1024^2, loss_sum 3
+  configs[1] cfg_kitti_baseline_odometry_boundary_ce_iou_1024_20      static, [0,-1,1], B=3 (file) — run at 512^2
+  configs[2] cfg_kitti_baseline_kitti_odom_4gpus                      static, loss_sum 1 (IoU only), B=3 — 256^2
+  configs[3] cfg_kitti_baseline_kitti_odom_8pugsB24_lr1e-4_ce_eigen   static_eigen, loss_sum 0, split eigen — 256^2
+  configs[4] cfg_kitti_baseline_argo_both_boundary_ce_iou_1024_20_B1  Argo_both: tests/test_step_parity_gpu.py
+             (reference-generated golden at exactly these flags) + the 2056x2464 label case below.
+(The 1024^2 x B=8 shape of the bench itself is exercised by bench.py; the CPU oracle needs minutes per step there, so
+configs[1..3] run their flags at 512^2 / 256^2 — every kernel is shape-generic and 1024^2 is covered by configs[0].)
+
+Tolerances: losses 2e-3 relative (BASELINE.json: 1e-3 on maps; sums of ~1e6 fp32 terms in a different order),
+gradients 2 % of each parameter's gradient norm with the device's discrete selections replayed in the oracle
+(DESIGN.md §2), optimizer update <= 1e-6 absolute when the oracle's Adam is fed the device gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from jperceiver_amd import synthetic as syn                                    # noqa: E402
+from jperceiver_amd.model import MONO                                          # noqa: E402
+from jperceiver_amd.apis import build_optimizer, change_input_variable        # noqa: E402
+from oracle import jp_oracle as J                                              # noqa: E402
+
+CONFIGS = {
+    "cfg0_odometry_B1_1024": dict(HW=1024, B=1, FR=[0, -1], type="static", split="odometry", loss_sum=3,
+                                  full_hw=(375, 1242), seed=21),
+    "cfg1_odometry_1024_20": dict(HW=512, B=3, FR=[0, -1, 1], type="static", split="odometry", loss_sum=3,
+                                  full_hw=(375, 1242), seed=22),
+    "cfg2_kitti_odom_4gpus": dict(HW=256, B=3, FR=[0, -1, 1], type="static", split="odometry", loss_sum=1,
+                                  full_hw=(375, 1242), seed=23),
+    "cfg3_eigen_8gpus": dict(HW=256, B=3, FR=[0, -1, 1], type="static_eigen", split="eigen", loss_sum=0,
+                             full_hw=(375, 1242), seed=24),
+    "dynamic_head_only": dict(HW=256, B=2, FR=[0, -1], type="dynamic", split="odometry", loss_sum=3,
+                              full_hw=(375, 1242), seed=25),
+    "cfg4_argo_full_frame": dict(HW=256, B=1, FR=[0, -1], type="Argo_both", split="argo", loss_sum=3,
+                                 full_hw=(2056, 2464), seed=26),
+}
+
+
+def _opt(c):
+    o = J.default_opt(frame_ids=c["FR"], imgs_per_gpu=c["B"], height=c["HW"], width=c["HW"], occ_map_size=c["HW"] // 4,
+                      type=c["type"], split=c["split"], loss_sum=c["loss_sum"])
+    if c["type"] == "Argo_both":
+        o.update(loss_weightS=20, loss2_weightS=20)
+    return o
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_step(name):
+    c = CONFIGS[name]
+    opt = _opt(c)
+    HW, B, FR = c["HW"], c["B"], c["FR"]
+    model = MONO.module_dict["Baseline"](opt)
+    state = syn.synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(state, strict=True)
+    model = model.cuda().train()
+    inp = syn.make_batch(B, HW, HW, FR, HW // 4, c["full_hw"], c["split"], seed=c["seed"])
+    masks = syn.make_dropout_masks(B, HW, HW, seed=c["seed"])
+    noise = syn.make_automask_noise(B, HW, HW, 4, len(FR) - 1, seed=c["seed"])
+    d = change_input_variable({k: v.clone() for k, v in inp.items()}, opt=model.opt)
+    assert ("scale_label", 0, 0) not in d
+    d[("dropout_mask", 0)], d[("dropout_mask", 1)] = masks[0].cuda(), masks[1].cuda()
+    for s, per in enumerate(noise):
+        for j, nz in enumerate(per):
+            d[("automask_noise", s, j)] = nz.cuda()
+    optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+    optim.zero_grad()
+    out, losses = model(d)
+    total = losses.total()
+    total.backward()
+    torch.cuda.synchronize()
+
+    # ---- the label the step generated vs the oracle's (details: tests/test_scale_label.py)
+    lab = out["scale_label"].cpu()
+    lab_ref = J.make_scale_label(opt, inp)
+    fin = torch.isfinite(lab) & torch.isfinite(lab_ref)
+    mism = int((((lab > 0) ^ (lab_ref > 0)) & fin).sum())
+    assert mism <= 0.03 * max(1, int((lab_ref > 0).sum())), f"scale label support differs in {mism} pixels"
+
+    # ---- expected loss keys for this type / loss_sum (root net.py:125-159)
+    S = ["topview_loss", "transform_topview_loss", "transform_loss", "layout_loss"]
+    D = [k + "B" for k in S]
+    want = {"static": S, "static_eigen": S, "dynamic": D, "Argo_both": S + D}[c["type"]]
+    assert [k for k in losses if isinstance(k, str)] == want
+
+    # ---- oracle with the device's discrete selections and the device-generated label
+    force = {("min_index", s): out[("min_index", s)].cpu() for s in range(4)}
+    for tag in ("road", "car"):
+        force["cv_argmax_" + tag] = out["cv_argmax_" + tag].cpu()
+        force["cm_argmax_" + tag] = out["cm_argmax_" + tag].cpu()
+    shapes = J.state_shapes(HW // 4)
+    P, Bf = J.make_params(shapes, state)
+    o2, L2 = J.forward(P, Bf, opt, inp, True, masks, noise, torch.nan_to_num(lab, nan=0.0, posinf=0.0, neginf=0.0), force)
+    tot2 = J.total_loss(L2)
+    tot2.backward()
+    assert set(L2) == set(losses)
+    for k in L2:
+        a, b = float(losses[k]), float(L2[k])
+        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-4), (name, k, a, b)
+    assert abs(float(total) - float(tot2)) <= 2e-3 * abs(float(tot2))
+    for f in FR[1:]:
+        np.testing.assert_allclose(out[("cam_T_cam", 0, f)].cpu().numpy(), o2[("cam_T_cam", 0, f)].detach().numpy(), atol=1e-4)
+    for s in range(4):
+        a, b = out[("disp", 0, s)].cpu(), o2[("disp", 0, s)].detach()
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-3, (name, "disp", s)
+    for k in ("topview", "topviewB"):
+        a, b = out[k].cpu(), o2[k].detach()
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-3, (name, k)
+
+    # ---- gradients: dead heads exactly zero, everything else element-wise vs the oracle
+    deadS = ("CycledViewProjection.", "CrossViewTransformer.", "LayoutDecoder.", "LayoutTransformDecoder.")
+    deadB = ("CycledViewProjectionB.", "CrossViewTransformerB.", "LayoutDecoderB.", "LayoutTransformDecoderB.")
+    dead = {"static": deadB, "static_eigen": deadB, "dynamic": deadS, "Argo_both": ()}[c["type"]]
+    bad = []
+    for n, p in model.named_parameters():
+        r = P[n].grad
+        if n.startswith(dead):
+            assert r is None and float(p.grad.abs().max()) == 0.0, n
+            continue
+        if r is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        rn = float(r.norm())
+        err = float((p.grad.detach().cpu() - r).norm())
+        tol = 8e-2 if p.numel() == 1 else 4e-2 if ("query_conv" in n or "key_conv" in n) else 2e-2
+        if err > tol * rn + 2e-5 * abs(float(tot2)):
+            bad.append((n, err, rn))
+    assert not bad, f"{name}: {len(bad)} gradient mismatches, first {bad[:6]}"
+
+    # ---- clip + Adam: the oracle's reference-ordered update fed with the DEVICE gradients must reproduce the arena
+    # update to fp32 rounding (checks arena offsets, live range, clip coefficient, bias corrections at step level)
+    for n, p in model.named_parameters():
+        if n in P:
+            P[n].grad = None if (P[n].grad is None) else p.grad.detach().cpu().clone()
+    norm_ref = J.adam_step(P, {}, lr=1e-4, max_norm=35.0)
+    optim.max_norm, optim.grad_scale = 35.0, 1.0
+    optim.step()
+    torch.cuda.synchronize()
+    norm_hip = float(optim.arena.normsq.sqrt())
+    assert abs(norm_hip - norm_ref) <= 1e-5 * norm_ref
+    worst = max(float((p.detach().cpu() - P[n].detach()).abs().max()) for n, p in model.named_parameters() if n in P)
+    assert worst <= 1e-6, f"{name}: parameters after clip+Adam differ from the oracle update by {worst}"

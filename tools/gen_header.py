@@ -24,7 +24,7 @@ GROUPS = [
      ["jp_maxpool_fwd", "jp_maxpool_bwd", "jp_upsample2x_fwd", "jp_upsample2x_bwd", "jp_copy_channels", "jp_axpby", "jp_mul",
       "jp_affine", "jp_act_fwd", "jp_act_bwd", "jp_mul_bcast_c", "jp_mul_bcast_c_bwd_s", "jp_bilinear_fwd", "jp_bilinear_bwd",
       "jp_area_downsample", "jp_fill", "jp_warp_perspective", "jp_softmax_c2", "jp_disp_to_depth",
-      "jp_scale_label_assemble"]),
+      "jp_scale_label_assemble", "jp_fill_convex_poly"]),
     ("Small dense algebra of the BEV branch — CVP MLP " + R + "CycledViewProjection.py:33-38,54-67; CCT attention "
      + R + "CrossViewTransformer.py:14-24,53-65,77-88; PoseDecoder spatial mean " + R + "pose_decoder.py:22-23.",
      ["jp_gemm_strided_batched", "jp_bias_act_rows", "jp_colsum", "jp_colmax", "jp_colmax_bwd", "jp_gather_cols",
@@ -34,7 +34,7 @@ GROUPS = [
      + R + "layers.py:41-82, " + R + "net.py:690-702; SSIM " + R + "layers.py:85-107; reprojection + automask min "
      + R + "net.py:84-92,159-175.",
      ["jp_pose_fwd", "jp_pose_bwd", "jp_cgt_warp_fwd", "jp_cgt_warp_bwd", "jp_ssim_l1_fwd", "jp_ssim_l1_bwd",
-      "jp_minreproj_fwd", "jp_scalar_finalize"]),
+      "jp_minreproj_fwd", "jp_scalar_finalize", "jp_ssim_map", "jp_backproject", "jp_project"]),
     ("Other losses — smoothness " + R + "net.py:182-190,758-786; CGT scale loss " + R + "net.py:193-211; IoU "
      + R + "dice_loss.py:31-81,293-331 + weighted CE " + R + "net.py:561,583 + boundary loss " + R + "boundary_loss.py:121-192 "
      "(jp_sdf = exact EDT + inner boundary on the GPU, no host round trip); cycle L1 " + R + "net.py:619-622.",

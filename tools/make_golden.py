@@ -54,7 +54,11 @@ def import_reference():
     np.bool = bool                                   # boundary_loss.py:137 (numpy>=1.24)
     torch.Tensor.cuda = lambda self, *a, **k: self   # hard .cuda() calls all over net.py/layers.py
     nn.Module.cuda = lambda self, *a, **k: self
-    _stub("imageio"); _stub("pykitti"); _stub("cv2")
+    _stub("imageio"); _stub("pykitti")
+    # cv2 is absent from the image: the two calls net.py makes (fillConvexPoly, cvtColor) are served by the numpy
+    # restatement of OpenCV's published algorithm (oracle/cv2_restated.py; third party, parity unpinned)
+    from oracle import cv2_restated
+    sys.modules["cv2"] = cv2_restated
 
     def find_boundaries(img, mode="inner"):          # skimage rule, connectivity=1
         img = np.asarray(img).astype(np.uint8)
@@ -268,6 +272,50 @@ def unit_vectors(net):
     print("unit_vectors keys", len(g))
 
 
+def scale_label_cases(net):
+    """get_scale_label_static / get_scale_label_dynamic (net.py:212-402) run by the REFERENCE on the synthetic
+    calibration (third-party pieces stubbed as above) -> tests/golden/scale_labels.npz: the 0/1 support as packed
+    bits, 32x32 pooled values, sums, and the polygon the reference handed to cv2.fillConvexPoly."""
+    from oracle import cv2_restated
+    g = {}
+    cases = {"static_odom": ("static", "odometry", (375, 1242), 256, 2, 1),
+             "dynamic_odom": ("dynamic", "odometry", (375, 1242), 256, 2, 1),
+             "static_argo_small": ("static", "argo", (514, 616), 128, 2, 2),
+             "static_argo_full": ("static", "argo", (2056, 2464), 256, 1, 3),
+             "dynamic_argo_full": ("dynamic", "argo", (2056, 2464), 256, 1, 3)}
+    for name, (ty, split, fhw, occ, B, seed) in cases.items():
+        HW = occ * 4
+        opt = Opt(occ_map_size=occ, split=split, type=ty)
+        inp = syn.make_batch(B, HW, HW, [0], occ, fhw, split, seed=seed)
+        dummy = types.SimpleNamespace()
+        for nm in ("get_scale_label_static", "get_scale_label_dynamic", "SE3", "homography_from_calibration"):
+            setattr(dummy, nm, types.MethodType(getattr(net.Baseline, nm), dummy))
+        seen = {}
+        real = cv2_restated.fillConvexPoly
+
+        def spy(img, pts, color, lineType=8, shift=0):
+            seen["pts"], seen["lineType"], seen["color"] = np.array(pts).reshape(-1, 2).copy(), lineType, tuple(color)
+            return real(img, pts, color, lineType, shift)
+        cv2_restated.fillConvexPoly = spy
+        try:
+            fn = dummy.get_scale_label_static if ty == "static" else dummy.get_scale_label_dynamic
+            lab = fn({k: v.clone() for k, v in inp.items()}, opt).float()
+        finally:
+            cv2_restated.fillConvexPoly = real
+        g[name + "/meta"] = np.array(repr(dict(type=ty, split=split, full_hw=list(fhw), occ=occ, B=B, seed=seed)))
+        g[name + "/pts"] = seen["pts"].astype(np.int32)
+        g[name + "/lineType"] = np.int64(seen["lineType"])
+        g[name + "/n_nonfinite"] = np.int64((~torch.isfinite(lab)).sum().item())   # horizon pixels: x/0 in the warp
+        g[name + "/support"] = np.packbits((lab > 0).numpy().reshape(-1))
+        lab = torch.nan_to_num(lab, nan=0.0, posinf=0.0, neginf=0.0)
+        g[name + "/pool"] = pool_to(lab, 32)
+        g[name + "/sum"] = np.float64(lab.double().sum().item())
+        g[name + "/nnz"] = np.int64((lab > 0).sum().item())
+        g[name + "/rowsum"] = lab.double().sum(-1).numpy().astype(np.float32)
+        print(name, "nnz", g[name + "/nnz"], "sum", g[name + "/sum"], "pts", seen["pts"].tolist())
+    np.savez_compressed(os.path.join(OUT, "scale_labels.npz"), **g)
+
+
 CASES = {
     # name: (HW, B, frames, type, split, full-res frame (shrunk), seed)
     "argo_both_256_b2": (256, 2, [0, -1, 1], "Argo_both", "argo", (257, 308), 1),
@@ -277,9 +325,11 @@ CASES = {
 
 if __name__ == "__main__":
     net = import_reference()
-    want = sys.argv[1:] or (["unit"] + list(CASES))
+    want = sys.argv[1:] or (["unit", "scale_labels"] + list(CASES))
     for c in want:
         if c == "unit":
             unit_vectors(net)
+        elif c == "scale_labels":
+            scale_label_cases(net)
         else:
             run_case(net, c, *CASES[c][:6], seed=CASES[c][6])
