@@ -22,6 +22,10 @@ _CT = {
 }
 
 
+_PTR_DTYPE = {"float*": torch.float32, "double*": torch.float64, "int*": torch.int32, "int64_t*": torch.int64,
+              "long*": torch.int64, "uint8_t*": torch.uint8}
+
+
 class JPerceiverHipError(RuntimeError):
     pass
 
@@ -65,6 +69,9 @@ class _Lib:
                          else ctypes.c_long if ret == "long" else ctypes.c_int)
             self.fn[name] = f
         self.ptr_args = {name: [t.endswith("*") for t, _ in args] for name, (ret, args) in self.protos.items()}
+        # element type every pointer argument must have (None = untyped: void* scratch / stream)
+        self.ptr_dtypes = {name: [_PTR_DTYPE.get(t.replace("const ", "").strip()) if t.endswith("*") else None
+                                  for t, _ in args] for name, (ret, args) in self.protos.items()}
 
     def last_error(self) -> str:
         s = self.fn["jp_last_error_string"]()
@@ -81,21 +88,20 @@ def lib() -> _Lib:
     return _LIB
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
 def call(name: str, *args):
-    """Invoke a jp_* kernel launcher on torch's current stream.  Tensor arguments are passed as raw device
-    pointers (must be contiguous); None -> NULL.  The trailing `stream` argument is appended automatically."""
+    """Invoke a jp_* kernel launcher.  Tensor arguments are passed as raw device pointers (must be contiguous, of the
+    element type the ABI declares, and all on ONE device); None -> NULL.  The trailing `stream` argument is appended
+    automatically: torch's current stream OF THAT DEVICE (not of the process-wide current device)."""
     L = lib()
     f = L.fn[name]
     flags = L.ptr_args[name]
+    dtypes = L.ptr_dtypes[name]
     conv = []
     n_user = len(flags) - 1  # last is the stream
     if len(args) != n_user:
         raise TypeError(f"{name}: expected {n_user} arguments, got {len(args)}")
-    for a, is_ptr in zip(args, flags):
+    dev = None
+    for a, is_ptr, dt in zip(args, flags, dtypes):
         if is_ptr:
             if a is None:
                 conv.append(None)
@@ -104,12 +110,18 @@ def call(name: str, *args):
                     raise JPerceiverHipError(f"{name}: tensor argument is not on the GPU")
                 if not a.is_contiguous():
                     raise JPerceiverHipError(f"{name}: tensor argument is not contiguous")
+                if dt is not None and a.dtype != dt:
+                    raise JPerceiverHipError(f"{name}: tensor argument has dtype {a.dtype}, the ABI expects {dt}")
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise JPerceiverHipError(f"{name}: tensor arguments live on different devices ({dev} vs {a.device})")
                 conv.append(a.data_ptr())
             else:
                 conv.append(int(a))
         else:
             conv.append(a)
-    conv.append(_stream_ptr())
+    conv.append(torch.cuda.current_stream(dev).cuda_stream)
     rc = f(*conv)
     if rc != 0:
         raise JPerceiverHipError(f"{name} failed (rc={rc}): {L.last_error()}")

@@ -69,6 +69,8 @@ def build_optimizer(model, optimizer_cfg):
         skip = ("CycledViewProjectionB.", "CrossViewTransformerB.", "LayoutDecoderB.", "LayoutTransformDecoderB.")
     elif ty in ("dynamic", "Argo_dynamic"):
         skip = ("CycledViewProjection.", "CrossViewTransformer.", "LayoutDecoder.", "LayoutTransformDecoder.")
+    if hasattr(m, "opt") and not m.opt.get("layout_branch", True):     # bench.py's secondary sub-path figure only
+        skip = ("LayoutEncoder.", "CycledViewProjection", "CrossViewTransformer", "LayoutDecoder", "LayoutTransformDecoder")
     opt = FlatAdam(m, lr=cfg.get("lr", 1e-4), betas=tuple(cfg.get("betas", (0.9, 0.999))), eps=cfg.get("eps", 1e-8),
                    weight_decay=cfg.get("weight_decay", 0), skip_prefixes=skip)
     m._jp_arena = opt.arena

@@ -2,18 +2,31 @@
 (mono/core/utils/dist_utils.py:12-60): `allreduce_grads(model, coalesce, bucket_size_mb)` and
 `DistOptimizerHook(grad_clip, coalesce, bucket_size_mb).after_train_iter(runner)`.
 
-MI355X design: gradients already live in one flat arena, so there is nothing to flatten or copy back.
-The arena prefix holding live gradients is all-reduced (SUM) in a few large buckets over RCCL
-(torch.distributed backend "nccl" == RCCL on ROCm; xGMI is point-to-point, so few large messages
-beat many small ones); the 1/world_size scale is folded into the fused clip+Adam kernel, and the
-global-norm reduction runs on the reduced buffer (identical on every rank, so no extra collective).
-The reference's redundant second averaging through DDP is not reproduced.
+MI355X design.  Gradients already live in one flat arena whose live prefix is laid out in the order the
+backward pass finishes them (runtime.SEGMENT_ORDER), so there is nothing to flatten or copy back and a
+bucket is simply a slice:
+
+  * OVERLAP.  The step's tape fires `ops.grad_ready(segment)` right after a segment's last backward kernel
+    was enqueued.  The hook answers by launching that segment's SUM all-reduce (in <= bucket_size_mb pieces)
+    with `async_op=True` from the stream the tape is replaying on: RCCL's own stream picks the bucket up as
+    soon as those kernels finish and moves it over xGMI while the rest of the backward (the other branch,
+    the encoders) is still computing.  This is what the reference gets from the DDP reducer
+    (mono/apis/trainer.py:167); its second, redundant averaging pass is not reproduced.
+  * TWO-PHASE CLIP + ADAM.  As each bucket lands, stage 1 of the deterministic global-norm reduction runs
+    over it (`jp_grad_sumsq_partials`, overlapping the buckets still in flight); after the last one a single
+    tiny kernel folds the partials (`jp_sum_doubles`) and the fused clip+Adam pass updates the whole prefix.
+    The 1/world_size averaging rides along in that pass (grad_scale).  All ranks hold bit-identical reduced
+    gradients and the norm reduction has a fixed order, so every rank derives the same clip coefficient and
+    the replicas do not drift.
+  * xGMI is point-to-point (7 links per GPU), so a few large messages beat many small ones: 5 segments of
+    34-50 MB, split only above bucket_size_mb (default 64 MiB).
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from ..runtime import FlatAdam
 
 
@@ -25,22 +38,59 @@ def _arena_of(model_or_opt):
     return a
 
 
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _bucket_floats(bucket_size_mb):
+    return int((bucket_size_mb if bucket_size_mb and bucket_size_mb > 0 else 64) * 1024 * 1024 // 4)
+
+
+class _Exchange:
+    """One step's worth of in-flight bucket all-reduces over the arena's live prefix."""
+
+    def __init__(self, arena, bucket_size_mb=-1):
+        self.arena, self.bucket = arena, _bucket_floats(bucket_size_mb)
+        self.works = []                 # (work, offset, numel) in launch order
+        self.done = set()
+
+    def launch(self, seg: str):
+        """Start the all-reduce of one arena segment (idempotent).  Called from the tape (ops.grad_ready) with the
+        replaying stream current: async_op=True makes the collective wait for exactly the kernels enqueued so far
+        on that stream and run on the communicator's own stream from there."""
+        if seg in self.done or seg not in self.arena.segments:
+            return
+        self.done.add(seg)
+        off, n = self.arena.segments[seg]
+        for o in range(off, off + n, self.bucket):
+            k = min(self.bucket, off + n - o)
+            w = dist.all_reduce(self.arena.grads[o:o + k], op=dist.ReduceOp.SUM, async_op=True)
+            self.works.append((w, o, k))
+
+    def finish(self, with_norm: bool):
+        """Launch whatever the tape did not report, then wait bucket by bucket (in launch order) on the current stream
+        and fold each landed bucket into the global-norm partials while later buckets are still in flight."""
+        for seg in self.arena.segments:
+            self.launch(seg)
+        for w, o, k in self.works:
+            w.wait()
+            if with_norm:
+                self.arena.add_norm_partial(o, k)
+        self.works = []
+
+
 def allreduce_grads(model, coalesce=True, bucket_size_mb=-1, average_in_place=True):
-    """All-reduce the gradient arena across ranks.  bucket_size_mb <= 0 -> 64 MiB buckets."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """All-reduce the gradient arena across ranks (no overlap: every bucket is launched here).
+    bucket_size_mb <= 0 -> 64 MiB buckets."""
+    world = _world()
+    if world == 1:
         return
     arena = _arena_of(model)
-    world = dist.get_world_size()
-    n = arena.live_numel
-    bucket = int((bucket_size_mb if bucket_size_mb and bucket_size_mb > 0 else 64) * 1024 * 1024 // 4)
-    works = []
-    for off in range(0, n, bucket):
-        works.append(dist.all_reduce(arena.grads[off:min(n, off + bucket)], op=dist.ReduceOp.SUM, async_op=True))
-    for w in works:
-        w.wait()
+    ex = _Exchange(arena, bucket_size_mb)
+    ex.finish(with_norm=False)
     if average_in_place:
         from .._lib import call
-        call("jp_axpby", arena.grads, None, arena.grads, n, 1.0 / world, 0.0)
+        call("jp_axpby", arena.grads, None, arena.grads, arena.live_numel, 1.0 / world, 0.0)
 
 
 class DistOptimizerHook(object):
@@ -50,18 +100,29 @@ class DistOptimizerHook(object):
         self.bucket_size_mb = bucket_size_mb
 
     def after_train_iter(self, runner):
-        """zero_grad -> backward -> all-reduce -> clip -> Adam (dist_utils.py:54-60)."""
+        """zero_grad -> backward (+ overlapped all-reduce) -> global norm -> clip + Adam (dist_utils.py:54-60)."""
         opt = runner.optimizer
         opt.zero_grad()
-        runner.outputs["loss"].backward()
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        world = _world()
         if isinstance(opt, FlatAdam):
+            max_norm = self.grad_clip.get("max_norm") if self.grad_clip else None
+            ex = None
+            if world > 1:
+                ex = _Exchange(opt.arena, self.bucket_size_mb)
+                prev = ops.set_grad_ready_hook(ex.launch)
+                try:
+                    runner.outputs["loss"].backward()
+                finally:
+                    ops.set_grad_ready_hook(prev)
+                ex.finish(with_norm=bool(max_norm))
+            else:
+                runner.outputs["loss"].backward()
             # SUM all-reduce; the averaging rides along in the Adam pass (grad_scale)
-            allreduce_grads(runner.model, self.coalesce, self.bucket_size_mb, average_in_place=False)
             opt.grad_scale = 1.0 / world
-            opt.max_norm = self.grad_clip.get("max_norm") if self.grad_clip else None
+            opt.max_norm = max_norm
             opt.step()
         else:  # foreign optimizer object: keep the reference's literal sequence
+            runner.outputs["loss"].backward()
             allreduce_grads(runner.model, self.coalesce, self.bucket_size_mb)
             if self.grad_clip is not None:
                 torch.nn.utils.clip_grad_norm_(runner.model.parameters(), **self.grad_clip)

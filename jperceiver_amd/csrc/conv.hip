@@ -32,6 +32,116 @@ namespace {
 // unconditional global loads (no exec-mask save/restore per element).
 __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight packing.  The MFMA kernels read their A operand (the weights) from a packed copy whose layout depends on the
+// kernel family (5 layouts below).  A pack is a pure function of the weight tensor, so it only has to be redone when
+// the weights change -- once per training step, after the optimizer.  Every pack goes through do_pack(), which
+//   * launches it right away (ws_state 0 of the conv entry points: the caller's scratch holds nothing yet), and
+//   * appends a 64-byte job descriptor to the caller's host buffer while a recording is open (jp_pack_record_begin).
+// The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
+// launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
+// tiny launches per step become one.
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4 };
+struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
+    const float* w;
+    float* wp;
+    long total, begin;      // elements of this pack; prefix offset inside a replay table
+    int mode, p[6];
+};
+static_assert(sizeof(JpPackJob) == 64, "JpPackJob layout");
+
+// taps a (class, slot) pair of the parity-class form stands for: dy in [y0, y1], dx in [x0, x1]
+__device__ __forceinline__ float pack_slot_sum(const float* wc, int pl) {
+    const int a = pl >> 3, b = (pl >> 2) & 1, r = (pl >> 1) & 1, sx = pl & 1;
+    // Dy(a, r): a=0 -> {0} / {1,2};  a=1 -> {0,1} / {2}
+    const int y0 = a ? (r ? 2 : 0) : (r ? 1 : 0), y1 = a ? (r ? 2 : 1) : (r ? 2 : 0);
+    const int x0 = b ? (sx ? 2 : 0) : (sx ? 1 : 0), x1 = b ? (sx ? 2 : 1) : (sx ? 2 : 0);
+    float v = 0.f;
+    for (int dy = y0; dy <= y1; ++dy)
+        for (int dx = x0; dx <= x1; ++dx) v += wc[dy * 3 + dx];
+    return v;
+}
+
+__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w, long i, const int* p) {
+    switch (mode) {
+        case PACK_TAP: {       // p = Cout, Cin, KHW, Cp, for_dgrad: wp[tap][row][Cp], rows = Cout (fwd) / Cin (dgrad)
+            const int Cout = p[0], Cin = p[1], KHW = p[2], Cp = p[3], for_dgrad = p[4];
+            const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+            const int c = (int)(i % Cp);
+            const long t = i / Cp;
+            const int r = (int)(t % rows), tap = (int)(t / rows);
+            if (c >= red) return 0.f;
+            const int co = for_dgrad ? c : r, ci = for_dgrad ? r : c;
+            return w[((size_t)co * Cin + ci) * KHW + tap];
+        }
+        case PACK_ROWMAJOR: {  // p = Cout, Cin, KHW, CP, Kp: wp[m][k = tap*CP + c] (zero padded to Kp), stem convs
+            const int Cin = p[1], KHW = p[2], CP = p[3], Kp = p[4];
+            const int k = (int)(i % Kp), m = (int)(i / Kp);
+            const int tap = k / CP, c = k - tap * CP;
+            return (tap < KHW && c < Cin) ? w[((size_t)m * Cin + c) * KHW + tap] : 0.f;
+        }
+        case PACK_SEG: {       // p = Cout, Cin, c_off, C, Cp, up: one channel segment [c_off, c_off + C); full resolution
+                               // -> wp[tap][co][Cp]; upsampled -> wp[class][slot][co][Cp] (pre-summed taps)
+            const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], Cp = p[4], up = p[5];
+            const int c = (int)(i % Cp);
+            const long t = i / Cp;
+            const int co = (int)(t % Cout), pl = (int)(t / Cout);
+            if (c >= C) return 0.f;
+            const float* wc = w + ((size_t)co * Cin + c_off + c) * 9;
+            return up ? pack_slot_sum(wc, pl) : wc[pl];
+        }
+        case PACK_UP_DGRAD: {  // p = Cout, Cin, c_off, Cx, Cp: wpT[(class, slot)][c][co_pad] (dgrad A of the upsampled segment)
+            const int Cout = p[0], Cin = p[1], c_off = p[2], Cx = p[3], Cp = p[4];
+            const int co = (int)(i % Cp);
+            const long t = i / Cp;
+            const int c = (int)(t % Cx), pl = (int)(t / Cx);
+            if (co >= Cout) return 0.f;
+            return pack_slot_sum(w + ((size_t)co * Cin + c_off + c) * 9, pl);
+        }
+        default: {             // PACK_FLIP, p = Cout, Cin, c_off, C: wf[c][co][t] = w[co][c_off + c][8 - t]
+            const int Cout = p[0], Cin = p[1], c_off = p[2];
+            const int t = (int)(i % 9), co = (int)((i / 9) % Cout), c = (int)(i / (9 * (long)Cout));
+            return w[((size_t)co * Cin + c_off + c) * 9 + 8 - t];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_one_kernel(JpPackJob job) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < job.total; i += (long)gridDim.x * 256)
+        job.wp[i] = pack_elem(job.mode, job.w, i, job.p);
+}
+
+// every pack of the model in one launch: workgroup-sized pieces of the concatenated element range, job found by
+// binary search over the prefix offsets (wave-uniform: a 256-element piece never straddles ... it may: per-thread search)
+__global__ __launch_bounds__(256) void pack_replay_kernel(const JpPackJob* __restrict__ jobs, int njobs, long total) {
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].begin <= g) lo = mid; else hi = mid - 1;
+        }
+        const JpPackJob& j = jobs[lo];
+        j.wp[g - j.begin] = pack_elem(j.mode, j.w, g - j.begin, j.p);
+    }
+}
+
+thread_local JpPackJob* g_pack_rec = nullptr;
+thread_local int g_pack_rec_n = 0, g_pack_rec_cap = 0;
+
+void do_pack(int mode, const float* w, float* wp, long total, int p0, int p1, int p2, int p3, int p4, int p5, hipStream_t st) {
+    JpPackJob j{w, wp, total, 0, mode, {p0, p1, p2, p3, p4, p5}};
+    if (g_pack_rec) {
+        if (g_pack_rec_n < g_pack_rec_cap) g_pack_rec[g_pack_rec_n] = j;
+        ++g_pack_rec_n;      // counted even when the buffer is full: jp_pack_record_end reports the overflow
+    }
+    hipLaunchKernelGGL(pack_one_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, j);
+}
+
+void pack_weights(const float* w, float* wp, int Cout, int Cin, int KHW, int Cp, int for_dgrad, hipStream_t st) {
+    do_pack(PACK_TAP, w, wp, (long)KHW * (for_dgrad ? Cin : Cout) * Cp, Cout, Cin, KHW, Cp, for_dgrad, 0, st);
+}
+
+
 struct Src3 {  // input as up to 3 channel segments, each optionally stored at half resolution
     const float *p0, *p1, *p2;
     int e0, e1, e2;     // cumulative channel ends
@@ -615,16 +725,6 @@ struct FwdBC {  // B[k=(tap, c)][n=pixel], zero padding, single full-resolution 
     __device__ __forceinline__ bool all_ok(const St& st) const { return __all(st.ok == ((1u << TPC) - 1u)); }
     __device__ __forceinline__ float post(const St& st, float v, int r) const { return ((st.ok >> (r / CP)) & 1u) ? v : 0.f; }
 };
-// wp[m][k = tap*CP + c] (zero padded to Kp)
-__global__ void pack_weights_rowmajor_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KHW,
-                                             int CP, int Kp) {
-    const int total = Cout * Kp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int k = i % Kp, m = i / Kp;
-        const int tap = k / CP, c = k - tap * CP;
-        wp[i] = (tap < KHW && c < Cin) ? w[((size_t)m * Cin + c) * KHW + tap] : 0.f;
-    }
-}
 
 // ---- Upsample-aware 3x3 reflect conv (iconv layers: cat(reduce, up2x(x), disp), depth_decoder.py:68,76-77).
 // For the nearest-2x upsampled segment U = up(X) an output pixel (2i+a, 2j+b) sees only a 2x2 patch of X through its
@@ -756,34 +856,6 @@ struct FwdEpiP {  // y[img][co][2i+a][2j+b] = act(acc + bias[co])
     }
 };
 
-// packed weights of one channel segment [c_off, c_off + C): full-resolution -> wp[tap][co][Cp]; upsampled ->
-// wp[class][slot][co][Cp] with the taps each (class, slot) pair stands for summed
-__global__ void pack_weights_seg_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int c_off,
-                                        int C, int Cp, int up) {
-    const int planes = up ? 16 : 9;
-    const long total = (long)planes * Cout * Cp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cp);
-        const long t = i / Cp;
-        const int co = (int)(t % Cout);
-        const int pl = (int)(t / Cout);
-        float v = 0.f;
-        if (c < C) {
-            const float* wc = w + ((size_t)co * Cin + c_off + c) * 9;
-            if (!up) {
-                v = wc[pl];
-            } else {
-                const int a = pl >> 3, b = (pl >> 2) & 1, r = (pl >> 1) & 1, sx = pl & 1;
-                // Dy(a, r): a=0 -> {0} / {1,2};  a=1 -> {0,1} / {2}
-                const int y0 = a ? (r ? 2 : 0) : (r ? 1 : 0), y1 = a ? (r ? 2 : 1) : (r ? 2 : 0);
-                const int x0 = b ? (sx ? 2 : 0) : (sx ? 1 : 0), x1 = b ? (sx ? 2 : 1) : (sx ? 2 : 0);
-                for (int dy = y0; dy <= y1; ++dy)
-                    for (int dx = x0; dx <= x1; ++dx) v += wc[dy * 3 + dx];
-            }
-        }
-        wp[i] = v;
-    }
-}
 
 // ---- wgrad of the upsampled segment in the same parity-class form: dW'_{class}[slot][co][c] = sum over the class's
 // output pixels of dY[co][2i+a][2j+b] * X[c][clamp(i-1+a+r)][clamp(j-1+b+s)]  (GEMM M=co, N=(class, slot, c), K = class
@@ -1003,27 +1075,6 @@ struct DgradEdgeEpi {  // dx[img][c][y][x] += acc for the boundary pixel b of a 
         if (base >= 0) atomicAdd(dx + base + (size_t)m * h * w, v);
     }
 };
-// wpT[(class, slot)][c][co_pad] = W'_{class}[slot][co][c]  (dgrad A operand of the upsampled segment)
-__global__ void pack_weights_up_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int c_off,
-                                             int Cx, int Cp) {
-    const long total = 16L * Cx * Cp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cp);
-        const long t = i / Cp;
-        const int c = (int)(t % Cx);
-        const int pl = (int)(t / Cx);
-        float v = 0.f;
-        if (co < Cout) {
-            const float* wc = w + ((size_t)co * Cin + c_off + c) * 9;
-            const int a = pl >> 3, b = (pl >> 2) & 1, r = (pl >> 1) & 1, sx = pl & 1;
-            const int y0 = a ? (r ? 2 : 0) : (r ? 1 : 0), y1 = a ? (r ? 2 : 1) : (r ? 2 : 0);
-            const int x0 = b ? (sx ? 2 : 0) : (sx ? 1 : 0), x1 = b ? (sx ? 2 : 1) : (sx ? 2 : 0);
-            for (int dy = y0; dy <= y1; ++dy)
-                for (int dx = x0; dx <= x1; ++dx) v += wc[dy * 3 + dx];
-        }
-        wp[i] = v;
-    }
-}
 
 // ---- 3x3 stride-2 pad-1 dgrad (ResNet downsampling convs), parity-class form.  An input pixel (y, x) is reached only
 // through taps with ty = y+1 (mod 2), tx = x+1 (mod 2): 1, 2, 2 or 4 of the 9.  Input pixels are enumerated class-major
@@ -1531,24 +1582,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_wide_kernel(const float* __
 }
 
 // wp[tap][row][Cp]: forward rows = co (src W[co][ci][tap]); dgrad rows = ci, reduction = co
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KHW,
-                                    int Cp, int for_dgrad) {
-    const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
-    const long total = (long)KHW * rows * Cp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cp);
-        const long t = i / Cp;
-        const int r = (int)(t % rows);
-        const int tap = (int)(t / rows);
-        float v = 0.f;
-        if (c < red) {
-            const int co = for_dgrad ? c : r, ci = for_dgrad ? r : c;
-            v = w[((size_t)co * Cin + ci) * KHW + tap];
-        }
-        wp[i] = v;
-    }
-}
-
 constexpr int KC = 32;
 
 // split-K plan of a wgrad GEMM (M x Np, K = npix): workgroups run in rounds of `slots` = 256 CUs x per_cu; a split
@@ -1582,7 +1615,9 @@ inline WgradPlan wgrad_plan(int M, int Np, long npix, int BM, int BN, int per_cu
 template <bool IL, int WM, int WN, class A, class B, class E>
 void launch(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStream_t st) {
     dim3 grid(jp_cdiv(N, 64 * WN), jp_cdiv(M, 64 * WM), splits);
+    jp_prof_before(__PRETTY_FUNCTION__, 2.0 * M * (double)N * K, st);
     hipLaunchKernelGGL((jp_igemm_kernel<WM, WN, KC, A, B, E, false, IL>), grid, dim3(64 * WM * WN), 0, st, a, b, e, M, N, K, kps);
+    jp_prof_after(st);
 }
 
 template <bool IL = false, class A, class B, class E>
@@ -1595,7 +1630,9 @@ void launch_auto(A a, B b, E e, int M, int N, int K, int splits, int kps, hipStr
 template <int WM, int WN, class A, class B, class E>
 void launch_r3(A a, B b, E e, int M, int N, int K, hipStream_t st) {
     dim3 grid(N / (64 * WN), jp_cdiv(M, 64 * WM), 1);
+    jp_prof_before(__PRETTY_FUNCTION__, 2.0 * M * (double)N * K, st);
     hipLaunchKernelGGL((jp_igemm_r3_kernel<WM, WN, KC, A, B, E>), grid, dim3(256), 0, st, a, b, e, M, N, K);
+    jp_prof_after(st);
 }
 
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
@@ -1623,12 +1660,6 @@ inline bool seg_aligned(int c0, int c1, int c2) {   // every segment end except 
     if (c0 % 32) return false;
     if (c2 != 0 && (c0 + c1) % 32) return false;
     return true;
-}
-
-void pack_weights(const float* w, float* wp, int Cout, int Cin, int KHW, int Cp, int for_dgrad, hipStream_t st) {
-    const long total = (long)KHW * (for_dgrad ? Cin : Cout) * Cp;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, w, wp,
-                       Cout, Cin, KHW, Cp, for_dgrad);
 }
 
 }  // namespace
@@ -1680,7 +1711,8 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
 extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
                                   const float* x2, int c2, int up2, const float* w, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int KH, int stride, int pad, int pad_mode, int act,
-                                  float* ws, float* split_ws, void* stream) {
+                                  float* ws, int ws_state, float* split_ws, void* stream) {
+    // ws_state: 0 = pack the weights into ws now; 1 = ws already holds this layer's pack (refreshed by jp_pack_replay)
     JP_CHECK_ARG(x0 && w && y, "conv2d_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && c0 > 0 && stride >= 1, "conv2d_fwd: bad dims");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && (pad >= H || pad >= W)), "conv2d_fwd: reflect pad >= size");
@@ -1705,8 +1737,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         // stem convs: whole taps per K chunk
         const int CP = Cin <= 4 ? 4 : 8;
         const int Kp = jp_cdiv(KH * KH * CP, KC) * KC;
-        hipLaunchKernelGGL(pack_weights_rowmajor_kernel, dim3(jp_cdiv(Cout * Kp, 256)), dim3(256), 0, st, w, ws, Cout, Cin, KH * KH,
-                           CP, Kp);
+        if (!ws_state) do_pack(PACK_ROWMAJOR, w, ws, (long)Cout * Kp, Cout, Cin, KH * KH, CP, Kp, 0, st);
         PackARow a{ws, Kp};
 #define JP_BC(KHv, CPv)                                                          \
     {                                                                            \
@@ -1735,8 +1766,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                 O[i] = (int)off;
                 if (cs[i]) {
                     const long tot = (long)(us[i] ? 16 : 9) * Cout * P[i];
-                    hipLaunchKernelGGL(pack_weights_seg_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0,
-                                       st, w, ws + off, Cout, Cin, (i == 0 ? 0 : (i == 1 ? c0 : c0 + c1)), cs[i], P[i], us[i]);
+                    if (!ws_state) do_pack(PACK_SEG, w, ws + off, tot, Cout, Cin, (i == 0 ? 0 : (i == 1 ? c0 : c0 + c1)), cs[i], P[i], us[i], st);
                     off += tot;
                 }
             }
@@ -1751,7 +1781,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     }
     if (ws && Cin >= 16 && seg_aligned(c0, c1, c2)) {   // tap-major fast path (16-channel inputs: half-empty K chunks)
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
-        pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
+        if (!ws_state) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
         PackA a{ws, Cout, Kp, Cp, KH * KH};
         const int sp = small_grid_splits(Cout, npix, Kp);
         if (sp > 1) {
@@ -1825,9 +1855,9 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
 
 extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
                              int W, int Cout, int KH, int stride, int pad, int pad_mode, int act, float* ws,
-                             float* split_ws, void* stream) {
+                             int ws_state, float* split_ws, void* stream) {
     return jp_conv2d_fwd_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, w, bias, y, N, H, W, Cout, KH, stride, pad,
-                              pad_mode, act, ws, split_ws, stream);
+                              pad_mode, act, ws, ws_state, split_ws, stream);
 }
 
 // same for jp_conv2d_dgrad's `split_ws`
@@ -1856,8 +1886,8 @@ extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cou
 }
 
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
-                               int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, float* split_ws,
-                               void* stream) {
+                               int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, int ws_state,
+                               float* split_ws, void* stream) {
     JP_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && !(KH == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2)),
                  "conv2d_dgrad: reflect mode supports 3x3 stride 1 pad 1 only");
@@ -1868,7 +1898,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     DgradEpi e{dx, Cin, H * W, accumulate};
     if (ws && Cout >= 16) {
         const int Cp = pad32(Cout), Kp = KH * KH * Cp;
-        pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
+        if (!ws_state) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
         PackA a{ws, Cin, Kp, Cp, KH * KH};
         const int sp = small_grid_splits(Cin, npix, Kp);
         const long Nc = (long)N * (H / 2) * (W / 2);
@@ -1955,14 +1985,6 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     JP_LAUNCH_CHECK();
 }
 
-// wf[c][co][t] = w[co][c_off + c][8 - t]: the dgrad of a few input channels as a direct small-Cout correlation of dY
-__global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin, int c_off, int C) {
-    const int total = C * Cout * 9;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int t = i % 9, co = (i / 9) % Cout, c = i / (9 * Cout);
-        wf[i] = w[((size_t)co * Cin + c_off + c) * 9 + 8 - t];
-    }
-}
 
 // per-source dgrad of a conv whose input is the channel concat of up to 3 sources, one of them read through the fused
 // nearest-2x upsample: gradients go straight into the sources' own buffers (dx_s: (N, c_s, H, W), or (N, c_s, H/2, W/2)
@@ -1983,7 +2005,8 @@ extern "C" int jp_conv2d_dgrad_src3_ok(int c0, int up0, int c1, int up1, int c2,
 }
 extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
                                     int c1, int up1, int acc1, float* dx2, int c2, int up2, int acc2, int N, int H, int W,
-                                    int Cout, int KH, int stride, int pad, int pad_mode, float* ws, void* stream) {
+                                    int Cout, int KH, int stride, int pad, int pad_mode, float* ws, int ws_state,
+                                    void* stream) {
     JP_CHECK_ARG(dy && w, "conv2d_dgrad_src3: null pointer");
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
         if (dx0) jp_up_head_dgrad(dy, w, dx0, N, c0, H / 2, W / 2, acc0, (hipStream_t)stream);
@@ -1997,7 +2020,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
     const long npix = (long)N * H * W;
     float* dxs[3] = {dx0, dx1, dx2};
     const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2}, accs[3] = {acc0, acc1, acc2};
-    pack_weights(w, ws, Cout, Cin, 9, Cp, 1, st);                 // [tap][ci][Cp] for the full-resolution segments
+    if (!ws_state) pack_weights(w, ws, Cout, Cin, 9, Cp, 1, st);  // [tap][ci][Cp] for the full-resolution segments
     float* wsT = ws + ((size_t)9 * Cin + 256) * Cp;               // [16][Cx][Cp] for the upsampled one
     const int cx_up = up0 ? c0 : (up1 ? c1 : c2);
     DgradBT<3, true> b{dy, Cp, (int)npix, H, W, Cout, H, W, 1, 1, 1};
@@ -2012,7 +2035,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
                 // a few channels (the disparity channel): direct zero-pad correlation of dY with the flipped taps
                 // instead of a 64-row MFMA tile; the reflection fold still comes from the border pass below
                 float* wf = wsT + (16L * cx_up + 256) * Cp;     // behind the upsampled segment's pack (+ its slack)
-                hipLaunchKernelGGL(flip_weights_kernel, dim3(jp_cdiv(C * Cout * 9, 256)), dim3(256), 0, st, w, wf, Cout, Cin, coff, C);
+                if (!ws_state) do_pack(PACK_FLIP, w, wf, (long)C * Cout * 9, Cout, Cin, coff, C, 0, 0, st);
                 jp_conv_small_fwd(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, wf, nullptr, dx, N, H, W, C, JP_ACT_NONE, 0, st,
                                   accs[sidx]);
             } else {
@@ -2036,8 +2059,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
         } else if (dx) {
             const int h2 = H / 2, w2 = W / 2, KpU = 16 * Cp;
             const long tot = 16L * C * Cp, np2 = (long)N * h2 * w2;
-            hipLaunchKernelGGL(pack_weights_up_dgrad_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, w,
-                               wsT, Cout, Cin, coff, C, Cp);
+            if (!ws_state) do_pack(PACK_UP_DGRAD, w, wsT, tot, Cout, Cin, coff, C, Cp, 0, st);
             PackA a{wsT, C, KpU, Cp, 16};
             DgradUPB bu{dy, (int)np2, h2, w2, Cout};
             DgradEpi e{dx, C, h2 * w2, accs[sidx]};
@@ -2307,4 +2329,29 @@ extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout
     const bool narrow = Cout <= 64 && Cin <= 64;
     const WgradPlan p = wgrad_plan(Cout, Np, (long)N * pad32(OH * OW), narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
     return p.use_ws ? p.ws_need : 0;
+}
+
+// ---- weight-pack recording / replay (see do_pack).  `host_jobs`: caller-owned HOST buffer of max_jobs 64-byte records.
+extern "C" int jp_pack_job_bytes(void) { return (int)sizeof(JpPackJob); }
+
+extern "C" int jp_pack_record_begin(void* host_jobs, int max_jobs) {
+    JP_CHECK_ARG(host_jobs && max_jobs > 0 && !g_pack_rec, "pack_record_begin: bad args or a recording is already open");
+    g_pack_rec = (JpPackJob*)host_jobs;
+    g_pack_rec_n = 0;
+    g_pack_rec_cap = max_jobs;
+    return JP_OK;
+}
+
+// -> number of packs the conv entry points issued on this thread since jp_pack_record_begin (> max_jobs: overflow)
+extern "C" int jp_pack_record_end(void) {
+    g_pack_rec = nullptr;
+    return g_pack_rec_n;
+}
+
+// jobs: DEVICE copy of `njobs` records whose `begin` fields hold the exclusive prefix sum of `total`; total_elems = the sum.
+extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, void* stream) {
+    JP_CHECK_ARG(jobs && njobs > 0 && total_elems > 0, "pack_replay: bad args");
+    hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 1023) / 1024, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
+    JP_LAUNCH_CHECK();
 }

@@ -7,6 +7,9 @@
 #define JP_EBADARG (-1)
 
 extern "C" void jp_set_last_error(const char* msg);
+// opt-in per-kernel profiler (capi.cpp): no-ops unless jp_profile_begin() opened a profile
+void jp_prof_before(const char* tag, double flops, hipStream_t st);
+void jp_prof_after(hipStream_t st);
 
 #define JP_CHECK_ARG(cond, msg)                         \
     do {                                                \

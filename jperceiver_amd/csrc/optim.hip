@@ -12,7 +12,14 @@ namespace {
 
 constexpr int TPB = 256;
 
-__global__ __launch_bounds__(TPB) void sumsq_kernel(const float* __restrict__ g, double* __restrict__ out, long n) {
+// Deterministic global-norm reduction (two stages, no atomics): stage 1 writes one double per block -- the block's
+// grid-stride share of g, reduced in a fixed order -- stage 2 sums any number of such partials in a fixed order.
+// Every rank of a data-parallel job therefore derives bit-identical clip coefficients from its (bit-identical)
+// all-reduced gradients, run after run (the cross-block atomicAdd this replaces depended on block completion order).
+constexpr int SUMSQ_BLOCKS = 256;
+
+__global__ __launch_bounds__(TPB) void sumsq_partial_kernel(const float* __restrict__ g, double* __restrict__ partials,
+                                                            long n) {
     __shared__ double sm[4];
     double s = 0.0;
     float fs = 0.f;
@@ -27,7 +34,15 @@ __global__ __launch_bounds__(TPB) void sumsq_kernel(const float* __restrict__ g,
     for (long i = (n4 << 2) + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) fs += g[i] * g[i];
     s += fs;
     s = jp_block_sum_d(s, sm);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(TPB) void sum_doubles_kernel(const double* __restrict__ in, double* __restrict__ out, int count) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += TPB) s += in[i];
+    s = jp_block_sum_d(s, sm);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps), with g scaled by grad_scale * min(1, max_norm/(norm+1e-6))
@@ -103,12 +118,21 @@ inline int blocks_for(long n) { return (int)std::min<long>((n + TPB * 4 - 1) / (
 
 #define JP_ST hipStream_t st = (hipStream_t)stream
 
-// out (1 double) += sum g^2 (zeroed first unless accumulate)
-extern "C" int jp_grad_sumsq(const float* g, double* out, long n, int accumulate, void* stream) {
-    JP_CHECK_ARG(g && out && n > 0 && ((uintptr_t)g & 15) == 0, "grad_sumsq: bad args (16-B aligned arena required)");
+// Stage 1 of the global gradient norm over one bucket g[0..n): writes jp_sumsq_blocks() doubles to `partials`.
+extern "C" int jp_sumsq_blocks(void) { return SUMSQ_BLOCKS; }
+
+extern "C" int jp_grad_sumsq_partials(const float* g, double* partials, long n, void* stream) {
+    JP_CHECK_ARG(g && partials && n > 0 && ((uintptr_t)g & 15) == 0, "grad_sumsq_partials: bad args (16-B aligned bucket required)");
     JP_ST;
-    if (!accumulate) JP_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, g, out, n);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(TPB), 0, st, g, partials, n);
+    JP_LAUNCH_CHECK();
+}
+
+// Stage 2: out[0] = sum of `count` doubles in a fixed order (all buckets' partials -> the squared global norm).
+extern "C" int jp_sum_doubles(const double* in, double* out, int count, void* stream) {
+    JP_CHECK_ARG(in && out && count > 0, "sum_doubles: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(TPB), 0, st, in, out, count);
     JP_LAUNCH_CHECK();
 }
 

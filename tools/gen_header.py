@@ -12,8 +12,10 @@ GROUPS = [
      + R + "resnet.py:6-13,91; " + R + "layers.py:147-167; " + R + "depth_decoder.py:15-39; " + R + "pose_decoder.py:9-12; "
      + R + "layout_model.py:31-47,138-153; " + R + "CrossViewTransformer.py:30-42.  *_src3: the input is the channel concat of up to 3 "
      "tensors, each optionally stored at half resolution (fused F.interpolate(scale_factor=2,'nearest') + torch.cat, "
-     + R + "depth_decoder.py:68,76-77).  pad_mode 0=zero 1=reflect; act 0=none 1=relu 2=leaky_relu(0.01) 3=sigmoid.",
-     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum"]),
+     + R + "depth_decoder.py:68,76-77).  pad_mode 0=zero 1=reflect; act 0=none 1=relu 2=leaky_relu(0.01) 3=sigmoid.  ws / ws_state: caller scratch for the packed weights "
+     "(jp_conv2d_ws_floats) and whether it already holds this layer's pack (1) or must be packed by this call (0); packs recorded with "
+     "jp_pack_record_begin/end can be refreshed for the whole model by one jp_pack_replay launch per step.",
+     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
     ("Train-mode BatchNorm2d (+fused residual add / ReLU) — " + R + "resnet.py:21-24,41-45,92; " + R + "layout_model.py:146,152. "
      "ws = jp_bn_ws_doubles(N, C, HW) doubles of caller scratch.  n_updates = number of momentum updates of the running stats (2 for the layout "
      "branch the reference evaluates twice, " + R + "net.py:73-74).",
@@ -43,8 +45,11 @@ GROUPS = [
     ("Optimizer over flat arenas + RNG — clip_grads(max_norm=35)+Adam mono/core/utils/dist_utils.py:58-60, "
      "config/cfg_kitti_baseline_odometry_boundary_ce_iou_1024_20.py:69-70; Dropout / randn " + R + "depth_decoder.py:13, "
      + R + "net.py:163.",
-     ["jp_grad_sumsq", "jp_adam_clip_step", "jp_rng_keep_mask", "jp_rng_normal"]),
-    ("Library plumbing.", ["jp_abi_version", "jp_last_error_string", "jp_set_last_error"]),
+     ["jp_sumsq_blocks", "jp_grad_sumsq_partials", "jp_sum_doubles", "jp_adam_clip_step", "jp_rng_keep_mask", "jp_rng_normal"]),
+    ("Library plumbing.  jp_profile_*: opt-in per-kernel HIP-event timing of the implicit-GEMM launches on the streams they "
+     "are launched on (bench.py's roofline leg; never active in the train step).",
+     ["jp_abi_version", "jp_last_error_string", "jp_set_last_error", "jp_profile_begin", "jp_profile_count", "jp_profile_end",
+      "jp_profile_get"]),
 ]
 
 
