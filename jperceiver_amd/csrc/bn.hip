@@ -22,11 +22,21 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__
     double s = 0.0, q = 0.0;
     float fs = 0.f, fq = 0.f;
     int run = 0;
-    for (int i = beg + threadIdx.x; i < end; i += TPB) {
-        const float v = xp[i];
-        fs += v;
-        fq += v * v;
-        if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+    if (((HW | chunk) & 3) == 0) {      // 16 B per lane: planes and chunks are float4-aligned
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        for (int i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += TPB) {
+            const float4 v = x4[i];
+            fs += (v.x + v.y) + (v.z + v.w);
+            fq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            if (++run == 8) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+        }
+    } else {
+        for (int i = beg + threadIdx.x; i < end; i += TPB) {
+            const float v = xp[i];
+            fs += v;
+            fq += v * v;
+            if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+        }
     }
     s += fs; q += fq;
     s = jp_block_sum_d(s, sm);
@@ -68,6 +78,34 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __res
     }
 }
 
+// The normalised value is ALWAYS formed as fmaf(x, sc, sh) with sc = invstd*gamma, sh = beta - mean*sc: the backward
+// kernels re-evaluate exactly this expression to recover the ReLU mask of residual-free layers instead of reading y.
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return fmaf(x, sc, sh); }
+__device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return fmaf(-mean, sc, beta); }
+
+__device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* __restrict__ residual,
+                                              float* __restrict__ y, float sc, float sh, size_t base, int HW, int relu) {
+    if ((HW & 3) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* r4 = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
+        float4* y4 = reinterpret_cast<float4*>(y + base);
+        for (int i = blockIdx.x * TPB + threadIdx.x; i < (HW >> 2); i += gridDim.x * TPB) {
+            const float4 a = x4[i];
+            float4 v = make_float4(bn_affine(a.x, sc, sh), bn_affine(a.y, sc, sh), bn_affine(a.z, sc, sh), bn_affine(a.w, sc, sh));
+            if (r4) { const float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            y4[i] = v;
+        }
+    } else {
+        for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+            float v = bn_affine(x[base + i], sc, sh);
+            if (residual) v += residual[base + i];
+            if (relu) v = fmaxf(v, 0.f);
+            y[base + i] = v;
+        }
+    }
+}
+
 // y = relu?( (x-mean)*invstd*gamma + beta (+ residual) )
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
@@ -78,14 +116,8 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
     const int nc = blockIdx.y;  // n*C + c
     const int c = nc % C;
     const float sc = invstd[c] * gamma[c];
-    const float sh = beta[c] - mean[c] * sc;
-    const size_t base = (size_t)nc * HW;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
-        float v = x[base + i] * sc + sh;
-        if (residual) v += residual[base + i];
-        if (relu) v = v > 0.f ? v : 0.f;
-        y[base + i] = v;
-    }
+    const float sh = bn_shift(beta[c], mean[c], sc);
+    bn_apply_body(x, residual, y, sc, sh, (size_t)nc * HW, HW, relu);
 }
 
 // eval mode: y = relu?( (x-running_mean)/sqrt(running_var+eps)*gamma + beta (+ residual) )
@@ -97,22 +129,19 @@ __global__ __launch_bounds__(TPB) void bn_eval_kernel(const float* __restrict__ 
     const int nc = blockIdx.y;
     const int c = nc % C;
     const float sc = gamma[c] / sqrtf(rv[c] + eps);
-    const float sh = beta[c] - rm[c] * sc;
-    const size_t base = (size_t)nc * HW;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
-        float v = x[base + i] * sc + sh;
-        if (residual) v += residual[base + i];
-        if (relu) v = v > 0.f ? v : 0.f;
-        y[base + i] = v;
-    }
+    const float sh = bn_shift(beta[c], rm[c], sc);
+    bn_apply_body(x, residual, y, sc, sh, (size_t)nc * HW, HW, relu);
 }
 
-// backward reduction: per channel sum(dyr), sum(dyr * xhat) with dyr = dy * (y > 0) when relu
+// backward reduction: per channel sum(dyr), sum(dyr * xhat) with dyr = dy * (y > 0) when relu.
+// y == nullptr with relu: residual-free layer, the mask is recomputed as bn_affine(x) > 0 (one tensor read less).
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restrict__ dy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ y,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
                                                             double* __restrict__ sums, int C, int HW, int CH,
                                                             int chunk, int relu) {
     __shared__ double sm[4];
@@ -121,17 +150,35 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restr
     const int beg = ck * chunk, end = min(HW, beg + chunk);
     const size_t base = ((size_t)n * C + c) * HW;
     const float mu = mean[c], is = invstd[c];
+    const float sc = is * gamma[c], sh = bn_shift(beta[c], mu, sc);
     double s = 0.0, q = 0.0;
     float fs = 0.f, fq = 0.f;
     int run = 0;
-    for (int i = beg + threadIdx.x; i < end; i += TPB) {
-        const size_t o = base + i;
-        float g = dy[o];
-        if (relu && !(y[o] > 0.f)) g = 0.f;
-        fs += g;
-        fq += g * (x[o] - mu) * is;
-        if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+#define JP_BN_RED1(G, X, Yv)                                              \
+    {                                                                     \
+        float g_ = (G);                                                   \
+        if (relu && !((y ? (Yv) : bn_affine((X), sc, sh)) > 0.f)) g_ = 0.f; \
+        fs += g_;                                                         \
+        fq += g_ * ((X) - mu) * is;                                       \
     }
+    if (((HW | chunk) & 3) == 0) {
+        const float4* d4 = reinterpret_cast<const float4*>(dy + base);
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* y4 = y ? reinterpret_cast<const float4*>(y + base) : nullptr;
+        for (int i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += TPB) {
+            const float4 d = d4[i], a = x4[i];
+            const float4 yy = y4 ? y4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            JP_BN_RED1(d.x, a.x, yy.x) JP_BN_RED1(d.y, a.y, yy.y) JP_BN_RED1(d.z, a.z, yy.z) JP_BN_RED1(d.w, a.w, yy.w)
+            if (++run == 8) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+        }
+    } else {
+        for (int i = beg + threadIdx.x; i < end; i += TPB) {
+            const size_t o = base + i;
+            JP_BN_RED1(dy[o], x[o], y[o])
+            if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+        }
+    }
+#undef JP_BN_RED1
     s += fs; q += fq;
     s = jp_block_sum_d(s, sm);
     q = jp_block_sum_d(q, sm);
@@ -147,6 +194,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const double* __restrict__ sums, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C, int HW, double count,
@@ -154,6 +202,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
     const int nc = blockIdx.y;
     const int c = nc % C;
     const float mu = mean[c], is = invstd[c], g = gamma[c];
+    const float sc = is * g, sh = bn_shift(beta[c], mu, sc);
     __shared__ double tot[2];
     if (threadIdx.x < 64) {   // one wave sums the partials (fixed order), the rest of the workgroup waits
         double a = 0.0, b = 0.0;
@@ -174,13 +223,38 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
         dbeta[c] = acc_param_grads ? dbeta[c] + db : db;
     }
     const size_t base = (size_t)nc * HW;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
-        float d = dy[base + i];
-        if (relu && !(y[base + i] > 0.f)) d = 0.f;
-        if (dres) dres[base + i] = d;
-        const float xh = (x[base + i] - mu) * is;
-        dx[base + i] = g * is * (d - k1 - xh * k2);
+    const float gi = g * is;
+#define JP_BN_APP1(D, X, Yv, OUT, RES)                                     \
+    {                                                                      \
+        float d_ = (D);                                                    \
+        if (relu && !((y ? (Yv) : bn_affine((X), sc, sh)) > 0.f)) d_ = 0.f; \
+        RES = d_;                                                          \
+        OUT = gi * (d_ - k1 - ((X) - mu) * is * k2);                       \
     }
+    if ((HW & 3) == 0) {
+        const float4* d4 = reinterpret_cast<const float4*>(dy + base);
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* y4 = y ? reinterpret_cast<const float4*>(y + base) : nullptr;
+        float4* o4 = reinterpret_cast<float4*>(dx + base);
+        float4* r4 = dres ? reinterpret_cast<float4*>(dres + base) : nullptr;
+        for (int i = blockIdx.x * TPB + threadIdx.x; i < (HW >> 2); i += gridDim.x * TPB) {
+            const float4 d = d4[i], a = x4[i];
+            const float4 yy = y4 ? y4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o, r;
+            JP_BN_APP1(d.x, a.x, yy.x, o.x, r.x) JP_BN_APP1(d.y, a.y, yy.y, o.y, r.y)
+            JP_BN_APP1(d.z, a.z, yy.z, o.z, r.z) JP_BN_APP1(d.w, a.w, yy.w, o.w, r.w)
+            o4[i] = o;
+            if (r4) r4[i] = r;
+        }
+    } else {
+        for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
+            float o, r;
+            JP_BN_APP1(dy[base + i], x[base + i], y[base + i], o, r)
+            dx[base + i] = o;
+            if (dres) dres[base + i] = r;
+        }
+    }
+#undef JP_BN_APP1
 }
 
 // generic per-channel sum over (N, HW): out[c] (+)= sum  — conv bias gradients
@@ -233,26 +307,26 @@ extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* 
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(jp_cdiv(C, 64)), dim3(64), 0, st, ws, save_mean, save_invstd,
                        running_mean, running_var, C, (double)N * HW, momentum, eps, n_updates, N * CH);
-    const int gx = std::min(jp_cdiv(HW, TPB), 64);
+    const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, save_mean, save_invstd, gamma, beta,
                        residual, y, C, HW, relu);
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, float* dx, float* dres,
                                float* dgamma, float* dbeta, double* ws, int N, int C, int HW, int relu,
                                int acc_param_grads, void* stream) {
-    JP_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
-    JP_CHECK_ARG(!relu || y, "bn_train_bwd: relu needs the forward output");
+    JP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
+    // y == NULL with relu: legal only for layers WITHOUT a residual input (the mask is recomputed from x)
     hipStream_t st = (hipStream_t)stream;
     int CH, chunk;
     chunking(N, C, HW, &CH, &chunk);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, ws, C,
-                       HW, CH, chunk, relu);
-    const int gx = std::min(jp_cdiv(HW, TPB), 64);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, gamma,
+                       beta, ws, C, HW, CH, chunk, relu);
+    const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, gamma,
-                       ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH);
+                       beta, ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH);
     JP_LAUNCH_CHECK();
 }
 
@@ -271,7 +345,7 @@ extern "C" int jp_bn_eval_fwd(const float* x, const float* gamma, const float* b
                               float eps, int relu, void* stream) {
     JP_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && N > 0 && C > 0 && HW > 0, "bn_eval_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    const int gx = std::min(jp_cdiv(HW, TPB), 64);
+    const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_eval_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, running_mean, running_var, gamma, beta,
                        residual, y, C, HW, eps, relu);
     JP_LAUNCH_CHECK();

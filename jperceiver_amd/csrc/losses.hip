@@ -273,15 +273,17 @@ __global__ __launch_bounds__(TPB) void layout_fwd_kernel(const float* __restrict
     }
 }
 
-// one thread: loss = lw * iou + cew * ce + l2w * bd
+// one thread: loss = lw * region + cew * ce + l2w * bd with the overlap score of dice_loss.py generalised to
+//   score_c = (ra*tp + 1) / (ra*tp + ralpha*fp + rbeta*fn + 1)
+// IoULoss: (1, 1, 1) dice_loss.py:293-331;  SoftDiceLoss: (2, 1, 1) :255-290;  TverskyLoss: (1, 0.3, 0.7) :333-372
 __global__ void layout_finalize_kernel(const double* __restrict__ sums, float* __restrict__ loss, int B, int hw,
-                                       float lw, float cew, float l2w) {
+                                       float lw, float cew, float l2w, float ra, float ralpha, float rbeta) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double iou = 0.0;
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < 2; ++c) {
             const double tp = sums[8 * b + 3 * c], fp = sums[8 * b + 3 * c + 1], fn = sums[8 * b + 3 * c + 2];
-            iou += (tp + 1.0) / (tp + fp + fn + 1.0);
+            iou += ((double)ra * tp + 1.0) / ((double)ra * tp + (double)ralpha * fp + (double)rbeta * fn + 1.0);
         }
     iou = -iou / (2.0 * B);
     const double ce = sums[8 * B + 1] > 0.0 ? sums[8 * B] / sums[8 * B + 1] : 0.0;
@@ -295,15 +297,17 @@ __global__ __launch_bounds__(TPB) void layout_bwd_kernel(const float* __restrict
                                                          const double* __restrict__ sums,
                                                          const float* __restrict__ gout, float* __restrict__ dlogits,
                                                          int B, int hw, float w0, float w1, float lw, float cew,
-                                                         float l2w, int accumulate) {
+                                                         float l2w, float ra, float ralpha, float rbeta, int accumulate) {
     const int b = blockIdx.y;
     const float go = gout ? gout[0] : 1.f;
-    // d iou_c / d p_c(pixel) = (oh*D - (tp+1)*(1-oh)) / D^2 ; loss_iou = -(1/(2B)) sum iou
+    // score_c = T/D, T = ra*tp+1, D = ra*tp + ralpha*fp + rbeta*fn + 1; a pixel moves tp by oh*dp, fp by (1-oh)*dp and
+    // fn by -oh*dp:  d score_c / d p_c(pixel) = (ra*oh*D - T*(ra*oh + ralpha*(1-oh) - rbeta*oh)) / D^2
+    // (IoU: (oh*D - T*(1-oh)) / D^2);  loss_region = -(1/(2B)) sum score
     float Dc[2], Tc[2];
     for (int c = 0; c < 2; ++c) {
         const double tp = sums[8 * b + 3 * c], fp = sums[8 * b + 3 * c + 1], fn = sums[8 * b + 3 * c + 2];
-        Dc[c] = (float)(tp + fp + fn + 1.0);
-        Tc[c] = (float)(tp + 1.0);
+        Dc[c] = (float)((double)ra * tp + (double)ralpha * fp + (double)rbeta * fn + 1.0);
+        Tc[c] = (float)((double)ra * tp + 1.0);
     }
     const float kiou = -lw * go / (2.f * (float)B);
     const float kce = cew * go / (float)sums[8 * B + 1];
@@ -322,8 +326,8 @@ __global__ __launch_bounds__(TPB) void layout_bwd_kernel(const float* __restrict
         const float p0 = e0 * inv, p1 = e1 * inv;
         const bool fg = lb[p] > 0.5f;
         const float oh0 = fg ? 0.f : 1.f, oh1 = fg ? 1.f : 0.f;
-        float dp0 = kiou * (oh0 * Dc[0] - Tc[0] * (1.f - oh0)) / (Dc[0] * Dc[0]);
-        float dp1 = kiou * (oh1 * Dc[1] - Tc[1] * (1.f - oh1)) / (Dc[1] * Dc[1]);
+        float dp0 = kiou * (ra * oh0 * Dc[0] - Tc[0] * (ra * oh0 + ralpha * (1.f - oh0) - rbeta * oh0)) / (Dc[0] * Dc[0]);
+        float dp1 = kiou * (ra * oh1 * Dc[1] - Tc[1] * (ra * oh1 + ralpha * (1.f - oh1) - rbeta * oh1)) / (Dc[1] * Dc[1]);
         if (sd) dp1 += kbd * sd[p];
         const float dot = p0 * dp0 + p1 * dp1;          // softmax Jacobian
         float g0 = p0 * (dp0 - dot), g1 = p1 * (dp1 - dot);
@@ -516,23 +520,24 @@ extern "C" int jp_scale_loss_bwd(const float* disp, int hs, int ws, const float*
 // sums: (8*B + 3) doubles, kept for backward.  loss: device float.
 extern "C" int jp_layout_loss_fwd(const float* logits, const float* label, const float* sdf, double* sums,
                                   float* loss, int B, int h, int w, float w0, float w1, float lw, float cew,
-                                  float l2w, void* stream) {
+                                  float l2w, float ra, float ralpha, float rbeta, void* stream) {
     JP_CHECK_ARG(logits && label && sums && loss && B > 0, "layout_loss_fwd: bad args");
     JP_ST;
     JP_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (8 * B + 3), st));
     hipLaunchKernelGGL(layout_fwd_kernel, dim3(std::min(jp_cdiv(h * w, TPB), 256), B), dim3(TPB), 0, st, logits, label,
                        sdf, sums, B, h * w, w0, w1);
-    hipLaunchKernelGGL(layout_finalize_kernel, dim3(1), dim3(64), 0, st, sums, loss, B, h * w, lw, cew, l2w);
+    hipLaunchKernelGGL(layout_finalize_kernel, dim3(1), dim3(64), 0, st, sums, loss, B, h * w, lw, cew, l2w, ra, ralpha, rbeta);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_layout_loss_bwd(const float* logits, const float* label, const float* sdf, const double* sums,
                                   const float* gout, float* dlogits, int B, int h, int w, float w0, float w1,
-                                  float lw, float cew, float l2w, int accumulate, void* stream) {
+                                  float lw, float cew, float l2w, float ra, float ralpha, float rbeta, int accumulate,
+                                  void* stream) {
     JP_CHECK_ARG(logits && label && sums && dlogits && B > 0, "layout_loss_bwd: bad args");
     JP_ST;
     hipLaunchKernelGGL(layout_bwd_kernel, dim3(std::min(jp_cdiv(h * w, TPB), 256), B), dim3(TPB), 0, st, logits, label,
-                       sdf, sums, gout, dlogits, B, h * w, w0, w1, lw, cew, l2w, accumulate);
+                       sdf, sums, gout, dlogits, B, h * w, w0, w1, lw, cew, l2w, ra, ralpha, rbeta, accumulate);
     JP_LAUNCH_CHECK();
 }
 

@@ -206,6 +206,200 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_s1_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------ 5x5 stride-1 pad-2 max pool, row-streaming form
+// The CRP chains (layers.py:184-199) pool 256-channel maps of width 32 ... 256.  For W = 4*L with L | 64 a GROUP of L
+// lanes owns whole image rows (one float4 per lane = 16-B coalesced accesses, the row's left / right neighbours are
+// the adjacent lanes: wave shuffles, no LDS tile, no barrier) and walks down a band of rows with a 5-row register
+// window.  Both passes are separable with the scan-order (first maximum) tie rule kept:
+//   forward : per row the first maximum over kx of each column's 5 taps (rv, rk), then per output the first maximum
+//             over ky of the 5 row results;  idx = ky*5 + rk[that row].
+//   backward: rk of a row does not depend on the window that picked the row, so the gather splits the same way:
+//             t[r][ox] = sum over ky of dy[r+2-ky][ox] where that window picked row r, then dx[r][x] = sum over the 5
+//             columns ox whose row pick points at x.  10 candidates per input instead of 25 (+ the fused residual addend).
+// grid: ceil(units / (4*G)) blocks of 4 waves, G = 64/L groups per wave, unit = (plane, band of RB rows).
+template <int L>
+__device__ __forceinline__ void row5_neighbours(const float4 v, int lane_in_row, float e[8], float pad) {
+    // e[0..7] = columns 4*lane-2 .. 4*lane+5
+    const float lz = __shfl_up(v.z, 1, 64), lw = __shfl_up(v.w, 1, 64);
+    const float rx = __shfl_down(v.x, 1, 64), ry = __shfl_down(v.y, 1, 64);
+    e[0] = lane_in_row == 0 ? pad : lz;
+    e[1] = lane_in_row == 0 ? pad : lw;
+    e[2] = v.x; e[3] = v.y; e[4] = v.z; e[5] = v.w;
+    e[6] = lane_in_row == L - 1 ? pad : rx;
+    e[7] = lane_in_row == L - 1 ? pad : ry;
+}
+
+template <int L>
+__global__ __launch_bounds__(TPB) void maxpool5_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                uint8_t* __restrict__ idx, int NC, int H, int RB, int bands) {
+    constexpr int G = 64 / L, W = 4 * L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / L, lir = lane % L;
+    const long unit = ((long)blockIdx.x * 4 + wave) * G + grp;
+    const bool live = unit < (long)NC * bands;
+    const long nc = live ? unit / bands : 0;
+    const int r0 = live ? (int)(unit % bands) * RB : 0;
+    const int r1 = min(H, r0 + RB);                       // output rows [r0, r1)
+    const float4* xp = reinterpret_cast<const float4*>(x + nc * (long)H * W) + lir;
+    float4* yp = reinterpret_cast<float4*>(y + nc * (long)H * W) + lir;
+    uchar4* ip = reinterpret_cast<uchar4*>(idx + nc * (long)H * W) + lir;
+    const float NEG = -INFINITY;
+    float rv[5][4];
+    int rk[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rv[i][j] = NEG; rk[i][j] = 0; }
+    const int rend = live ? r1 + 2 : r0 - 2;             // dead groups still execute the shuffles of their wave: run 0 rows
+    for (int r = r0 - 2; r < rend; ++r) {
+        float4 v = make_float4(NEG, NEG, NEG, NEG);
+        if ((unsigned)r < (unsigned)H) v = xp[(long)r * L];
+        float e[8];
+        row5_neighbours<L>(v, lir, e, NEG);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rv[i][j] = rv[i + 1][j]; rk[i][j] = rk[i + 1][j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                    // first maximum over kx (a NaN always takes over: PyTorch's rule)
+            float b = e[j];
+            int k = 0;
+#pragma unroll
+            for (int kx = 1; kx < 5; ++kx) {
+                const float c = e[j + kx];
+                const bool take = c > b || c != c;
+                b = take ? c : b;
+                k = take ? kx : k;
+            }
+            rv[4][j] = b;
+            rk[4][j] = k;
+        }
+        const int oy = r - 2;
+        if (oy >= r0) {                                  // rows oy-2 .. oy+2 are in the window: first maximum over ky
+            float o[4];
+            unsigned char oi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float b = rv[0][j];
+                int bi = rk[0][j];
+#pragma unroll
+                for (int ky = 1; ky < 5; ++ky) {
+                    const float c = rv[ky][j];
+                    const bool take = c > b || c != c;
+                    b = take ? c : b;
+                    bi = take ? ky * 5 + rk[ky][j] : bi;
+                }
+                o[j] = b;
+                oi[j] = (unsigned char)bi;
+            }
+            yp[(long)oy * L] = make_float4(o[0], o[1], o[2], o[3]);
+            ip[(long)oy * L] = make_uchar4(oi[0], oi[1], oi[2], oi[3]);
+        }
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(TPB) void maxpool5_rows_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                                float* __restrict__ dx, const float* __restrict__ addend,
+                                                                int NC, int H, int RB, int bands) {
+    constexpr int G = 64 / L, W = 4 * L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / L, lir = lane % L;
+    const long unit = ((long)blockIdx.x * 4 + wave) * G + grp;
+    const bool live = unit < (long)NC * bands;
+    const long nc = live ? unit / bands : 0;
+    const int r0 = live ? (int)(unit % bands) * RB : 0;
+    const int r1 = min(H, r0 + RB);                       // input rows [r0, r1)
+    const float4* dp = reinterpret_cast<const float4*>(dy + nc * (long)H * W) + lir;
+    const uchar4* ip = reinterpret_cast<const uchar4*>(idx + nc * (long)H * W) + lir;
+    const float4* ap = addend ? reinterpret_cast<const float4*>(addend + nc * (long)H * W) + lir : nullptr;
+    float4* op = reinterpret_cast<float4*>(dx + nc * (long)H * W) + lir;
+    // window of output rows oy = r-2 .. r+2 around input row r: gradient, picked row (ky) and picked column (kx)
+    float d[5][4];
+    int wy[5][4], wx[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[i][j] = 0.f; wy[i][j] = 7; wx[i][j] = 0; }
+    const int oend = live ? r1 + 2 : r0 - 2;
+    for (int oy = r0 - 2; oy < oend; ++oy) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { d[i][j] = d[i + 1][j]; wy[i][j] = wy[i + 1][j]; wx[i][j] = wx[i + 1][j]; }
+        if ((unsigned)oy < (unsigned)H) {
+            const float4 g = dp[(long)oy * L];
+            const uchar4 q = ip[(long)oy * L];
+            const float gg[4] = {g.x, g.y, g.z, g.w};
+            const int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ky = (qq[j] * 13) >> 6;         // / 5 for 0..24
+                d[4][j] = gg[j];
+                wy[4][j] = ky;
+                wx[4][j] = qq[j] - 5 * ky;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { d[4][j] = 0.f; wy[4][j] = 7; wx[4][j] = 0; }
+        }
+        const int r = oy - 2;                             // window slot i holds output row r-2+i, which reaches r via ky = 4-i
+        // (executed by every lane, also before the first input row: the shuffles below need the whole wave)
+        float t[4];
+        float tk[4];                                      // picked column as a float: travels through the same shuffles
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+            int kx = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const bool hit = wy[i][j] == 4 - i;
+                acc += hit ? d[i][j] : 0.f;
+                kx = hit ? wx[i][j] : kx;
+            }
+            t[j] = acc;
+            tk[j] = (float)kx;
+        }
+        float et[8], ek[8];
+        row5_neighbours<L>(make_float4(t[0], t[1], t[2], t[3]), lir, et, 0.f);
+        row5_neighbours<L>(make_float4(tk[0], tk[1], tk[2], tk[3]), lir, ek, -1.f);
+        if (r >= r0 && r < r1) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                 // input column 4*lane+j <- output columns ox = x-2 .. x+2 (e index j .. j+4)
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < 5; ++m) acc += ek[j + m] == (float)(4 - m) ? et[j + m] : 0.f;   // kx = x - ox + 2 = 4 - m
+                o[j] = acc;
+            }
+            if (ap) { const float4 a = ap[(long)r * L]; o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+            op[(long)r * L] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int L>
+static void launch_pool5_rows(bool fwd, const float* a, float* out, uint8_t* idx, const uint8_t* cidx, const float* addend,
+                              int NC, int H, hipStream_t st) {
+    const int RB = H <= 64 ? H : 64, bands = jp_cdiv(H, RB), G = 64 / L;
+    const long units = (long)NC * bands;
+    const dim3 grid((unsigned)jp_cdiv(units, 4L * G));
+    if (fwd) hipLaunchKernelGGL((maxpool5_rows_fwd_kernel<L>), grid, dim3(TPB), 0, st, a, out, idx, NC, H, RB, bands);
+    else hipLaunchKernelGGL((maxpool5_rows_bwd_kernel<L>), grid, dim3(TPB), 0, st, a, cidx, out, addend, NC, H, RB, bands);
+}
+static bool pool5_rows_ok(int k, int s, int p, int W) {
+    return k == 5 && s == 1 && p == 2 && (W == 32 || W == 64 || W == 128 || W == 256);
+}
+static void pool5_rows(bool fwd, const float* a, float* out, uint8_t* idx, const uint8_t* cidx, const float* addend, int NC,
+                       int H, int W, hipStream_t st) {
+    switch (W) {
+        case 32: launch_pool5_rows<8>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
+        case 64: launch_pool5_rows<16>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
+        case 128: launch_pool5_rows<32>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
+        default: launch_pool5_rows<64>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
+    }
+}
+
 // ------------------------------------------------------------------ nearest 2x upsample
 __global__ __launch_bounds__(TPB) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              long total, int C, int H, int W, int dstC, int dc0) {
@@ -304,41 +498,103 @@ __global__ __launch_bounds__(TPB) void copy_channels_v4_kernel(const float* __re
 
 // ------------------------------------------------------------------ elementwise
 // out = alpha * a (*|+) b ...
+// ---- elementwise: 16 B per lane on the 16-B aligned body (every torch allocation is >= 256-B aligned; views into the
+// flat arenas are 256-B aligned slices), scalar on the tail / unaligned operands.  F: float4 lanes -> float4.
+template <class F4, class F1>
+__device__ __forceinline__ void ew_loop(long n, bool aligned, F4 f4, F1 f1) {
+    const long n4 = aligned ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long)gridDim.x * TPB) f4(i);
+    for (long i = (n4 << 2) + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) f1(i);
+}
+__device__ __forceinline__ bool al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                                     const void* e = nullptr, const void* f = nullptr) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f) & 15) == 0;
+}
+#define JP_F4(p) reinterpret_cast<const float4*>(p)
+#define JP_F4W(p) reinterpret_cast<float4*>(p)
+
 __global__ __launch_bounds__(TPB) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                     float* __restrict__ out, long n, float alpha, float beta) {
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
-        out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+    ew_loop(n, al16(a, b, out),
+            [&](long i) {
+                const float4 x = JP_F4(a)[i];
+                float4 r = make_float4(alpha * x.x, alpha * x.y, alpha * x.z, alpha * x.w);
+                if (b) { const float4 y = JP_F4(b)[i]; r.x += beta * y.x; r.y += beta * y.y; r.z += beta * y.z; r.w += beta * y.w; }
+                JP_F4W(out)[i] = r;
+            },
+            [&](long i) { out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f); });
+}
+
+// out = a0 + a1 (+ a2 + a3 + a4): the residual sum of a CRP block (layers.py:193-198) in ONE pass instead of a
+// chain of pairwise adds.  Left-to-right order = the reference's accumulation order (x + top1 + top2 + ...).
+__global__ __launch_bounds__(TPB) void sum_n_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                    const float* __restrict__ a2, const float* __restrict__ a3,
+                                                    const float* __restrict__ a4, float* __restrict__ out, long n) {
+    ew_loop(n, al16(a0, a1, a2, a3, a4, out),
+            [&](long i) {
+                float4 r = JP_F4(a0)[i];
+                const float4 b = JP_F4(a1)[i];
+                r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
+                if (a2) { const float4 c = JP_F4(a2)[i]; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+                if (a3) { const float4 c = JP_F4(a3)[i]; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+                if (a4) { const float4 c = JP_F4(a4)[i]; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+                JP_F4W(out)[i] = r;
+            },
+            [&](long i) {
+                float r = a0[i] + a1[i];
+                if (a2) r += a2[i];
+                if (a3) r += a3[i];
+                if (a4) r += a4[i];
+                out[i] = r;
+            });
 }
 
 __global__ __launch_bounds__(TPB) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, long n, float scale) {
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
-        out[i] = a[i] * b[i] * scale;
+    ew_loop(n, al16(a, b, out),
+            [&](long i) {
+                const float4 x = JP_F4(a)[i], y = JP_F4(b)[i];
+                JP_F4W(out)[i] = make_float4(x.x * y.x * scale, x.y * y.y * scale, x.z * y.z * scale, x.w * y.w * scale);
+            },
+            [&](long i) { out[i] = a[i] * b[i] * scale; });
 }
 
 __global__ __launch_bounds__(TPB) void affine_kernel(const float* __restrict__ a, float* __restrict__ out, long n,
                                                      float scale, float shift) {
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
-        out[i] = a[i] * scale + shift;
+    ew_loop(n, al16(a, out),
+            [&](long i) {
+                const float4 x = JP_F4(a)[i];
+                JP_F4W(out)[i] = make_float4(x.x * scale + shift, x.y * scale + shift, x.z * scale + shift, x.w * scale + shift);
+            },
+            [&](long i) { out[i] = a[i] * scale + shift; });
 }
 
 __global__ __launch_bounds__(TPB) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
                                                       int act) {
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB)
-        y[i] = jp_act(x[i], act);
+    ew_loop(n, al16(x, y),
+            [&](long i) {
+                const float4 v = JP_F4(x)[i];
+                JP_F4W(y)[i] = make_float4(jp_act(v.x, act), jp_act(v.y, act), jp_act(v.z, act), jp_act(v.w, act));
+            },
+            [&](long i) { y[i] = jp_act(x[i], act); });
 }
 
 // dx = dy * act'(.) expressed through the activation OUTPUT y (valid for relu / leaky / sigmoid)
+__device__ __forceinline__ float act_bwd1(float d, float v, int act) {
+    if (act == JP_ACT_RELU) return v > 0.f ? d : 0.f;
+    if (act == JP_ACT_LEAKY) return v > 0.f ? d : 0.01f * d;
+    if (act == JP_ACT_SIGMOID) return d * v * (1.f - v);
+    return d;
+}
 __global__ __launch_bounds__(TPB) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       float* __restrict__ dx, long n, int act) {
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
-        const float v = y[i];
-        float d = dy[i];
-        if (act == JP_ACT_RELU) d = v > 0.f ? d : 0.f;
-        else if (act == JP_ACT_LEAKY) d = v > 0.f ? d : 0.01f * d;
-        else if (act == JP_ACT_SIGMOID) d = d * v * (1.f - v);
-        dx[i] = d;
-    }
+    ew_loop(n, al16(dy, y, dx),
+            [&](long i) {
+                const float4 d = JP_F4(dy)[i], v = JP_F4(y)[i];
+                JP_F4W(dx)[i] = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act),
+                                            act_bwd1(d.w, v.w, act));
+            },
+            [&](long i) { dx[i] = act_bwd1(dy[i], y[i], act); });
 }
 
 // out[n][c][hw] = a[n][c][hw] * s[n][0][hw]   (CrossViewTransformer.py:68) and its two adjoints
@@ -674,6 +930,10 @@ extern "C" int jp_maxpool_fwd(const float* x, float* y, uint8_t* idx, int NC, in
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
     const dim3 gt(jp_cdiv(OW, MP_TW), jp_cdiv(OH, MPF_TH), NC);
+    if (pool5_rows_ok(k, s, p, W)) {   // CRP maps: row-streaming kernel (wave shuffles, no LDS tile)
+        pool5_rows(true, x, y, idx, nullptr, nullptr, NC, H, W, st);
+        JP_LAUNCH_CHECK();
+    }
     if (k == 5 && s == 1) {
         hipLaunchKernelGGL((maxpool_fwd_t_kernel<5, 1>), gt, dim3(TPB), 0, st, x, y, idx, H, W, OH, OW, p);
         JP_LAUNCH_CHECK();
@@ -699,6 +959,10 @@ extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, co
     JP_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_bwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    if (pool5_rows_ok(k, s, p, W)) {
+        pool5_rows(false, dy, dx, nullptr, idx, addend, NC, H, W, st);
+        JP_LAUNCH_CHECK();
+    }
     if (k == 5 && s == 1) {
         hipLaunchKernelGGL((maxpool_bwd_s1_kernel<5>), dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MPF_TH), NC), dim3(TPB), 0, st,
                            dy, idx, dx, addend, H, W, OH, OW, p);
@@ -756,38 +1020,46 @@ extern "C" int jp_copy_channels(const float* src, float* dst, int N, int C, int 
     JP_LAUNCH_CHECK();
 }
 
+extern "C" int jp_sum_n(const float* a0, const float* a1, const float* a2, const float* a3, const float* a4, float* out,
+                        long n, void* stream) {
+    JP_CHECK_ARG(a0 && a1 && out && n > 0 && !(a3 && !a2) && !(a4 && !a3), "sum_n: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(sum_n_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, a0, a1, a2, a3, a4, out, n);
+    JP_LAUNCH_CHECK();
+}
+
 extern "C" int jp_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream) {
     JP_CHECK_ARG(a && out && n > 0, "axpby: bad args");
     JP_ST;
-    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, a, b, out, n, alpha, beta);
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, a, b, out, n, alpha, beta);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_mul(const float* a, const float* b, float* out, long n, float scale, void* stream) {
     JP_CHECK_ARG(a && b && out && n > 0, "mul: bad args");
     JP_ST;
-    hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, a, b, out, n, scale);
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, a, b, out, n, scale);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_affine(const float* a, float* out, long n, float scale, float shift, void* stream) {
     JP_CHECK_ARG(a && out && n > 0, "affine: bad args");
     JP_ST;
-    hipLaunchKernelGGL(affine_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, a, out, n, scale, shift);
+    hipLaunchKernelGGL(affine_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, a, out, n, scale, shift);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_act_fwd(const float* x, float* y, long n, int act, void* stream) {
     JP_CHECK_ARG(x && y && n > 0, "act_fwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, x, y, n, act);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, x, y, n, act);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, int act, void* stream) {
     JP_CHECK_ARG(dy && y && dx && n > 0, "act_bwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, dy, y, dx, n, act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, dy, y, dx, n, act);
     JP_LAUNCH_CHECK();
 }
 

@@ -30,14 +30,14 @@ def _two_class(x, y):
 
 class _LayoutLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, label, sdf, lw, cew, l2w, w0, w1):
+    def forward(ctx, logits, label, sdf, lw, cew, l2w, w0, w1, region=(1.0, 1.0, 1.0)):
         B, _, h, w = logits.shape
         sums = torch.empty(8 * B + 3, device=logits.device, dtype=torch.float64)
         out = torch.empty(1, device=logits.device, dtype=torch.float32)
         call("jp_layout_loss_fwd", logits, label, sdf, sums, out, B, h, w, float(w0), float(w1), float(lw), float(cew),
-             float(l2w))
+             float(l2w), *region)
         ctx.save_for_backward(logits, label, sums)
-        ctx.sdf, ctx.k = sdf, (B, h, w, float(w0), float(w1), float(lw), float(cew), float(l2w))
+        ctx.sdf, ctx.k, ctx.region = sdf, (B, h, w, float(w0), float(w1), float(lw), float(cew), float(l2w)), region
         return out.view(())
 
     @staticmethod
@@ -46,8 +46,8 @@ class _LayoutLossFn(torch.autograd.Function):
         B, h, w, w0, w1, lw, cew, l2w = ctx.k
         d = torch.empty_like(logits)
         call("jp_layout_loss_bwd", logits, label, ctx.sdf, sums, g.reshape(1).contiguous().float(), d, B, h, w, w0, w1, lw,
-             cew, l2w, 0)
-        return d, None, None, None, None, None, None, None
+             cew, l2w, *ctx.region, 0)
+        return d, None, None, None, None, None, None, None, None
 
 
 def _is_softmax_dim1(fn) -> bool:
@@ -61,13 +61,14 @@ def _is_softmax_dim1(fn) -> bool:
         return False
 
 
-class IoULoss(nn.Module):
-    """-mean_{b,c} (tp + smooth) / (tp + fp + fn + smooth) on softmax probabilities (dice_loss.py:293-331)."""
+class _RegionLoss(nn.Module):
+    """-mean_{b,c} (a*tp + smooth) / (a*tp + alpha*fp + beta*fn + smooth) on softmax probabilities."""
+    REGION = (1.0, 1.0, 1.0)
 
     def __init__(self, apply_nonlin=None, batch_dice=False, do_bg=True, smooth=1., square=False):
         super().__init__()
         if batch_dice or not do_bg or smooth != 1.0 or square:
-            raise NotImplementedError("only the reference's call pattern IoULoss(apply_nonlin=softmax) is built")
+            raise NotImplementedError("only the reference's call pattern <Loss>(apply_nonlin=softmax) is built")
         if not _is_softmax_dim1(apply_nonlin):
             raise NotImplementedError("apply_nonlin must be softmax over dim 1 (fused into the kernel)")
         self.apply_nonlin, self.batch_dice, self.do_bg, self.smooth, self.square = apply_nonlin, False, True, 1.0, False
@@ -76,7 +77,26 @@ class IoULoss(nn.Module):
         if loss_mask is not None:
             raise NotImplementedError("loss_mask is never used by the reference's train step")
         x, y, B, h, w = _two_class(x, y)
-        return _LayoutLossFn.apply(x, y, None, 1.0, 0.0, 0.0, 1.0, 1.0)
+        return _LayoutLossFn.apply(x, y, None, 1.0, 0.0, 0.0, 1.0, 1.0, self.REGION)
+
+
+class IoULoss(_RegionLoss):
+    """dice_loss.py:293-331."""
+    REGION = (1.0, 1.0, 1.0)
+
+
+class SoftDiceLoss(_RegionLoss):
+    """dice_loss.py:255-290: (2 tp + s) / (2 tp + fp + fn + s)."""
+    REGION = (2.0, 1.0, 1.0)
+
+
+class TverskyLoss(_RegionLoss):
+    """dice_loss.py:333-372: (tp + s) / (tp + 0.3 fp + 0.7 fn + s)."""
+    REGION = (1.0, 0.3, 0.7)
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.alpha, self.beta = 0.3, 0.7
 
 
 def compute_sdf(label: torch.Tensor) -> torch.Tensor:

@@ -97,26 +97,28 @@ class CRPBlock(nn.Module):
 
     def _fwd(self, x):
         outer = ops.current_tape()
-        if outer is None or not x.rg:
-            top = x
-            for i in range(self.n_stages):
-                top = ops.maxpool(top, 5, 1, 2)
-                top = getattr(self, "{}_{}".format(i + 1, "pointwise"))._fwd(top)
-                x = ops.add(top, x)
-            return x
+        train = outer is not None and x.rg
+        # The output x + top_1 + ... + top_n is ONE pass over its n+1 terms (jp_sum_n, the reference's left-to-right
+        # accumulation order) instead of n pairwise adds.
         # Training: the output gradient G reaches every `top_i` and the block input unchanged through the adds, so
         # the whole chain is ONE node of the outer tape.  Its backward replays a private tape of the pools and convs
         # with G folded into each max-pool backward kernel (g(top_{i-1}) = G + pool_bwd(conv_dgrad(g(top_i)))):
         # no per-stage gradient-accumulation pass.
         private, G = ops.Tape(), [None]
-        acc, top = x.t, x
-        with ops.recording(private):
+        tops, top = [], x
+        with ops.recording(private if train else None):
             for i in range(self.n_stages):
-                top = ops.maxpool(top, 5, 1, 2, bwd_addend=lambda: G[0])
+                top = ops.maxpool(top, 5, 1, 2, bwd_addend=(lambda: G[0]) if train else None)
                 top = getattr(self, "{}_{}".format(i + 1, "pointwise"))._fwd(top)
-                nxt = torch.empty_like(acc)
-                ops.call("jp_axpby", top.t, acc, nxt, nxt.numel(), 1.0, 1.0)
-                acc = nxt
+                tops.append(top)
+        terms, acc = [x.t] + [t.t for t in tops], None
+        while len(terms) > 1:                      # up to 5 terms per launch (n_stages = 4 -> exactly one)
+            chunk, terms = terms[:5], terms[5:]
+            acc = torch.empty_like(x.t)
+            ops.call("jp_sum_n", *(chunk + [None] * (5 - len(chunk))), acc, acc.numel())
+            terms = [acc] + terms
+        if not train:
+            return Var(acc if acc is not None else x.t, False)
         out = Var(acc, True)
         last = top
 

@@ -268,6 +268,11 @@ class Baseline(nn.Module):
         lsum = o["loss_sum"]
         use_ce = 0.0 if lsum in (1, 2) else 1.0
         use_bd = 0.0 if lsum == 1 else 1.0
+        region = o.get("loss_type", "iou")                # net.py:562-573: 'iou' | 'dice' | 'tversky' | 'focal'
+        if region not in ops_loss.REGION:
+            raise NotImplementedError(f"loss_type={region!r}: only iou / dice / tversky are built (the north-star configs use iou)")
+        if o.get("loss2_type", "boundary") != "boundary":
+            raise NotImplementedError("loss2_type must be 'boundary' (net.py:574-575)")
 
         def layout_heads(Fv, f4):
             """CVP / CCT / BEV decoders of both heads + the layout losses (net.py:107-138 with root-net.py conditionals):
@@ -287,8 +292,8 @@ class Baseline(nn.Module):
                 label = inputs[lab_key]
                 sdf = ops_loss.signed_distance(label) if use_bd else None
                 h = heads[sfx]
-                ops_loss.layout_loss(lv, "topview_loss" + sfx, h["top"], label, sdf, 1.0, cw, a_, use_ce, b2 * use_bd)
-                ops_loss.layout_loss(lv, "transform_topview_loss" + sfx, h["ttop"], label, sdf, 1.0, cw, a_, use_ce, b2 * use_bd)
+                ops_loss.layout_loss(lv, "topview_loss" + sfx, h["top"], label, sdf, 1.0, cw, a_, use_ce, b2 * use_bd, region)
+                ops_loss.layout_loss(lv, "transform_topview_loss" + sfx, h["ttop"], label, sdf, 1.0, cw, a_, use_ce, b2 * use_bd, region)
                 ops_loss.l1_loss(lv, "transform_loss" + sfx, h["feats"], h["r"])
                 ops_loss.combine(lv, "layout_loss" + sfx, [("topview_loss" + sfx, 1.0), ("transform_loss" + sfx, 0.001),
                                                           ("transform_topview_loss" + sfx, 1.0)])

@@ -381,8 +381,10 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
         need_res = residual is not None and residual.rg
         dres = torch.empty_like(x.t) if need_res else None
         ws2 = _new((nbw,), x.t, torch.float64)
-        call("jp_bn_train_bwd", out.g, x.t, y if relu else None, gamma.t, mean, invstd, dx, dres, gamma.g, beta.g, ws2,
-             N, C, H * W, int(relu), 1)
+        # residual-free ReLU layers: the kernel recomputes the mask from x (fmaf(x, sc, sh) > 0, bit-identical to the
+        # forward's) instead of reading y
+        call("jp_bn_train_bwd", out.g, x.t, y if (relu and residual is not None) else None, gamma.t, beta.t, mean, invstd, dx,
+             dres, gamma.g, beta.g, ws2, N, C, H * W, int(relu), 1)
         if x.rg:
             x.add_grad(dx)
         if need_res:

@@ -310,20 +310,25 @@ def signed_distance(label: torch.Tensor) -> torch.Tensor:
     return sdf
 
 
-def layout_loss(lv: LossVec, slot, logits: Var, label: torch.Tensor, sdf, w0, w1, lw, cew, l2w):
-    """compute_topview_loss (net.py:554-585): lw*IoU + cew*CE(w0,w1) + l2w*BD in one fused pass."""
+REGION = {"iou": (1.0, 1.0, 1.0), "dice": (2.0, 1.0, 1.0), "tversky": (1.0, 0.3, 0.7)}   # (a, alpha, beta) of the overlap score
+
+
+def layout_loss(lv: LossVec, slot, logits: Var, label: torch.Tensor, sdf, w0, w1, lw, cew, l2w, region="iou"):
+    """compute_topview_loss (net.py:554-585): lw*region + cew*CE(w0,w1) + l2w*BD in one fused pass; region =
+    opt.loss_type: IoULoss / SoftDiceLoss / TverskyLoss (dice_loss.py:255-372)."""
     B, C, h, w = logits.t.shape
     assert C == 2
+    ra, ral, rbe = REGION[region]
     sums = _new((8 * B + 3,), logits.t, torch.float64)
     call("jp_layout_loss_fwd", logits.t, label, sdf, sums, lv.val(slot), B, h, w, float(w0), float(w1), float(lw),
-         float(cew), float(l2w))
+         float(cew), float(l2w), ra, ral, rbe)
 
     def bwd():
         if not logits.rg:
             return
         g, a = logits.grad_buf()
         call("jp_layout_loss_bwd", logits.t, label, sdf, sums, lv.grad(slot), g, B, h, w, float(w0), float(w1),
-             float(lw), float(cew), float(l2w), a)
+             float(lw), float(cew), float(l2w), ra, ral, rbe, a)
 
     _rec(True, bwd)
 

@@ -70,14 +70,19 @@ def _gain(name: str) -> float:
     return 1.13
 
 
-def synth_tensor_for(name: str, shape, seed: int) -> torch.Tensor:
-    """Name-keyed deterministic initial value for one state-dict entry."""
+def synth_tensor_for(name: str, shape, seed: int, bn_stats: bool = False) -> torch.Tensor:
+    """Name-keyed deterministic initial value for one state-dict entry.  bn_stats: non-trivial BatchNorm running
+    statistics (as after some training) instead of the (0, 1) initial ones -- used by the eval-mode fixtures."""
     shape = tuple(int(s) for s in shape)
     if name.endswith("num_batches_tracked"):
         return torch.zeros((), dtype=torch.long)
     if name.endswith("running_mean"):
+        if bn_stats:
+            return torch.from_numpy((0.3 * (hash_uniform(seed, name, shape) - 0.5)).astype(np.float32))
         return torch.zeros(shape)
     if name.endswith("running_var"):
+        if bn_stats:
+            return torch.from_numpy((0.6 + 0.8 * hash_uniform(seed, name, shape)).astype(np.float32))
         return torch.ones(shape)
     u = hash_uniform(seed, name, shape)
     if len(shape) >= 2:                       # conv / linear weight: Kaiming-uniform-like
@@ -91,11 +96,11 @@ def synth_tensor_for(name: str, shape, seed: int) -> torch.Tensor:
     return torch.from_numpy((0.1 * (u - 0.5)).astype(np.float32))  # biases / BN beta
 
 
-def synth_state_dict(template: dict, seed: int = 0) -> dict:
+def synth_state_dict(template: dict, seed: int = 0, bn_stats: bool = False) -> dict:
     """template: name -> tensor (only shape/dtype are used)."""
     out = {}
     for name, t in template.items():
-        v = synth_tensor_for(name, t.shape, seed)
+        v = synth_tensor_for(name, t.shape, seed, bn_stats)
         out[name] = v.to(t.dtype) if t.dtype != torch.long else v
     return out
 

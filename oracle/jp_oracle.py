@@ -373,10 +373,9 @@ def bev_decoder(cx, prefix, x):
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         x = bn(cx, f"{prefix}decoder.{idx + 4}", conv(cx, f"{prefix}decoder.{idx + 3}", x, 1, 1))
         idx += 5
-    x = conv(cx, f"{prefix}decoder.{idx}.conv", x, refl=True)
-    if not cx.training:
-        x = F.softmax(x, 1)
-    return x
+    # raw logits in train AND eval: Baseline.predict_layout calls the decoder with its default is_training=True
+    # (net.py:644-689), so the Softmax2d branch of layout_model.py:194-199 never runs inside the model
+    return conv(cx, f"{prefix}decoder.{idx}.conv", x, refl=True)
 
 
 def predict_layout(cx, inputs, depth_feature, sfx="", features=None, force=None):

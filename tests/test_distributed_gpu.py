@@ -5,7 +5,7 @@ with grad_scale = 1/world (mono/core/utils/dist_utils.py:12-60, mono/apis/traine
 
 Checked per rank:  the arena holds g_0 + g_1 after the exchange (each rank's local gradients are measured in a
 separate, hook-free backward on the same inputs);  the parameters after the step equal the oracle's reference-ordered
-clip+Adam applied to the MEAN gradient (<= 1e-6);  both replicas end bit-identical (SHA-1 of the parameter arena);
+clip+Adam applied to the exchanged arena / world, i.e. the MEAN gradient (<= 1e-6);  both replicas end bit-identical (SHA-1 of the parameter arena);
 the dead tail is untouched.  (The 8-GPU RCCL run itself belongs to the driver; the rendezvous here is 127.0.0.1.)"""
 import hashlib
 import os
@@ -69,11 +69,13 @@ def _worker(rank, world, port, ty, q):
         live = a.live_numel
         err_sum = float((g_sum[:live] - expect[:live]).norm() / expect[:live].norm())
         tail_untouched = bool(torch.equal(g_sum[live:], g_local[live:]))
-        # (3) oracle clip+Adam on the mean gradient
+        # (3) oracle clip+Adam on the mean gradient = the exchanged arena / world.  (The arena of THIS step, not
+        # g_local's sum: Adam's first update is lr*g/(|g|+1e-8), so the ~1e-6 relative run-to-run noise of two separate
+        # backward passes would move weights whose gradient is ~1e-8 by a good fraction of lr.)
         P = {}
         for n, p, o, k in a.entries[:a.n_live_entries]:
             t = p_before[n].clone().requires_grad_(True)
-            t.grad = (expect[o:o + k] / world).view(t.shape).clone()
+            t.grad = (g_sum[o:o + k] / world).view(t.shape).clone()
             P[n] = t
         norm_ref = J.adam_step(P, {}, lr=1e-4, max_norm=35.0)
         worst = max(float((p.detach().cpu() - P[n].detach()).abs().max()) for n, p in model.named_parameters() if n in P)

@@ -23,7 +23,7 @@ GROUPS = [
     ("Pooling / resampling / elementwise — MaxPool2d " + R + "resnet.py:94, " + R + "layers.py:191, " + R + "layout_model.py:84; "
      "nearest upsample " + R + "layers.py:110; torch.cat; Dropout multiply " + R + "depth_decoder.py:52-53; F.interpolate bilinear "
      + R + "net.py:196,632,692 and area " + R + "net.py:762.",
-     ["jp_maxpool_fwd", "jp_maxpool_bwd", "jp_upsample2x_fwd", "jp_upsample2x_bwd", "jp_copy_channels", "jp_axpby", "jp_mul",
+     ["jp_maxpool_fwd", "jp_maxpool_bwd", "jp_upsample2x_fwd", "jp_upsample2x_bwd", "jp_copy_channels", "jp_axpby", "jp_sum_n", "jp_mul",
       "jp_affine", "jp_act_fwd", "jp_act_bwd", "jp_mul_bcast_c", "jp_mul_bcast_c_bwd_s", "jp_bilinear_fwd", "jp_bilinear_bwd",
       "jp_area_downsample", "jp_fill", "jp_warp_perspective", "jp_softmax_c2", "jp_disp_to_depth",
       "jp_scale_label_assemble", "jp_fill_convex_poly"]),
@@ -46,6 +46,10 @@ GROUPS = [
      "config/cfg_kitti_baseline_odometry_boundary_ce_iou_1024_20.py:69-70; Dropout / randn " + R + "depth_decoder.py:13, "
      + R + "net.py:163.",
      ["jp_sumsq_blocks", "jp_grad_sumsq_partials", "jp_sum_doubles", "jp_adam_clip_step", "jp_rng_keep_mask", "jp_rng_normal"]),
+    ("Evaluation metrics as GPU reductions — mean_IU / mean_precision mono/core/evaluation/pixel_error.py:59-118 (confusion counts "
+     "of argmax(logits) vs label); depth compute_errors + median scaling + Garg crop mono/core/evaluation/pixel_error.py:27-40, "
+     "mono/core/evaluation/eval_hooks.py:147-179.",
+     ["jp_confusion2", "jp_depth_eval_prepare", "jp_masked_median", "jp_depth_errors"]),
     ("Library plumbing.  jp_profile_*: opt-in per-kernel HIP-event timing of the implicit-GEMM launches on the streams they "
      "are launched on (bench.py's roofline leg; never active in the train step).",
      ["jp_abi_version", "jp_last_error_string", "jp_set_last_error", "jp_profile_begin", "jp_profile_count", "jp_profile_end",

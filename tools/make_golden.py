@@ -272,6 +272,84 @@ def unit_vectors(net):
     print("unit_vectors keys", len(g))
 
 
+def eval_case(net, name="eval_256_b2", HW=256, B=2, seed=7):
+    """model.eval() forward of the REFERENCE (BatchNorm running statistics, Dropout off, raw logits out of
+    predict_layout) on synthetic weights with non-trivial running statistics -> disparities, layout logits, features."""
+    occ = HW // 4
+    opt = Opt(depth_num_layers=18, pose_num_layers=18, frame_ids=[0, -1, 1], imgs_per_gpu=B, height=HW, width=HW,
+              scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0, depth_pretrained_path=None, pose_pretrained_path=None,
+              automask=True, disp_norm=True, smoothness_weight=1e-3, scale_weight=0.1, dynamic_weight=15., static_weight=5.,
+              occ_map_size=occ, num_class=2, loss_type="iou", loss_weight=20, loss_weightS=20, loss2_type="boundary",
+              loss2_weight=20, loss2_weightS=20, type="Argo_both", loss_sum=3, split="argo")
+    torch.manual_seed(0)
+    model = net.Baseline(opt)
+    model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0, bn_stats=True), strict=True)
+    model.eval()
+    inp = syn.make_batch(B, HW, HW, [0, -1, 1], occ, (257, 308), "argo", seed=seed)
+    with torch.no_grad():
+        out = model({k: v.clone() for k, v in inp.items()})
+    g = {"meta": np.array(repr(dict(HW=HW, B=B, seed=seed, occ=occ)))}
+    for s_ in range(4):
+        d = out[("disp", 0, s_)]
+        g[f"disp{s_}/pool"] = pool_to(d)
+        g[f"disp{s_}/first"] = d.numpy()[:, :, :8, :8].copy()
+    for k in ("topview", "transform_topview", "topviewB", "transform_topviewB"):
+        g[k + "/pool"] = pool_to(out[k])
+        g[k + "/first"] = out[k].numpy()[:, :, :8, :8].copy()
+        g[k + "/argmax_frac"] = np.float64(out[k].argmax(1).float().mean().item())
+    for k in ("features", "featuresB", "retransform_features", "origin_features"):
+        g["feat/" + k] = out[k].numpy()
+    nbt = dict(model.named_buffers())["DepthEncoder.encoder.bn1.num_batches_tracked"]
+    g["nbt_unchanged"] = np.int64(nbt.item())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
+    print(name, "keys", len(g), "topview argmax frac", g["topview/argmax_frac"])
+
+
+def eval_metric_vectors():
+    """Known answers of the reference's metric functions (mono/core/evaluation/pixel_error.py, imported as is) and of the
+    eval hook's per-sample depth block (eval_hooks.py:147-179, restated here line by line with cv2.resize ==
+    half-pixel bilinear because the hook itself needs mmcv / cv2)."""
+    pe = _load("mono_core_pixel_error", REF + "/mono/core/evaluation/pixel_error.py")
+    g = {}
+    rng = np.random.default_rng(5)
+    n = 40
+    cases = {"mixed": (rng.random((n, n)) > 0.6, rng.random((n, n)) > 0.7), "pred_empty": (np.zeros((n, n), bool), rng.random((n, n)) > 0.5),
+             "gt_empty": (rng.random((n, n)) > 0.5, np.zeros((n, n), bool)), "both_empty": (np.zeros((n, n), bool), np.zeros((n, n), bool)),
+             "both_full": (np.ones((n, n), bool), np.ones((n, n), bool))}
+    for k, (p, t) in cases.items():
+        g[f"seg/{k}/pred"], g[f"seg/{k}/true"] = p.astype(np.uint8), t.astype(np.uint8)
+        g[f"seg/{k}/iu"] = np.asarray(pe.mean_IU(p.astype(np.int64), t.astype(np.int64)), np.float64)
+        g[f"seg/{k}/prec"] = np.asarray(pe.mean_precision(p.astype(np.int64), t.astype(np.int64)), np.float64)
+    gt = (rng.random((50, 70)) * 60 + 1).astype(np.float32)
+    pr = (gt * (0.7 + 0.6 * rng.random((50, 70)))).astype(np.float32)
+    g["err/gt"], g["err/pred"] = gt, pr
+    g["err/out"] = np.asarray(pe.compute_errors(gt, pr), np.float64)
+    # the hook's depth block on a synthetic disparity / sparse ground truth
+    disp = torch.from_numpy(syn.hash_uniform(9, "evdisp", (1, 1, 48, 160)))
+    H, W = 94, 311
+    gtd = (rng.random((H, W)) * 90).astype(np.float32)
+    gtd[rng.random((H, W)) > 0.35] = 0
+    g["depth/disp"], g["depth/gt"] = disp.numpy(), gtd
+    pred_disp, _ = pe.disp_to_depth(disp)
+    pred_disp = F.interpolate(pred_disp, (H, W), mode="bilinear", align_corners=False)[0, 0].numpy()   # == cv2.resize INTER_LINEAR
+    pred_depth = 1 / pred_disp
+    mask = np.logical_and(gtd > 1e-3, gtd < 80)
+    crop = np.array([0.40810811 * H, 0.99189189 * H, 0.03594771 * W, 0.96405229 * W]).astype(np.int32)
+    cm = np.zeros(mask.shape)
+    cm[crop[0]:crop[1], crop[2]:crop[3]] = 1
+    mask = np.logical_and(mask, cm)
+    pd, gd = pred_depth[mask], gtd[mask]
+    ratio = np.median(gd) / np.median(pd)
+    for tag, scale in (("median", ratio), ("stereo", 36.0)):
+        q = pd * scale
+        q[q < 1e-3] = 1e-3
+        q[q > 80] = 80
+        g[f"depth/{tag}/errors"] = np.asarray(pe.compute_errors(gd, q), np.float64)
+    g["depth/ratio"], g["depth/n_valid"] = np.float64(ratio), np.int64(mask.sum())
+    np.savez_compressed(os.path.join(OUT, "eval_metrics.npz"), **g)
+    print("eval_metrics keys", len(g), "ratio", ratio, "n_valid", int(mask.sum()))
+
+
 def scale_label_cases(net):
     """get_scale_label_static / get_scale_label_dynamic (net.py:212-402) run by the REFERENCE on the synthetic
     calibration (third-party pieces stubbed as above) -> tests/golden/scale_labels.npz: the 0/1 support as packed
@@ -325,10 +403,14 @@ CASES = {
 
 if __name__ == "__main__":
     net = import_reference()
-    want = sys.argv[1:] or (["unit", "scale_labels"] + list(CASES))
+    want = sys.argv[1:] or (["unit", "scale_labels", "eval", "eval_metrics"] + list(CASES))
     for c in want:
         if c == "unit":
             unit_vectors(net)
+        elif c == "eval":
+            eval_case(net)
+        elif c == "eval_metrics":
+            eval_metric_vectors()
         elif c == "scale_labels":
             scale_label_cases(net)
         else:
