@@ -1,5 +1,7 @@
-from .trainer import batch_processor, build_optimizer, change_input_variable, Runner, DataParallelShell
+from .trainer import (batch_processor, build_optimizer, change_input_variable, Runner, DataParallelShell,
+                      StepLrUpdaterHook)
 from .env import init_dist, get_dist_info, set_random_seed
+from .checkpoint import save_checkpoint, load_checkpoint, weights_to_cpu
 
 __all__ = ["batch_processor", "build_optimizer", "change_input_variable", "Runner", "DataParallelShell", "init_dist",
-           "get_dist_info", "set_random_seed"]
+           "get_dist_info", "set_random_seed", "StepLrUpdaterHook", "save_checkpoint", "load_checkpoint", "weights_to_cpu"]

@@ -93,17 +93,117 @@ class DataParallelShell(torch.nn.Module):
         return self.module(*a, **k)
 
 
-class Runner(object):
-    """The slice of mmcv.Runner the hot loop needs: model, batch_processor, optimizer, outputs, one iteration."""
+class StepLrUpdaterHook(object):
+    """mmcv 0.4.4 `LrUpdaterHook` with policy='step' (the `lr_config` of every north-star config:
+    config/cfg_kitti_baseline_kitti_odom_4gpus.py:84-91): lr = base * gamma ** (number of `step` epochs passed), with an
+    optional linear warm-up over the first `warmup_iters` iterations starting at warmup_ratio * lr."""
 
-    def __init__(self, model, batch_processor, optimizer, optimizer_hook):
+    def __init__(self, step, gamma=0.1, warmup=None, warmup_iters=0, warmup_ratio=0.1, policy="step", **kw):
+        if policy != "step":
+            raise NotImplementedError("only policy='step' (all north-star configs)")
+        if warmup not in (None, "constant", "linear", "exp"):
+            raise ValueError(f'"{warmup}" is not a supported type for warming up')
+        self.step, self.gamma = step, gamma
+        self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
+        self.base_lr, self.regular_lr = None, None
+
+    def get_lr(self, epoch, base_lr):
+        if isinstance(self.step, int):
+            return base_lr * (self.gamma ** (epoch // self.step))
+        exp = len(self.step)
+        for i, s in enumerate(self.step):
+            if epoch < s:
+                exp = i
+                break
+        return base_lr * self.gamma ** exp
+
+    def get_warmup_lr(self, cur_iters):
+        if self.warmup == "constant":
+            return [lr * self.warmup_ratio for lr in self.regular_lr]
+        if self.warmup == "linear":
+            k = (1 - cur_iters / self.warmup_iters) * (1 - self.warmup_ratio)
+            return [lr * (1 - k) for lr in self.regular_lr]
+        k = self.warmup_ratio ** (1 - cur_iters / self.warmup_iters)
+        return [lr * k for lr in self.regular_lr]
+
+    @staticmethod
+    def _set_lr(runner, lrs):
+        for g, lr in zip(runner.optimizer.param_groups, lrs):
+            g["lr"] = lr
+
+    def before_run(self, runner):
+        for g in runner.optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        self.base_lr = [g["initial_lr"] for g in runner.optimizer.param_groups]
+
+    def before_train_epoch(self, runner):
+        if self.base_lr is None:
+            self.before_run(runner)
+        self.regular_lr = [self.get_lr(runner.epoch, b) for b in self.base_lr]
+        self._set_lr(runner, self.regular_lr)
+
+    def before_train_iter(self, runner):
+        if self.warmup is None or runner.iter > self.warmup_iters:
+            return
+        if self.regular_lr is None:
+            self.before_train_epoch(runner)
+        if runner.iter == self.warmup_iters:
+            self._set_lr(runner, self.regular_lr)
+        else:
+            self._set_lr(runner, self.get_warmup_lr(runner.iter))
+
+
+class Runner(object):
+    """The slice of mmcv.Runner the hot loop needs: model, batch_processor, optimizer, outputs, one iteration, the
+    step-policy learning-rate hook, and checkpoints in mmcv's layout (save / load / resume)."""
+
+    def __init__(self, model, batch_processor, optimizer, optimizer_hook, lr_config=None, work_dir=None):
         self.model, self.batch_processor, self.optimizer, self.hook = model, batch_processor, optimizer, optimizer_hook
         self.outputs = None
         self.iter = 0
+        self.epoch = 0
+        self.work_dir = work_dir
+        self.lr_hook = StepLrUpdaterHook(**lr_config) if lr_config else None
+        if self.lr_hook is not None:
+            self.lr_hook.before_run(self)
+
+    def current_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
 
     def train_iter(self, data_batch):
         self.model.train()
+        if self.lr_hook is not None:
+            self.lr_hook.before_train_iter(self)
         self.outputs = self.batch_processor(self.model, data_batch, train_mode=True)
         self.hook.after_train_iter(self)
         self.iter += 1
         return self.outputs
+
+    def train_epoch(self, data_loader):
+        """mmcv.Runner.train: before_train_epoch hooks, one pass over the loader, epoch += 1."""
+        if self.lr_hook is not None:
+            self.lr_hook.before_train_epoch(self)
+        for batch in data_loader:
+            self.train_iter(batch)
+        self.epoch += 1
+
+    # ---- checkpoints (mmcv.Runner.save_checkpoint / load_checkpoint / resume)
+    def save_checkpoint(self, out_dir=None, filename_tmpl="epoch_{}.pth", save_optimizer=True, meta=None):
+        from .checkpoint import save_checkpoint
+        import os
+        meta = dict(meta or {}, epoch=self.epoch + 1, iter=self.iter)
+        path = os.path.join(out_dir or self.work_dir or ".", filename_tmpl.format(self.epoch + 1))
+        save_checkpoint(self.model, path, optimizer=self.optimizer if save_optimizer else None, meta=meta)
+        return path
+
+    def load_checkpoint(self, filename, map_location="cpu", strict=False):
+        from .checkpoint import load_checkpoint
+        return load_checkpoint(self.model, filename, map_location, strict)
+
+    def resume(self, checkpoint, resume_optimizer=True, map_location="cpu"):
+        ckpt = self.load_checkpoint(checkpoint, map_location=map_location)
+        self.epoch = ckpt["meta"]["epoch"]
+        self.iter = ckpt["meta"]["iter"]
+        if "optimizer" in ckpt and resume_optimizer:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        return ckpt

@@ -22,7 +22,7 @@
 //        4 pre-summed weight slots per output parity instead of 9 taps, in forward, dgrad and wgrad.
 //   "S2" parity-class dgrad of the 3x3 stride-2 convs; "C" whole-tap K chunks for the 3/6-channel stems.
 //   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
-#include "igemm.h"
+#include "igemm_p9.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -41,7 +41,7 @@ __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 // The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
 // launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
 // tiny launches per step become one.
-enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4 };
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5 };
 struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
     const float* w;
     float* wp;
@@ -97,6 +97,25 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             const int c = (int)(t % Cx), pl = (int)(t / Cx);
             if (co >= Cout) return 0.f;
             return pack_slot_sum(w + ((size_t)co * Cin + c_off + c) * 9, pl);
+        }
+        case PACK_FRAG: {      // p = Cout, Cin, for_dgrad, BMT: MFMA fragment order of the P9 kernel (igemm_p9.h), 3x3 only:
+                               // wp[M tile][chunk*144 + tap*16 + s (+ slack steps)][k parity][row in tile] =
+                               //   W(row, reduction channel chunk*32 + 2s + parity, tap); zero beyond the last step / row / channel
+            const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3];
+            const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+            const long per_tile = ((long)((red + 31) / 32) * 144 + P9_AHEAD + 1) * 2 * BMT;
+            const int mt = (int)(i / per_tile);
+            long t = i - (long)mt * per_tile;
+            const int m = mt * BMT + (int)(t % BMT);
+            t /= BMT;
+            const int par = (int)(t & 1); t >>= 1;          // t = global k-step
+            const int s_ = (int)(t & 15);
+            const long tc = t >> 4;                         // chunk*9 + tap
+            const int tap = (int)(tc % 9);
+            const int c = (int)(tc / 9) * 32 + 2 * s_ + par;
+            if (m >= rows || c >= red) return 0.f;
+            const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
+            return w[((size_t)co * Cin + ci) * 9 + tap];
         }
         default: {             // PACK_FLIP, p = Cout, Cin, c_off, C: wf[c][co][t] = w[co][c_off + c][8 - t]
             const int Cout = p[0], Cin = p[1], c_off = p[2];
@@ -1635,6 +1654,40 @@ void launch_r3(A a, B b, E e, int M, int N, int K, hipStream_t st) {
     jp_prof_after(st);
 }
 
+// P9 patch kernel (igemm_p9.h): 3x3 stride 1 pad 1, single full-resolution source.  JP_P9=0 in the environment turns
+// it off (A/B measurements); the pack needs p9_ws_floats() floats of scratch.
+inline bool p9_enabled() {
+    static const int on = [] { const char* e = getenv("JP_P9"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+inline int p9_bmt(int rows) { return rows <= 64 ? 64 : 128; }        // channels per M tile: 64 x (8x32 px) or 128 x (4x32 px)
+inline long dgrad_tap_floats(int Cin, int Cout, int KH) { return ((long)(KH * KH + 16) * Cin + 512 + 64) * ((Cout + 31) / 32 * 32); }
+inline long p9_ws_floats(int rows, int red) {
+    const int bmt = p9_bmt(rows);
+    return ((long)jp_cdiv(red, 32) * 144 + P9_AHEAD + 1) * 2 * bmt * jp_cdiv(rows, bmt);
+}
+inline bool p9_ok(int rows, int red, int N, int H, int W) {
+    const int tr = rows <= 64 ? 8 : 4;
+    return p9_enabled() && rows >= 32 && red >= 32 && red % 32 == 0 && W % 32 == 0 && H % tr == 0 &&
+           (long)jp_cdiv(rows, p9_bmt(rows)) * N * (H / tr) * (W / 32) >= 192;
+}
+template <int WM, int WN, bool REFLECT, bool REV, class E>
+const char* p9_tag() { return __PRETTY_FUNCTION__; }       // profiler tag naming the instantiation
+template <bool REFLECT, bool REV, class E>
+void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st) {
+    const int NCH = jp_cdiv(red, 32);
+    jp_prof_before(rows <= 64 ? p9_tag<1, 4, REFLECT, REV, E>() : p9_tag<2, 2, REFLECT, REV, E>(),
+                   2.0 * rows * (double)N * H * W * 9.0 * red, st);
+    if (rows <= 64) {
+        dim3 grid(N * (H / 8) * (W / 32), 1, 1);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W);
+    } else {
+        dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W);
+    }
+    jp_prof_after(st);
+}
+
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
               int up2, int H, int W) {
     Src3 s;
@@ -1702,9 +1755,11 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
     if (which == 0 && Cin <= 8) return (long)(Cout + 256) * pad32(KH * KH * 8);   // row-major pack of the stem path
-    if (which == 0) return Cin >= 16 ? ((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96) : 0;
-    // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled segment
-    if (which == 1) return Cout >= 16 ? ((long)(KH * KH + 16) * Cin + 512 + 64) * pad32(Cout) : 0;
+    if (which == 0) return Cin >= 16 ? std::max(((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96),
+                                                KH == 3 ? p9_ws_floats(Cout, pad32(Cin)) : 0L) : 0;
+    // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled
+    // segment, plus the fragment-order pack of the P9 main pass behind them
+    if (which == 1) return Cout >= 16 ? dgrad_tap_floats(Cin, Cout, KH) + (KH == 3 ? p9_ws_floats(Cin, pad32(Cout)) : 0L) : 0;
     return 0;
 }
 
@@ -1781,6 +1836,16 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     }
     if (ws && Cin >= 16 && seg_aligned(c0, c1, c2)) {   // tap-major fast path (16-channel inputs: half-empty K chunks)
         const int Cp = pad32(Cin), Kp = KH * KH * Cp;
+        const bool use_p9 = KH == 3 && stride == 1 && pad == 1 && !((c0 && up0) || (c1 && up1) || (c2 && up2)) && c1 == 0 &&
+                            c2 == 0 && p9_ok(Cout, Cin, N, H, W);
+        if (use_p9) {
+            // P9 patch kernel: the input patch of a 4x32 pixel tile is staged once per channel chunk for all 9 taps,
+            // weights stream from L2 in MFMA fragment order (igemm_p9.h); its pack takes the place of the tap-major one
+            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin), Cout, Cin, 0, p9_bmt(Cout), 0, 0, st);
+            if (pad_mode == JP_PAD_REFLECT) launch_p9<true, false>(ws, x0, e, Cout, Cin, N, H, W, st);
+            else launch_p9<false, false>(ws, x0, e, Cout, Cin, N, H, W, st);
+            JP_LAUNCH_CHECK();
+        }
         if (!ws_state) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
         PackA a{ws, Cout, Kp, Cp, KH * KH};
         const int sp = small_grid_splits(Cout, npix, Kp);
@@ -1936,6 +2001,13 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                     const int tail = (Cin > 128 && Cin % 128 <= 16) ? Cin % 128 : 0;
                     const int Mm = Cin - tail;
                     const int bn3 = Mm <= 64 ? 256 : 128;
+                    if (KH == 3 && pad == 1 && tail == 0 && p9_ok(Cin, Cout, N, H, W)) {
+                        // P9 patch kernel on dY (taps mirrored, zero fill; the reflection fold stays with the border pass);
+                        // fragment-order pack behind the tap-major one (which the border pass still reads)
+                        float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
+                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin), 0, 0, st);
+                        launch_p9<false, true>(wfr, dy, e, Cin, Cout, N, H, W, st);
+                    } else
                     if (KH == 3 && pad == 1 && Cout >= 32 && W % bn3 == 0 && npix > 64) {
                         // row-tile kernel on dY (taps mirrored, zero fill; the reflection fold stays with the border pass)
                         const Src3 sdy = make_src(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, H, W);

@@ -1,0 +1,196 @@
+// "P9" patch kernel: 3x3 stride-1 pad-1 convolution (forward, and the dgrad main pass as the same correlation with
+// reversed taps) on the fp32 MFMA pipe with NINE-fold reuse of the staged input.
+//
+// The generic engine (igemm.h) gathers a fresh 32 x BN operand tile for every (channel chunk, tap): each input element
+// is fetched from L2 and written to LDS 9 times per M tile (3 times in the row-tile kernel).  Here a workgroup owns a
+// 2-D pixel tile of TR rows x 32 columns; per 32-channel chunk it stages the (TR+2) x 34 input PATCH once -- padding
+// (zero or reflection) resolved while staging -- and all 9 taps read their MFMA B fragments from that patch at a
+// constant LDS offset (dy*PITCH + dx).  The weights (A operand) do not go through LDS at all: they are pre-packed in
+// MFMA fragment order [M tile][chunk][tap][k-pair][k parity][row in tile] (PACK_FRAG, conv.hip: a workgroup's weight
+// stream is one contiguous run, 1 KB per k-step), so a lane's A value for a k-step is ONE coalesced global load (L1/L2-resident: every workgroup of an M tile walks the same stream), prefetched a fixed
+// number of k-steps ahead into a register ring.  Per 64 MFMAs a wave therefore issues 32 coalesced weight loads,
+// 2 x 16 ds_read_b32 and ~3 patch loads / LDS stores (vs 32 gathered loads + 32 LDS stores before), and a workgroup
+// meets 2 barriers per 576 MFMAs per wave instead of per 64.
+//
+// Geometry: 4 waves; wave (wm, wn) owns rows {2wn, 2wn+1} of the pixel tile (j = 0, 1; 32 pixels = one MFMA N
+// block each) and 64 output channels (i = 0, 1): the same 2x2 grid of 32x32 accumulators as igemm.h.
+//   WM=2, WN=2: 128 channels x (4 rows x 32 cols);   WM=1, WN=4: 64 channels x (8 rows x 32 cols)
+// Preconditions (host-checked): W % 32 == 0, H % (2*WN) == 0, reduction channels padded to 32 in the pack.
+#pragma once
+#include "igemm.h"
+
+constexpr int P9_PITCH = 36;          // patch row pitch in floats: [halo | 32 pixels | halo] + 2 pad
+constexpr int P9_AHEAD = 12;          // k-steps of weight prefetch (register ring of 2*P9_AHEAD values)
+
+template <int WM, int WN, bool REFLECT, bool REV, class Epi>
+__global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
+                                                          Epi epi, int M, int C, int NCH, int H, int W) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int TR = 2 * WN, PR = TR + 2;                 // tile rows, patch rows
+    constexpr int NROW = 32 * PR / 8;                       // patch rows (c, pr) per 8-row group of the block: loads per thread
+    constexpr int STEPS = 9 * 16;                           // k-steps (of 2) per channel chunk
+    __shared__ float patch[32 * PR * P9_PITCH];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int mt, nt;
+    {   // XCD band order, see jp_igemm_kernel
+        const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
+        const int L = blockIdx.x + blockIdx.y * gx;
+        if (L < G * gy) {
+            const int j = L >> 3;
+            mt = j % gy;
+            nt = (L & 7) * (G >> 3) + j / gy;
+        } else {
+            const int i = L - G * gy;
+            mt = i % gy;
+            nt = G + i / gy;
+        }
+    }
+    const int tiles_x = W / 32, tiles_y = H / TR;
+    const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
+    const int y0 = (tr_ / tiles_x) * TR, x0 = (tr_ % tiles_x) * 32;
+    const int m0 = mt * 64 * WM;
+    const long HW = (long)H * W;
+    const float* xin = x + (long)img * C * HW;              // channel c of this image at xin + c*HW
+
+    // ---- patch staging map.  Patch row rho' = pr*32 + c; the 8 half-waves of the block take rows rho' = 8*r + w8
+    // (r = 0 .. NROW-1), lanes run along the 32 centre columns.  pr = r/4 is compile-time, c = 8*(r%4) + w8.
+    const int w8 = t >> 5, l32 = t & 31;
+    long rowoff[PR];                                        // uniform: source row offset of patch row pr, or -1 (zero row)
+#pragma unroll
+    for (int pr = 0; pr < PR; ++pr) {
+        int yy = y0 - 1 + pr;
+        if (REFLECT) yy = jp_reflect(yy, H);
+        rowoff[pr] = (yy >= 0 && yy < H) ? (long)yy * W : -1;
+    }
+    const long lane_off = (long)w8 * HW + x0 + l32;        // + 8*(r%4)*HW + rowoff[pr] + chunk*32*HW
+    // halo columns: element e = t + 256*q < 64*PR: side = e & 1, rho' = e >> 1
+    int xl = x0 - 1, xr = x0 + 32;
+    if (REFLECT) { xl = jp_reflect(xl, W); xr = jp_reflect(xr, W); }
+    const bool okl = xl >= 0, okr = xr < W;
+
+    constexpr int NHALO = (64 * PR + 255) / 256;
+    float rb[NROW], rh[NHALO];
+    // The next chunk's patch is fetched in single loads SPREAD over the current chunk's k-steps (one every
+    // P9_SPREAD steps): vector-memory returns are counted in order, so a burst of 26 possibly HBM-missing patch loads
+    // in front of the weight stream would make every following weight wait behind the whole burst.
+    auto gload_row = [&](const float* xc, int r) {
+        const int pr = r / 4;
+        const long ro = rowoff[pr];
+        rb[r] = ro >= 0 ? xc[lane_off + (long)(8 * (r % 4)) * HW + ro] : 0.f;
+    };
+    auto gload_halo = [&](const float* xc, int q) {
+        const int e = t + 256 * q;
+        float v = 0.f;
+        if (e < 64 * PR) {
+            const int side = e & 1, rp = e >> 1, pr = rp >> 5, c = rp & 31;
+            int yy = y0 - 1 + pr;
+            if (REFLECT) yy = jp_reflect(yy, H);
+            const bool ok = yy >= 0 && yy < H && (side ? okr : okl);
+            if (ok) v = xc[(long)c * HW + (long)yy * W + (side ? xr : xl)];
+        }
+        rh[q] = v;
+    };
+    auto gload = [&](int ch) {
+        const float* xc = xin + (long)ch * 32 * HW;
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) gload_row(xc, r);
+#pragma unroll
+        for (int q = 0; q < NHALO; ++q) gload_halo(xc, q);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            const int pr = r / 4, c = 8 * (r % 4) + w8;
+            patch[(c * PR + pr) * P9_PITCH + 1 + l32] = rb[r];
+        }
+#pragma unroll
+        for (int q = 0; q < NHALO; ++q) {
+            const int e = t + 256 * q;
+            if (e < 64 * PR) {
+                const int side = e & 1, rp = e >> 1, pr = rp >> 5, c = rp & 31;
+                patch[(c * PR + pr) * P9_PITCH + (side ? 33 : 0)] = rh[q];
+            }
+        }
+    };
+
+    jp_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- weight stream of this M tile: k-step q (global over chunks) = 2 x BMT floats at wt + q*2*BMT, lane (l31, lhi)
+    // reads [lhi][wm*64 + i*32 + l31]: a wave-uniform base that advances by a compile-time 2*BMT per step + one
+    // per-lane offset register
+    constexpr int BMT = 64 * WM;
+    const float* wt = wp + (long)mt * ((long)NCH * STEPS + P9_AHEAD + 1) * 2 * BMT;
+    const int aoff = lhi * BMT + wm * 64 + l31;
+    float ra[P9_AHEAD][2];
+#pragma unroll
+    for (int d = 0; d < P9_AHEAD; ++d) {
+        ra[d][0] = wt[d * 2 * BMT + aoff];
+        ra[d][1] = wt[d * 2 * BMT + aoff + 32];
+    }
+    const float* bp = patch + (lhi * PR + 2 * wn) * P9_PITCH + l31;
+
+    gload(0);
+    for (int ch = 0; ch < NCH; ++ch) {
+        lstore();
+        __syncthreads();
+        // patch of the next chunk (the last chunk re-reads its own: no branch in the unrolled stream)
+        const float* xn = xin + (long)(ch + 1 < NCH ? ch + 1 : ch) * 32 * HW;
+        const float* aq = wt + (long)ch * STEPS * 2 * BMT;
+        // B fragments are read one k-step ahead of the MFMAs that use them (offsets are compile-time: the loop over the
+        // 144 k-steps of the chunk is fully unrolled)
+        auto boff = [&](int q) -> int {
+            const int tap = q / 16, s = q % 16;
+            const int dy = REV ? 2 - tap / 3 : tap / 3, dx = REV ? 2 - tap % 3 : tap % 3;
+            return (2 * s * PR + dy) * P9_PITCH + dx;
+        };
+        float b0 = bp[boff(0)], b1 = bp[boff(0) + P9_PITCH];
+#pragma unroll
+        for (int q = 0; q < STEPS; ++q) {
+            const int qn = q + 1 < STEPS ? q + 1 : q;
+            const float nb0 = bp[boff(qn)], nb1 = bp[boff(qn) + P9_PITCH];
+            const float a0 = ra[q % P9_AHEAD][0], a1 = ra[q % P9_AHEAD][1];
+            // refill the ring slot with the weights of step q + AHEAD (the stream continues into the next chunk; the
+            // pack carries AHEAD steps of slack past the end)
+            ra[q % P9_AHEAD][0] = aq[(q + P9_AHEAD) * 2 * BMT + aoff];
+            ra[q % P9_AHEAD][1] = aq[(q + P9_AHEAD) * 2 * BMT + aoff + 32];
+            constexpr int SPREAD = (STEPS - 8) / (NROW + NHALO);
+            if (q % SPREAD == 0 && q / SPREAD < NROW) gload_row(xn, q / SPREAD);
+            if (q % SPREAD == 0 && q / SPREAD >= NROW && q / SPREAD < NROW + NHALO) gload_halo(xn, q / SPREAD - NROW);
+            // keep the software pipeline as written (loads of step q+AHEAD / q+1 issue before the MFMAs of step q; the
+            // scheduler must not hoist the whole unrolled chunk's loads to the front: 300+ live registers)
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            b0 = nb0; b1 = nb1;
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = img * (int)HW + (y0 + 2 * wn + j) * W + x0 + l31;
+        const typename Epi::St se = epi.col(p);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < M) epi.put(se, m, acc[i][j][r]);
+            }
+        }
+    }
+}

@@ -1,0 +1,93 @@
+"""Host logic of the runner slice (no GPU): mmcv-layout checkpoints incl. a torch.optim.Adam optimizer entry written the
+way the REFERENCE's runner writes it (mono/apis/trainer.py:195-198, mmcv 0.4.4 save_checkpoint), and the step-policy
+learning-rate hook with linear warm-up of config/cfg_kitti_baseline_kitti_odom_4gpus.py:84-91."""
+import os
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from jperceiver_amd.apis import Runner, StepLrUpdaterHook, build_optimizer, load_checkpoint, save_checkpoint
+from jperceiver_amd.model import MONO
+from oracle import jp_oracle as J
+
+
+def _model(ty="static"):
+    return MONO.module_dict["Baseline"](J.default_opt(height=256, width=256, occ_map_size=64, imgs_per_gpu=1, type=ty))
+
+
+def test_reference_style_checkpoint_resumes_into_flat_adam(tmp_path):
+    torch.manual_seed(0)
+    src = _model()
+    # what the reference's process would hold: DDP-wrapped names, torch.optim.Adam over model.parameters(), one step taken
+    # on the parameters that receive gradients for type='static'
+    opt = torch.optim.Adam(src.parameters(), lr=1e-4, weight_decay=0)
+    dead = ("CycledViewProjectionB.", "CrossViewTransformerB.", "LayoutDecoderB.", "LayoutTransformDecoderB.")
+    for n, p in src.named_parameters():
+        if n.endswith((".fc.weight", ".fc.bias", ".res_conv.weight", ".res_conv.bias")) or n.startswith(dead):
+            continue
+        p.grad = torch.randn_like(p) * 0.01
+    opt.step()
+    path = os.path.join(tmp_path, "epoch_3.pth")
+    torch.save({"meta": {"epoch": 3, "iter": 4321, "mmcv_version": "0.4.4"},
+                "state_dict": OrderedDict(("module." + k, v.cpu()) for k, v in src.state_dict().items()),
+                "optimizer": opt.state_dict()}, path)
+
+    dst = _model()
+    optim = build_optimizer(dst, dict(type="Adam", lr=1e-4, weight_decay=0))
+    runner = Runner(dst, None, optim, None)
+    runner.resume(path)
+    assert runner.epoch == 3 and runner.iter == 4321 and optim.arena.step_count == 1
+    for (n, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), n
+    names = [n for n, _ in src.named_parameters()]
+    where = {n: (o, k) for n, _, o, k in optim.arena.entries}
+    for i, st in opt.state_dict()["state"].items():
+        o, k = where[names[i]]
+        assert torch.equal(optim.arena.exp_avg[o:o + k], st["exp_avg"].reshape(-1)), names[i]
+        assert torch.equal(optim.arena.exp_avg_sq[o:o + k], st["exp_avg_sq"].reshape(-1)), names[i]
+    # and back: our checkpoint loads into a plain torch.optim.Adam the way the reference would resume it
+    p2 = runner.save_checkpoint(str(tmp_path))
+    assert os.path.basename(p2) == "epoch_4.pth"
+    ck = torch.load(p2, weights_only=False)
+    assert set(ck) == {"meta", "state_dict", "optimizer"} and ck["meta"]["epoch"] == 4 and ck["meta"]["iter"] == 4321
+    assert list(ck["state_dict"]) == list(src.state_dict()) and len(ck["state_dict"]) == 766
+    ref = _model()
+    load_checkpoint(ref, p2, strict=True)
+    opt2 = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    opt2.load_state_dict({"state": ck["optimizer"]["state"], "param_groups": [
+        {k: v for k, v in ck["optimizer"]["param_groups"][0].items() if k in opt2.state_dict()["param_groups"][0]}]})
+    for i, st in opt.state_dict()["state"].items():
+        assert torch.equal(opt2.state_dict()["state"][i]["exp_avg"], st["exp_avg"])
+    # a checkpoint whose optimizer state does not fit the arena is refused
+    bad = dict(ck["optimizer"])
+    bad["param_groups"] = [dict(bad["param_groups"][0], params=list(range(5)))]
+    with pytest.raises(ValueError):
+        optim.load_state_dict(bad)
+
+
+def test_step_lr_policy_with_linear_warmup():
+    class Opt:
+        param_groups = [dict(lr=1e-4)]
+
+    class R:
+        optimizer, epoch, iter = Opt(), 0, 0
+    r = R()
+    h = StepLrUpdaterHook(policy="step", warmup="linear", warmup_iters=500, warmup_ratio=1.0 / 3, step=[20, 30], gamma=0.5)
+    h.before_run(r)
+    h.before_train_epoch(r)
+    seen = {}
+    for it in (0, 1, 250, 499, 500, 501):
+        r.iter = it
+        r.optimizer.param_groups[0]["lr"] = seen.get("last", 1e-4)
+        h.before_train_iter(r)
+        seen[it] = seen["last"] = r.optimizer.param_groups[0]["lr"]
+    assert seen[0] == pytest.approx(1e-4 / 3) and seen[250] == pytest.approx(1e-4 * (1 - 0.5 * (2 / 3)))
+    assert seen[499] == pytest.approx(1e-4 * (1 - (1 / 500) * (2 / 3))) and seen[500] == 1e-4 and seen[501] == 1e-4
+    for ep, want in ((0, 1e-4), (19, 1e-4), (20, 5e-5), (29, 5e-5), (30, 2.5e-5), (179, 2.5e-5)):
+        r.epoch, r.iter = ep, 10 ** 6
+        h.before_train_epoch(r)
+        assert r.optimizer.param_groups[0]["lr"] == pytest.approx(want), ep
+    assert StepLrUpdaterHook(step=15).get_lr(31, 1e-4) == pytest.approx(1e-6)       # int step: gamma ** (epoch // step)
+    with pytest.raises(NotImplementedError):
+        StepLrUpdaterHook(policy="cosine", step=[1])

@@ -84,6 +84,12 @@ CONV_CASES = [
     (2, 72, 5, 128, 72, 3, 1, 1, 0, 1, True),       # row-tile kernel, channel tail chunk, zero pad
     (1, 3, 448, 448, 64, 7, 2, 3, 0, 0, False),     # stem at a size that takes the whole-tap K-chunk path (CP = 4)
     (1, 6, 448, 452, 64, 7, 2, 3, 0, 1, True),      # pose stem (CP = 8), ragged width
+    (2, 64, 96, 128, 256, 3, 1, 1, 1, 2, True),     # P9 patch kernel forward (reflect, 2 M tiles, 2 channel chunks)
+    (2, 128, 64, 96, 160, 3, 1, 1, 0, 1, True),     # P9 forward zero pad (M tile tail 160 = 128 + 32) AND P9 dgrad (rows 128)
+    (1, 32, 128, 256, 192, 3, 1, 1, 0, 0, False),   # P9 forward, a single channel chunk, tiles at every image border
+    (3, 160, 32, 64, 128, 3, 1, 1, 1, 2, True),     # P9 dgrad main pass + reflection border pass, 3 images, rows 160
+    (8, 64, 64, 96, 64, 3, 1, 1, 0, 0, False),      # P9 64-channel variant (8x32 pixel tiles), forward and dgrad, zero pad
+    (6, 64, 64, 128, 48, 3, 1, 1, 1, 2, True),      # ... reflect, Cout 48 (row tail inside the only M tile)
 ]
 
 
