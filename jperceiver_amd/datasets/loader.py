@@ -1,0 +1,77 @@
+"""Batch feeding for the data-parallel train step: pinned host staging + asynchronous H2D on a dedicated copy stream,
+double-buffered so that step k's upload (and device-side preprocessing) overlaps step k-1's compute.  Replaces the
+reference's synchronous `data[k].cuda()` per tensor (mono/apis/trainer.py:20-27) behind a 24-worker PIL pipeline
+(config workers_per_gpu, mono/datasets/loader/build_loader.py:18-55): at ~55 images/s per GPU that path is the bottleneck.
+
+    loader = DeviceLoader(iterable_of_cpu_batches, device, preprocess=None, depth=2)
+    for batch in loader: runner.train_iter(batch)        # tensors already on the GPU, ready on the current stream
+"""
+from __future__ import annotations
+
+import queue
+import threading
+
+import torch
+
+
+def collate(samples):
+    """mmcv.parallel.collate for dicts of equally shaped tensors / arrays: stack along a new batch dimension."""
+    out = {}
+    for k in samples[0]:
+        v0 = samples[0][k]
+        if torch.is_tensor(v0):
+            out[k] = torch.stack([s[k] for s in samples])
+        else:
+            out[k] = torch.stack([torch.as_tensor(s[k]) for s in samples])
+    return out
+
+
+class DeviceLoader:
+    def __init__(self, batches, device="cuda", preprocess=None, depth=2):
+        self.batches, self.dev, self.pre, self.depth = batches, torch.device(device), preprocess, max(1, depth)
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+
+    def _stage(self, batch):
+        """pin + enqueue the upload (and the device preprocessing) on the copy stream; -> (device batch, ready event)"""
+        with torch.cuda.stream(self.copy_stream):
+            dev_batch = {}
+            for k, v in batch.items():
+                t = torch.as_tensor(v)
+                if not t.is_pinned():
+                    t = t.contiguous().pin_memory()
+                dev_batch[k] = t.to(self.dev, non_blocking=True)
+            if self.pre is not None:
+                dev_batch = self.pre(dev_batch)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return dev_batch, ev
+
+    def __iter__(self):
+        q = queue.Queue(maxsize=self.depth)
+        stop = object()
+
+        def producer():
+            try:
+                torch.cuda.set_device(self.dev)
+                for b in self.batches:
+                    q.put(self._stage(b))
+            except BaseException as e:      # surface loader errors in the consumer
+                q.put(e)
+            q.put(stop)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is stop:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            dev_batch, ev = item
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_event(ev)                              # no host sync: the compute stream waits on the copy
+            for t in dev_batch.values():
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+            yield dev_batch
+        th.join()

@@ -61,7 +61,12 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, dvec):
         dvec = dvec.contiguous()
         call("jp_axpby", dvec, None, ctx.lv.grads, dvec.numel(), 1.0, 0.0)
-        ctx.tape.backward()
+        ops._WG_ACTIVE[0] = True
+        try:
+            ctx.tape.backward()
+        finally:
+            ops._WG_ACTIVE[0] = False
+        ops.join_param_grad_streams()
         side = getattr(ctx.tape, "side_stream", None)
         if side is not None:       # the pose branch's backward ran on its own stream: rejoin before the optimizer
             torch.cuda.current_stream(ctx.lv.vals.device).wait_stream(side)
@@ -359,6 +364,7 @@ class Baseline(nn.Module):
                 side.wait_stream(torch.cuda.current_stream(dev0))   # loss-vector gradients, dP of the photometric nodes
                 with torch.cuda.stream(side):
                     pose_tape.backward()
+                    ops.join_param_grad_streams()
 
             outer.record(side_bwd)
             outer.side_stream = side

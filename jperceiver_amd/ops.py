@@ -95,9 +95,37 @@ def set_grad_ready_hook(fn):
 def grad_ready(tag: str):
     def fire():
         if _READY_HOOK is not None:
+            join_param_grad_streams()       # the segment's wgrad kernels run on the companion stream
             _READY_HOOK(tag)
 
     _rec(True, fire)
+
+
+# ---- companion streams for parameter-gradient kernels (JP_WGRAD_STREAM=0 turns them off)
+import os as _os
+_WG_ON = _os.environ.get("JP_WGRAD_STREAM", "1") != "0"
+_WG_STREAMS = {}
+_WG_ACTIVE = [False]
+
+
+def _wgrad_stream():
+    """The companion stream of the CURRENT stream while a tape is being replayed for a training step; None otherwise."""
+    if not _WG_ON or not _WG_ACTIVE[0]:
+        return None
+    base = torch.cuda.current_stream()
+    key = (base.device, base.cuda_stream)
+    st = _WG_STREAMS.get(key)
+    if st is None:
+        st = _WG_STREAMS[key] = torch.cuda.Stream(device=base.device)
+    return st
+
+
+def join_param_grad_streams():
+    """Make the current stream wait for the parameter-gradient kernels launched on its companion stream so far."""
+    base = torch.cuda.current_stream()
+    st = _WG_STREAMS.get((base.device, base.cuda_stream))
+    if st is not None:
+        base.wait_stream(st)
 
 
 def as_var(x) -> Var:
@@ -279,45 +307,61 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             d2 = torch.empty_like(dy)
             call("jp_act_bwd", dy, y, d2, dy.numel(), act)
             dy = d2
-        if b is not None and b.rg:
-            call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
-        if w.rg:
-            nms = 0
-            if len(srcs) > 1:
-                nms = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout,
-                                                                         KH, stride, pad, pad_mode))
-            up_head = len(srcs) == 1 and srcs[0][1] and int(_jplib().fn["jp_conv2d_up_head_ok"](
-                s3[1], s3[2], 0, 0, Cout, KH, stride, pad, pad_mode, H, W))
-            if up_head:     # disparity head on an upsampled source: upsample-aware direct kernel, nothing materialised
-                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, None, 0)
-            elif nms:
-                # per-segment wgrad inside the library: full-resolution segments from their own tensors, the
-                # upsampled one in parity-class form -- no materialised concat
-                ws_w = _new((nms,), dy)
-                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nms)
-                del ws_w
-            elif (len(srcs) > 1 or srcs[0][1]) and Cin >= 32:
-                # materialise the virtual upsample+concat once: the single-source wgrad gather is ~2x faster
-                xc = _new((N, Cin, H, W), dy)
-                c0 = 0
-                for v, u in srcs:
-                    C = v.t.shape[1]
-                    if u:
-                        call("jp_upsample2x_fwd", v.t, xc, N, C, H // 2, W // 2, Cin, c0)
-                    else:
-                        call("jp_copy_channels", v.t, xc, N, C, H * W, C, 0, Cin, c0, 0)
-                    c0 += C
-                nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad))
-                ws_w = _new((nws,), dy) if nws else None
-                call("jp_conv2d_wgrad_src3", xc, Cin, 0, None, 0, 0, None, 0, 0, dy, w.g, N, H, W, Cout, KH, stride, pad,
-                     pad_mode, 1, ws_w, nws)
-                del xc, ws_w
-            else:
-                single = len(srcs) == 1 and not srcs[0][1]
-                nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad)) if single else 0
-                ws_w = _new((nws,), dy) if nws else None
-                call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
-                del ws_w
+        def param_grads():
+            if b is not None and b.rg:
+                call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
+            if w.rg:
+                nms = 0
+                if len(srcs) > 1:
+                    nms = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout,
+                                                                             KH, stride, pad, pad_mode))
+                up_head = len(srcs) == 1 and srcs[0][1] and int(_jplib().fn["jp_conv2d_up_head_ok"](
+                    s3[1], s3[2], 0, 0, Cout, KH, stride, pad, pad_mode, H, W))
+                if up_head:     # disparity head on an upsampled source: upsample-aware direct kernel, nothing materialised
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, None, 0)
+                elif nms:
+                    # per-segment wgrad inside the library: full-resolution segments from their own tensors, the
+                    # upsampled one in parity-class form -- no materialised concat
+                    ws_w = _new((nms,), dy)
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nms)
+                    del ws_w
+                elif (len(srcs) > 1 or srcs[0][1]) and Cin >= 32:
+                    # materialise the virtual upsample+concat once: the single-source wgrad gather is ~2x faster
+                    xc = _new((N, Cin, H, W), dy)
+                    c0 = 0
+                    for v, u in srcs:
+                        C = v.t.shape[1]
+                        if u:
+                            call("jp_upsample2x_fwd", v.t, xc, N, C, H // 2, W // 2, Cin, c0)
+                        else:
+                            call("jp_copy_channels", v.t, xc, N, C, H * W, C, 0, Cin, c0, 0)
+                        c0 += C
+                    nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad))
+                    ws_w = _new((nws,), dy) if nws else None
+                    call("jp_conv2d_wgrad_src3", xc, Cin, 0, None, 0, 0, None, 0, 0, dy, w.g, N, H, W, Cout, KH, stride, pad,
+                         pad_mode, 1, ws_w, nws)
+                    del xc, ws_w
+                else:
+                    single = len(srcs) == 1 and not srcs[0][1]
+                    nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad)) if single else 0
+                    ws_w = _new((nws,), dy) if nws else None
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
+                    del ws_w
+
+        # Parameter gradients are off the critical path (nothing in the backward chain reads them): they run on a
+        # companion stream of the tape's stream, so the wgrad kernels fill the CUs that the dgrad chain's kernel tails
+        # (last, partially filled round of workgroups) leave idle.  Joined in grad_ready / at the end of the backward.
+        wgs = _wgrad_stream()
+        if wgs is None:
+            param_grads()
+        elif w.rg or (b is not None and b.rg):
+            base = torch.cuda.current_stream(dy.device)
+            wgs.wait_stream(base)
+            with torch.cuda.stream(wgs):
+                param_grads()
+            dy.record_stream(wgs)
+            for v, _ in srcs:
+                v.t.record_stream(wgs)
         if any(v.rg for v, _ in srcs):
             nwd = _ws_floats(Cin, Cout, KH, 1) if Cout >= 16 else 0
             if len(srcs) == 1 and srcs[0][1] == 0:

@@ -50,6 +50,10 @@ GROUPS = [
      "of argmax(logits) vs label); depth compute_errors + median scaling + Garg crop mono/core/evaluation/pixel_error.py:27-40, "
      "mono/core/evaluation/eval_hooks.py:147-179.",
      ["jp_confusion2", "jp_depth_eval_prepare", "jp_masked_median", "jp_depth_errors"]),
+    ("Device-side input pipeline — MonoDataset.preprocess mono/datasets/mono_dataset.py:126-171 (PIL ANTIALIAS resize, bit-exact "
+     "Pillow fixed-point resampler; ToTensor; ColorJitter in torchvision tensor arithmetic) and process_topview :417-431, applied "
+     "to raw uint8 frames after one pinned async upload.",
+     ["jp_resample_h_u8", "jp_resample_v_u8", "jp_u8_to_tensor", "jp_color_jitter_op", "jp_topview_u8"]),
     ("Library plumbing.  jp_profile_*: opt-in per-kernel HIP-event timing of the implicit-GEMM launches on the streams they "
      "are launched on (bench.py's roofline leg; never active in the train step).",
      ["jp_abi_version", "jp_last_error_string", "jp_set_last_error", "jp_profile_begin", "jp_profile_count", "jp_profile_end",

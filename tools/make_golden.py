@@ -350,6 +350,71 @@ def eval_metric_vectors():
     print("eval_metrics keys", len(g), "ratio", ratio, "n_valid", int(mask.sum()))
 
 
+def sampler_vectors():
+    """Index sequences emitted by the REFERENCE's own sampler classes (mono/datasets/loader/sampler.py, imported as is)."""
+    sm = _load("mono_datasets_sampler", REF + "/mono/datasets/loader/sampler.py")
+
+    class DS:
+        def __init__(self, flag):
+            self.flag = np.asarray(flag, dtype=np.int64)
+
+        def __len__(self):
+            return len(self.flag)
+    g = {}
+    cases = {"one_group_103": np.zeros(103, np.int64), "two_groups": np.array([0] * 37 + [1] * 22, np.int64)[np.random.default_rng(0).permutation(59)]}
+    for name, flag in cases.items():
+        g[f"{name}/flag"] = flag
+        for world, spg in ((1, 3), (4, 3), (8, 1), (2, 8)):
+            for epoch in (0, 5):
+                for rank in range(world):
+                    s_ = sm.DistributedGroupSampler(DS(flag), spg, world, rank)
+                    s_.set_epoch(epoch)
+                    g[f"{name}/dgs/w{world}_s{spg}_e{epoch}_r{rank}"] = np.asarray(list(iter(s_)), np.int64)
+        for world in (1, 3):
+            for shuffle in (True, False):
+                for rank in range(world):
+                    s_ = sm.DistributedSampler(DS(flag), world, rank, shuffle=shuffle)
+                    s_.set_epoch(2)
+                    g[f"{name}/ds/w{world}_sh{int(shuffle)}_r{rank}"] = np.asarray(list(iter(s_)), np.int64)
+        np.random.seed(11)
+        g[f"{name}/gs"] = np.asarray([int(v) for v in iter(sm.GroupSampler(DS(flag), 4))], np.int64)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **g)
+    print("sampler keys", len(g))
+
+
+def preprocess_vectors():
+    """Pillow's own output for the resizes of MonoDataset.preprocess (mono/datasets/mono_dataset.py:83-92,133-147:
+    transforms.Resize(size, Image.ANTIALIAS) == Image.resize(..., LANCZOS) on 8-bit RGB) and the reference's
+    process_topview / process_topview_both (:417-431), executed line by line with PIL on hash-generated images."""
+    from PIL import Image
+    g = {}
+    for name, (H, W, OH, OW) in {"down": (94, 311, 64, 64), "up": (37, 50, 80, 120), "mixed": (60, 96, 90, 48), "same_w": (50, 64, 20, 64)}.items():
+        img = (syn.hash_uniform(21, ("pp", name), (H, W, 3)) * 256).astype(np.uint8)
+        g[f"resize/{name}/shape"] = np.array([H, W, OH, OW])
+        g[f"resize/{name}/out"] = np.asarray(Image.fromarray(img).resize((OW, OH), Image.LANCZOS))
+    # two-stage resize of the pipeline: raw -> full-res (375x1242 scaled down here) -> network size
+    img = (syn.hash_uniform(21, ("pp", "chain"), (80, 200, 3)) * 256).astype(np.uint8)
+    full = Image.fromarray(img).resize((124, 38), Image.LANCZOS)
+    g["resize/chain/full"] = np.asarray(full)
+    g["resize/chain/net"] = np.asarray(full.resize((64, 64), Image.LANCZOS))
+    for name, (h, w, S) in {"sq": (128, 128, 32), "rect": (100, 150, 64), "up": (20, 24, 32)}.items():
+        lab = ((syn.hash_uniform(22, ("tv", name), (h, w)) > 0.55) * 255).astype(np.uint8)
+        lab3 = np.stack([lab, lab, lab], -1)
+        for mode, arr in (("L", lab), ("RGB", lab3)):
+            tv = Image.fromarray(arr).convert("1").resize((S, S), Image.NEAREST).convert("L")       # process_topview
+            a = np.array(tv)
+            o = np.zeros(a.shape)
+            o[a == 255] = 1
+            g[f"topview/{name}/{mode}"] = o.astype(np.uint8)
+        tb = np.array(Image.fromarray(lab).resize((S, S), Image.NEAREST))                         # process_topview_both
+        o = np.zeros(tb.shape)
+        o[tb == 255] = 1
+        g[f"topview_both/{name}"] = o.astype(np.uint8)
+        g[f"topview/{name}/shape"] = np.array([h, w, S])
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **g)
+    print("preprocess keys", len(g))
+
+
 def scale_label_cases(net):
     """get_scale_label_static / get_scale_label_dynamic (net.py:212-402) run by the REFERENCE on the synthetic
     calibration (third-party pieces stubbed as above) -> tests/golden/scale_labels.npz: the 0/1 support as packed
@@ -403,7 +468,7 @@ CASES = {
 
 if __name__ == "__main__":
     net = import_reference()
-    want = sys.argv[1:] or (["unit", "scale_labels", "eval", "eval_metrics"] + list(CASES))
+    want = sys.argv[1:] or (["unit", "scale_labels", "eval", "eval_metrics", "sampler", "preprocess"] + list(CASES))
     for c in want:
         if c == "unit":
             unit_vectors(net)
@@ -411,6 +476,10 @@ if __name__ == "__main__":
             eval_case(net)
         elif c == "eval_metrics":
             eval_metric_vectors()
+        elif c == "sampler":
+            sampler_vectors()
+        elif c == "preprocess":
+            preprocess_vectors()
         elif c == "scale_labels":
             scale_label_cases(net)
         else:

@@ -29,12 +29,21 @@ def main(fetch_db, write_db, out_json):
     known = 4.0 * n
     kf = known / (sum(v for v, _ in cf) / len(cf) * 1024.0)
     kw = known / (sum(v for v, _ in cw) / len(cw) * 1024.0)
-    dom = [k for k in F if re.search(r"jp_igemm_r3_kernel<2, 2, 32.*PackA.*FwdBR3<true, false, 128>.*FwdEpi", k)]
+    # the kernel bench.py reported as by-time dominant (bench_families.json -> roofline.kernel), matched on its
+    # template-argument text; falls back to the dispatch-count-weighted largest igemm kernel
+    want = None
+    if len(sys.argv) > 4:
+        want = json.load(open(sys.argv[4]))["roofline"]["kernel"].split(" \u2014 ")[0].split(" — ")[0]
+    norm = lambda t: re.sub(r"\(anonymous namespace\)::", "", t).replace(" ", "")
+    dom = [k for k in F if want and norm(k).startswith(norm(want))]
+    if not dom:
+        ig = [k for k in F if "jp_igemm" in k]
+        dom = [max(ig, key=lambda k: sum(v for v, _ in F[k]))]
     assert len(dom) == 1, dom
     fv = [v for v, _ in F[dom[0]]]
     wv = [v for v, _ in W[dom[0]]]
     res = {
-        "kernel": re.sub(r"\(anonymous namespace\)::", "", dom[0])[:120],
+        "kernel": re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", dom[0]).split("(")[0])[:160],
         "launches_profiled": len(fv),
         "fetch_KB_raw_avg": sum(fv) / len(fv), "write_KB_raw_avg": sum(wv) / len(wv),
         "calibration": {"copy_bytes_each_way": known, "fetch_factor": kf, "write_factor": kw,
