@@ -28,7 +28,10 @@ def collate(samples):
 
 class DeviceLoader:
     def __init__(self, batches, device="cuda", preprocess=None, depth=2):
-        self.batches, self.dev, self.pre, self.depth = batches, torch.device(device), preprocess, max(1, depth)
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.batches, self.dev, self.pre, self.depth = batches, dev, preprocess, max(1, depth)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
 
     def _stage(self, batch):

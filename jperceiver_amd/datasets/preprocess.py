@@ -76,7 +76,10 @@ class DevicePreprocessor:
     """Preprocess one uploaded batch.  Tables are cached per (in, out) size; everything runs on the caller's stream."""
 
     def __init__(self, height, width, device):
-        self.h, self.w, self.dev = height, width, torch.device(device)
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.h, self.w, self.dev = height, width, dev
         self._tab = {}
 
     def _tables(self, n_in, n_out):
