@@ -20,16 +20,21 @@
 #include "igemm.h"
 
 constexpr int P9_PITCH = 36;          // patch row pitch in floats: [halo | 32 pixels | halo] + 2 pad
-constexpr int P9_AHEAD = 12;          // k-steps of weight prefetch (register ring of 2*P9_AHEAD values)
+constexpr int P9_AHEAD = 8;           // k-steps of weight prefetch (register ring of 2*P9_AHEAD values)
 
-template <int WM, int WN, bool REFLECT, bool REV, class Epi>
+// TAPS = 9: 3x3 (patch with a one-pixel halo).  TAPS = 1: 1x1 convolution ("P1": no halo; CPB = 2 channel chunks are
+// staged per barrier pair so that the barrier density stays at 2 per 128 MFMAs).
+template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS = 9, int CPB = 1>
 __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
                                                           Epi epi, int M, int C, int NCH, int H, int W) {
     static_assert(WM * WN == 4, "4 waves per block");
-    constexpr int TR = 2 * WN, PR = TR + 2;                 // tile rows, patch rows
-    constexpr int NROW = 32 * PR / 8;                       // patch rows (c, pr) per 8-row group of the block: loads per thread
-    constexpr int STEPS = 9 * 16;                           // k-steps (of 2) per channel chunk
-    __shared__ float patch[32 * PR * P9_PITCH];
+    static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
+    constexpr int HALO = TAPS == 9 ? 1 : 0;
+    constexpr int CS = 32 * CPB;                            // channels staged per barrier pair
+    constexpr int TR = 2 * WN, PR = TR + 2 * HALO;          // tile rows, patch rows
+    constexpr int NROW = CS * PR / 8;                       // patch rows (c, pr) per 8-row group of the block: loads per thread
+    constexpr int STEPS = TAPS * 16 * CPB;                  // k-steps (of 2) per stage
+    __shared__ float patch[CS * PR * P9_PITCH];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -56,13 +61,13 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
     const long HW = (long)H * W;
     const float* xin = x + (long)img * C * HW;              // channel c of this image at xin + c*HW
 
-    // ---- patch staging map.  Patch row rho' = pr*32 + c; the 8 half-waves of the block take rows rho' = 8*r + w8
-    // (r = 0 .. NROW-1), lanes run along the 32 centre columns.  pr = r/4 is compile-time, c = 8*(r%4) + w8.
+    // ---- patch staging map.  Patch row rho' = pr*CS + c; the 8 half-waves of the block take rows rho' = 8*r + w8
+    // (r = 0 .. NROW-1), lanes run along the 32 centre columns.  pr = r/(CS/8) is compile-time, c = 8*(r%(CS/8)) + w8.
     const int w8 = t >> 5, l32 = t & 31;
     long rowoff[PR];                                        // uniform: source row offset of patch row pr, or -1 (zero row)
 #pragma unroll
     for (int pr = 0; pr < PR; ++pr) {
-        int yy = y0 - 1 + pr;
+        int yy = y0 - HALO + pr;
         if (REFLECT) yy = jp_reflect(yy, H);
         rowoff[pr] = (yy >= 0 && yy < H) ? (long)yy * W : -1;
     }
@@ -72,21 +77,20 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
     if (REFLECT) { xl = jp_reflect(xl, W); xr = jp_reflect(xr, W); }
     const bool okl = xl >= 0, okr = xr < W;
 
-    constexpr int NHALO = (64 * PR + 255) / 256;
-    float rb[NROW], rh[NHALO];
-    // The next chunk's patch is fetched in single loads SPREAD over the current chunk's k-steps (one every
-    // P9_SPREAD steps): vector-memory returns are counted in order, so a burst of 26 possibly HBM-missing patch loads
-    // in front of the weight stream would make every following weight wait behind the whole burst.
+    constexpr int NHALO = HALO ? (2 * CS * PR + 255) / 256 : 0;
+    float rb[NROW], rh[NHALO > 0 ? NHALO : 1];
+    // (Measured and rejected: spreading the next patch's loads one by one over the current chunk's k-steps instead of
+    // issuing them as one burst behind the barrier -- 128 -> 83 TF.)
     auto gload_row = [&](const float* xc, int r) {
-        const int pr = r / 4;
+        const int pr = r / (CS / 8);
         const long ro = rowoff[pr];
-        rb[r] = ro >= 0 ? xc[lane_off + (long)(8 * (r % 4)) * HW + ro] : 0.f;
+        rb[r] = ro >= 0 ? xc[lane_off + (long)(8 * (r % (CS / 8))) * HW + ro] : 0.f;
     };
     auto gload_halo = [&](const float* xc, int q) {
         const int e = t + 256 * q;
         float v = 0.f;
-        if (e < 64 * PR) {
-            const int side = e & 1, rp = e >> 1, pr = rp >> 5, c = rp & 31;
+        if (e < 2 * CS * PR) {
+            const int side = e & 1, rp = e >> 1, pr = rp / CS, c = rp % CS;
             int yy = y0 - 1 + pr;
             if (REFLECT) yy = jp_reflect(yy, H);
             const bool ok = yy >= 0 && yy < H && (side ? okr : okl);
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
         rh[q] = v;
     };
     auto gload = [&](int ch) {
-        const float* xc = xin + (long)ch * 32 * HW;
+        const float* xc = xin + (long)ch * CS * HW;
 #pragma unroll
         for (int r = 0; r < NROW; ++r) gload_row(xc, r);
 #pragma unroll
@@ -104,14 +108,14 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
     auto lstore = [&]() {
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-            const int pr = r / 4, c = 8 * (r % 4) + w8;
+            const int pr = r / (CS / 8), c = 8 * (r % (CS / 8)) + w8;
             patch[(c * PR + pr) * P9_PITCH + 1 + l32] = rb[r];
         }
 #pragma unroll
         for (int q = 0; q < NHALO; ++q) {
             const int e = t + 256 * q;
-            if (e < 64 * PR) {
-                const int side = e & 1, rp = e >> 1, pr = rp >> 5, c = rp & 31;
+            if (e < 2 * CS * PR) {
+                const int side = e & 1, rp = e >> 1, pr = rp / CS, c = rp % CS;
                 patch[(c * PR + pr) * P9_PITCH + (side ? 33 : 0)] = rh[q];
             }
         }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
     // reads [lhi][wm*64 + i*32 + l31]: a wave-uniform base that advances by a compile-time 2*BMT per step + one
     // per-lane offset register
     constexpr int BMT = 64 * WM;
-    const float* wt = wp + (long)mt * ((long)NCH * STEPS + P9_AHEAD + 1) * 2 * BMT;
+    const float* wt = wp + (long)mt * ((long)NCH * STEPS + P9_AHEAD + 1) * 2 * BMT;     // NCH = number of STAGES here
     const int aoff = lhi * BMT + wm * 64 + l31;
     float ra[P9_AHEAD][2];
 #pragma unroll
@@ -143,15 +147,14 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
     for (int ch = 0; ch < NCH; ++ch) {
         lstore();
         __syncthreads();
-        // patch of the next chunk (the last chunk re-reads its own: no branch in the unrolled stream)
-        const float* xn = xin + (long)(ch + 1 < NCH ? ch + 1 : ch) * 32 * HW;
+        if (ch + 1 < NCH) gload(ch + 1);                   // next stage's patch: in flight during the MFMAs below
         const float* aq = wt + (long)ch * STEPS * 2 * BMT;
         // B fragments are read one k-step ahead of the MFMAs that use them (offsets are compile-time: the loop over the
         // 144 k-steps of the chunk is fully unrolled)
         auto boff = [&](int q) -> int {
-            const int tap = q / 16, s = q % 16;
-            const int dy = REV ? 2 - tap / 3 : tap / 3, dx = REV ? 2 - tap % 3 : tap % 3;
-            return (2 * s * PR + dy) * P9_PITCH + dx;
+            const int cc = q / (TAPS * 16), tap = (q / 16) % TAPS, s = q % 16;       // pack order: chunk, tap, k-pair
+            const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 1 : (REV ? 2 - tap % 3 : tap % 3);
+            return ((cc * 32 + 2 * s) * PR + dy) * P9_PITCH + dx;
         };
         float b0 = bp[boff(0)], b1 = bp[boff(0) + P9_PITCH];
 #pragma unroll
@@ -163,9 +166,6 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
             // pack carries AHEAD steps of slack past the end)
             ra[q % P9_AHEAD][0] = aq[(q + P9_AHEAD) * 2 * BMT + aoff];
             ra[q % P9_AHEAD][1] = aq[(q + P9_AHEAD) * 2 * BMT + aoff + 32];
-            constexpr int SPREAD = (STEPS - 8) / (NROW + NHALO);
-            if (q % SPREAD == 0 && q / SPREAD < NROW) gload_row(xn, q / SPREAD);
-            if (q % SPREAD == 0 && q / SPREAD >= NROW && q / SPREAD < NROW + NHALO) gload_halo(xn, q / SPREAD - NROW);
             // keep the software pipeline as written (loads of step q+AHEAD / q+1 issue before the MFMAs of step q; the
             // scheduler must not hoist the whole unrolled chunk's loads to the front: 300+ live registers)
             __builtin_amdgcn_sched_barrier(0);

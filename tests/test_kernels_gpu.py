@@ -90,6 +90,10 @@ CONV_CASES = [
     (3, 160, 32, 64, 128, 3, 1, 1, 1, 2, True),     # P9 dgrad main pass + reflection border pass, 3 images, rows 160
     (8, 64, 64, 96, 64, 3, 1, 1, 0, 0, False),      # P9 64-channel variant (8x32 pixel tiles), forward and dgrad, zero pad
     (6, 64, 64, 128, 48, 3, 1, 1, 1, 2, True),      # ... reflect, Cout 48 (row tail inside the only M tile)
+    (2, 64, 96, 128, 256, 1, 1, 0, 0, 0, False),    # P1 (1x1 through the patch kernel): forward, 2 M tiles, one 64-channel stage
+    (8, 128, 64, 64, 128, 1, 1, 0, 0, 1, True),     # P1 forward + dgrad, two stages, bias + relu
+    (8, 64, 64, 96, 64, 1, 1, 0, 0, 0, False),      # P1 64-channel variant (8x32 pixel tiles), forward + dgrad
+    (2, 192, 64, 64, 160, 1, 1, 0, 0, 2, True),     # P1: 3 stages, M tile tail (160), dgrad rows 192
 ]
 
 
