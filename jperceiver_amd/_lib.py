@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "csrc", "libjperceiver_hip.so")
+LIB_PATH = os.environ.get("JP_LIB_PATH") or os.path.join(_HERE, "csrc", "libjperceiver_hip.so")   # override: kernel A/B builds
 HEADER_PATH = os.path.join(_ROOT, "include", "jperceiver_hip.h")
 
 _CT = {
