@@ -47,35 +47,30 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__device__ __forceinline__ double bn_partial_sum(const double* __restrict__ sums, int row, int S) {
-    double t = 0.0;
-    for (int i = 0; i < S; ++i) t += sums[(size_t)row * S + i];
-    return t;
-}
-
-// C threads: mean / invstd and running-stat momentum update (applied n_updates times: the
-// reference evaluates the layout branch twice per iteration).
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int C, double count, float momentum, float eps,
-                                   int n_updates, int S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double m = bn_partial_sum(sums, 2 * c, S) / count;
-    double var = bn_partial_sum(sums, 2 * c + 1, S) / count - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const float unb = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
-        float rm = running_mean[c], rv = running_var[c];
-        for (int i = 0; i < n_updates; ++i) {
-            rm = (1.f - momentum) * rm + momentum * (float)m;
-            rv = (1.f - momentum) * rv + momentum * unb;
+// One wave of every apply workgroup folds its channel's partial sums (fixed order -> every workgroup of a channel gets
+// the same bits): mean / invstd, and -- by image 0's first workgroup only -- the saved statistics for backward and the
+// running-stat momentum update (applied n_updates times: the reference evaluates the layout branch twice per iteration,
+// SURVEY.md N4).  Replaces a separate C-thread "finalize" launch per layer (120 launches, 1.8 ms per step).
+__device__ __forceinline__ void bn_channel_stats(const double* __restrict__ sums, int c, int S, double count, float eps,
+                                                 double* __restrict__ tot /* LDS[2] */, float* mean_out, float* invstd_out,
+                                                 double* var_out) {
+    if (threadIdx.x < 64) {
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < S; i += 64) {
+            a += sums[(size_t)(2 * c) * S + i];
+            b += sums[(size_t)(2 * c + 1) * S + i];
         }
-        running_mean[c] = rm;
-        running_var[c] = rv;
+        a = jp_wave_sum_d(a);
+        b = jp_wave_sum_d(b);
+        if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
     }
+    __syncthreads();
+    const double m = tot[0] / count;
+    double var = tot[1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    *mean_out = (float)m;
+    *invstd_out = (float)(1.0 / sqrt(var + (double)eps));
+    *var_out = var;
 }
 
 // The normalised value is ALWAYS formed as fmaf(x, sc, sh) with sc = invstd*gamma, sh = beta - mean*sc: the backward
@@ -106,17 +101,37 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
     }
 }
 
-// y = relu?( (x-mean)*invstd*gamma + beta (+ residual) )
-__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd,
+// y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ), statistics from the stats kernel's partial sums
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, const double* __restrict__ sums,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ residual, float* __restrict__ y,
-                                                       int C, int HW, int relu) {
+                                                       int C, int HW, int relu, double count, float momentum, float eps,
+                                                       int n_updates, int S) {
+    __shared__ double tot[2];
     const int nc = blockIdx.y;  // n*C + c
     const int c = nc % C;
-    const float sc = invstd[c] * gamma[c];
-    const float sh = bn_shift(beta[c], mean[c], sc);
+    float mean, invstd;
+    double var;
+    bn_channel_stats(sums, c, S, count, eps, tot, &mean, &invstd, &var);
+    if (nc < C && blockIdx.x == 0 && threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const float unb = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+            float rm = running_mean[c], rv = running_var[c];
+            for (int i = 0; i < n_updates; ++i) {
+                rm = (1.f - momentum) * rm + momentum * mean;
+                rv = (1.f - momentum) * rv + momentum * unb;
+            }
+            running_mean[c] = rm;
+            running_var[c] = rv;
+        }
+    }
+    const float sc = invstd * gamma[c];
+    const float sh = bn_shift(beta[c], mean, sc);
     bn_apply_body(x, residual, y, sc, sh, (size_t)nc * HW, HW, relu);
 }
 
@@ -305,11 +320,9 @@ extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* 
     int CH, chunk;
     chunking(N, C, HW, &CH, &chunk);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(jp_cdiv(C, 64)), dim3(64), 0, st, ws, save_mean, save_invstd,
-                       running_mean, running_var, C, (double)N * HW, momentum, eps, n_updates, N * CH);
     const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, save_mean, save_invstd, gamma, beta,
-                       residual, y, C, HW, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, ws, save_mean, save_invstd, running_mean,
+                       running_var, gamma, beta, residual, y, C, HW, relu, (double)N * HW, momentum, eps, n_updates, N * CH);
     JP_LAUNCH_CHECK();
 }
 

@@ -1081,17 +1081,42 @@ struct DgradUPBorderB {   // only the clamp-folded entries: (extra row, any colu
         if (st.o3 >= 0) v += q[st.o3];
         return v;
     }
+    // slots (a, b, r, s) that fold something in for some pixel of the tile (see chunk()); the rest are stepped over
+    static constexpr bool SKIP = true;
+    __device__ __forceinline__ unsigned tile_mask(const St& st) const {
+        __shared__ unsigned tm;
+        if (threadIdx.x == 0) tm = 0;
+        __syncthreads();
+        unsigned mine = 0;
+        if (st.px.valid) {
+            const int i = st.px.y, j = st.px.x;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int a = q >> 3, b = (q >> 2) & 1, r = (q >> 1) & 1, s2 = q & 1;
+                const bool er = (i == 0 && a == 0 && r == 0) || (i == h2 - 1 && a == 1 && r == 1);
+                const bool ec = (j == 0 && b == 0 && s2 == 0) || (j == w2 - 1 && b == 1 && s2 == 1);
+                if (er || ec) mine |= 1u << q;
+            }
+        }
+        if (mine) atomicOr(&tm, mine);
+        __syncthreads();
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)tm);
+    }
+    __device__ __forceinline__ bool skip(unsigned m, int kc) const { return !((m >> ((kc >> 5) & 15)) & 1u); }
 };
 struct DgradEdgeEpi {  // dx[img][c][y][x] += acc for the boundary pixel b of a (h, w) map
     typedef long St;
     float* dx;
-    int C, h, w, Nb;
+    int C, h, w, Nb, split;
     __device__ __forceinline__ St col(int b) const {
         const InPixSt px = edge_pix(b, Nb, h, w);
         return px.valid ? (long)px.img * C * h * w + px.y * w + px.x : -1;
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
-        if (base >= 0) atomicAdd(dx + base + (size_t)m * h * w, v);
+        if (base < 0) return;
+        float* q = dx + base + (size_t)m * h * w;
+        if (split) atomicAdd(q, v);       // split-K partials meet here
+        else *q += v;                     // one workgroup owns the pixel: plain read-modify-write
     }
 };
 
@@ -1266,18 +1291,52 @@ struct DgradBorderB {   // scalar-base: uniform dY plane pointer + three per-lan
         return fmaf(st.m1, a, fmaf(st.m2, b, st.m3 * c));
     }
     __device__ __forceinline__ float post(const St&, float v, int) const { return v; }
+    // Only the taps that fold something in are non-zero: (ty, tx) with a row extra at ty (y == 1 / H-2) or a column
+    // extra at tx (x == 1 / W-2).  A pixel tile lies along one edge, so it needs 3 of the 9 taps (5 next to a corner):
+    // the engine steps over the other K chunks.
+    static constexpr bool SKIP = true;
+    __device__ __forceinline__ unsigned tile_mask(const St& st) const {
+        __shared__ unsigned tm;
+        if (threadIdx.x == 0) tm = 0;
+        __syncthreads();
+        unsigned mine = 0;
+        if (st.px.valid) {
+            const unsigned ry = (st.px.y == 1 ? 1u : 0u) | (st.px.y == H - 2 ? 4u : 0u);
+            const unsigned cx = (st.px.x == 1 ? 1u : 0u) | (st.px.x == W - 2 ? 4u : 0u);
+#pragma unroll
+            for (int ty = 0; ty < KH; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < KH; ++tx)
+                    if (((ry >> ty) | (cx >> tx)) & 1u) mine |= 1u << (ty * KH + tx);
+        }
+        if (mine) atomicOr(&tm, mine);
+        __syncthreads();
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)tm);
+    }
+    __device__ __forceinline__ bool skip(unsigned m, int kc) const { return !((m >> ((kc >> 5) % (KH * KH))) & 1u); }
 };
+
+// Split policy of the border passes.  Their cost is the scattered read-modify-write of the epilogue (one 4-byte access per
+// 64-byte sector, atomics when K is split: 12.6 M atomics = 0.24 ms for a 256-channel 256x256 layer with 6 splits), not
+// the K loop -- so K is split only when the pass would otherwise be a few dozen workgroups.
+static inline int border_splits(long btiles, int chunks) {
+    if (btiles >= 48) return 1;
+    return (int)std::max<long>(1, std::min<long>(jp_cdiv(96, btiles), chunks / 4));
+}
 
 struct DgradBorderEpi {  // dx[img][ci][y][x] += acc for the border pixel b
     typedef long St;
     float* dx;
-    int Cin, H, W, Nb;
+    int Cin, H, W, Nb, split;
     __device__ __forceinline__ St col(int b) const {
         const InPixSt px = border_pix(b, Nb, H, W);
         return px.valid ? (long)px.img * Cin * H * W + px.y * W + px.x : -1;
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
-        if (base >= 0) atomicAdd(dx + base + (size_t)m * H * W, v);   // split-K partials meet here
+        if (base < 0) return;
+        float* q = dx + base + (size_t)m * H * W;
+        if (split) atomicAdd(q, v);       // split-K partials meet here
+        else *q += v;                     // one workgroup owns the pixel: plain read-modify-write
     }
 };
 
@@ -2073,11 +2132,12 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         if (pad_mode == JP_PAD_REFLECT) {   // fold the reflected ring back in (border-adjacent lines only)
             const int Nb = N * (2 * W + 2 * H);
             DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
-            DgradBorderEpi be{dx, Cin, H, W, Nb};
+            DgradBorderEpi be{dx, Cin, H, W, Nb, 0};
             // a few dozen tiles only: split K so the pass is not one workgroup's whole K loop long
             const long btiles = (long)jp_cdiv(Cin, Cin <= 64 ? 64 : 128) * jp_cdiv(Nb, Cin <= 64 ? 256 : 128);
-            const int bsp = (int)std::max<long>(1, std::min<long>(jp_cdiv(768, btiles), Kp / KC / 4));
+            const int bsp = border_splits(btiles, Kp / KC);
             const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
+            be.split = jp_cdiv(Kp, bkps) > 1;
             launch_auto(a, bb, be, Cin, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
         }
     } else {
@@ -2157,10 +2217,11 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             }
             const int Nb = N * (2 * W + 2 * H);
             DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
-            DgradBorderEpi be{dx, C, H, W, Nb};
+            DgradBorderEpi be{dx, C, H, W, Nb, 0};
             const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
-            const int bsp = (int)std::max<long>(1, std::min<long>(jp_cdiv(768, btiles), Kp / KC / 4));
+            const int bsp = border_splits(btiles, Kp / KC);
             const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
+            be.split = jp_cdiv(Kp, bkps) > 1;
             launch_auto(a, bb, be, C, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
         } else if (dx) {
             const int h2 = H / 2, w2 = W / 2, KpU = 16 * Cp;
@@ -2172,10 +2233,11 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             launch_auto(a, bu, e, C, (int)np2, KpU, 1, KpU, st);
             const int Nb = N * (2 * w2 + 2 * h2);
             DgradUPBorderB bb{dy, Nb, h2, w2, Cout};
-            DgradEdgeEpi be{dx, C, h2, w2, Nb};
+            DgradEdgeEpi be{dx, C, h2, w2, Nb, 0};
             const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
-            const int bsp = (int)std::max<long>(1, std::min<long>(jp_cdiv(768, btiles), KpU / KC / 4));
+            const int bsp = border_splits(btiles, KpU / KC);
             const int bkps = jp_cdiv(jp_cdiv(KpU, bsp), KC) * KC;
+            be.split = jp_cdiv(KpU, bkps) > 1;
             launch_auto(a, bb, be, C, Nb, KpU, jp_cdiv(KpU, bkps), bkps, st);
         }
         coff += C;

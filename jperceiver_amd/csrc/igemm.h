@@ -36,6 +36,8 @@ template <class L, class = void> struct jp_has_all_ok : std::false_type {};   //
 template <class L> struct jp_has_all_ok<L, std::void_t<decltype(L::ALL_OK)>> : std::true_type {};
 template <class L, class = void> struct jp_wants_tile : std::false_type {};   // init(st, first, step, m0, n0)
 template <class L> struct jp_wants_tile<L, std::void_t<decltype(L::WANTS_TILE)>> : std::true_type {};
+template <class L, class = void> struct jp_has_skip : std::false_type {};    // unsigned tile_mask(st); bool skip(mask, kc)
+template <class L> struct jp_has_skip<L, std::void_t<decltype(L::SKIP)>> : std::true_type {};
 template <class L, class = void> struct jp_has_split : std::false_type {};
 template <class L> struct jp_has_split<L, std::void_t<decltype(L::SPLIT)>> : std::true_type {};
 
@@ -260,13 +262,24 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
             __syncthreads();
         }
     } else {
-        if (kbeg < kend) gload(kbeg);
-        for (int kc = kbeg; kc < kend; kc += KC) {
+        // SKIP loaders name K chunks that are zero for the whole pixel tile (workgroup-uniform): those are stepped over
+        unsigned tmask = 0;
+        if constexpr (jp_has_skip<BLoad>::value) tmask = bl.tile_mask(sb);
+        auto adv = [&](int kc) {
+            if constexpr (jp_has_skip<BLoad>::value)
+                while (kc < kend && bl.skip(tmask, kc)) kc += KC;
+            return kc;
+        };
+        int kc = adv(kbeg);
+        if (kc < kend) gload(kc);
+        while (kc < kend) {
             lstore(0);
             __syncthreads();
-            if (kc + KC < kend) gload(kc + KC);  // in flight during the MFMAs below
+            const int kn = adv(kc + KC);
+            if (kn < kend) gload(kn);  // in flight during the MFMAs below
             compute(0);
             __syncthreads();
+            kc = kn;
         }
     }
 
