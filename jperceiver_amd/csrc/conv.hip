@@ -23,6 +23,7 @@
 //   "S2" parity-class dgrad of the 3x3 stride-2 convs; "C" whole-tap K chunks for the 3/6-channel stems.
 //   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
 #include "igemm_p9.h"
+#include "igemm_w9.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -1769,6 +1770,50 @@ void launch_p1(const float* wp, const float* x, E e, int rows, int red, int N, i
     jp_prof_after(st);
 }
 
+// ---- W9 patch wgrad (igemm_w9.h): 3x3 s1 p1, single full-resolution source, >= 128 output channels, input channels a
+// multiple of 64.  One 12-wave workgroup per CU: the K (pixel-tile) range is split so that ~256 workgroups exist.
+static bool w9_enabled() {
+    static const bool on = [] { const char* e = getenv("JP_W9"); return !(e && e[0] == '0'); }();
+    return on;
+}
+struct W9Plan { int splits, tps, ntiles, slices, narrow; long need; };
+static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W9Plan* p) {
+    if (!w9_enabled() || KH != 3 || stride != 1 || pad != 1 || W % 32 || H % W9_TR || Cm < 64 || Cm % 64 || Cout < 48 ||
+        (long)N * H * W >= (1L << 31))
+        return false;
+    const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
+    const int ntiles = N * (H / W9_TR) * (W / 32), kg = narrow ? 2 : 1;
+    const long out_tiles = (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128), per = (long)Cout * 9 * Cm;
+    long sp = std::max<long>(1, std::min<long>(256 / std::max<long>(1, out_tiles), ntiles / 2));
+    sp = std::min<long>(sp, ws_floats / (per * kg));
+    if (sp < 1 || ntiles < 8) return false;
+    const int tps = (int)jp_cdiv(ntiles, sp);
+    p->splits = jp_cdiv(ntiles, tps);
+    p->tps = tps;
+    p->ntiles = ntiles;
+    p->narrow = narrow;
+    p->slices = p->splits * kg;
+    p->need = (long)p->slices * per;
+    return true;
+}
+template <int MW, int KG, bool REFLECT>
+const char* w9_tag() { return __PRETTY_FUNCTION__; }
+template <bool REFLECT>
+static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
+                      const W9Plan& p, hipStream_t st) {
+    jp_prof_before(p.narrow ? w9_tag<1, 2, REFLECT>() : w9_tag<2, 1, REFLECT>(), 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+    if (p.narrow) {
+        dim3 grid(Cm / 64, jp_cdiv(Cout, 64), p.splits);
+        hipLaunchKernelGGL((jp_wgrad_w9_kernel<1, 2, 2, REFLECT>), grid, dim3(768), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                           p.ntiles, p.tps);
+    } else {
+        dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
+        hipLaunchKernelGGL((jp_wgrad_w9_kernel<2, 2, 1, REFLECT>), grid, dim3(768), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                           p.ntiles, p.tps);
+    }
+    jp_prof_after(st);
+}
+
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
               int up2, int H, int W) {
     Src3 s;
@@ -2313,6 +2358,26 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         return 0;
     };
     JP_CHECK_ARG(whole || single, "conv2d_wgrad: internal sub-range call must be single-source");
+    W9Plan w9;
+    // W9 patch kernel on the 64-aligned channels (+ a table pass for a short channel tail, e.g. 513 = 512 + 1): input patch
+    // staged once per pixel tile for all 9 taps, dY fragments straight from global memory
+    const int c9 = Cin / 64 * 64, tail9 = Cin - c9;
+    if (single && ws && (tail9 == 0 || (tail9 <= 32 && c9 >= 128)) &&
+        w9_plan(N, c9, H, W, Cout, KH, stride, pad, ws_floats, &w9)) {
+        if (pad_mode == JP_PAD_REFLECT) launch_w9<true>(dy, x0, ws, N, Cin, c9, H, W, Cout, w9, st);
+        else launch_w9<false>(dy, x0, ws, N, Cin, c9, H, W, Cout, w9, st);
+        const long total = (long)Cout * 9 * c9;
+        if (w9.slices >= 16)     // many slices: 16 slice lanes per output instead of one serial chain of loads
+            hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((int)((total + 63) / 64)), dim3(1024), 0, st, ws, dw, Cout, 9 * c9,
+                               w9.slices, c9, c9, 9, dw_coff, dw_ctot);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, ws,
+                               dw, Cout, 9 * c9, w9.slices, c9, c9, 9, dw_coff, dw_ctot);
+        if (tail9) {
+            const int rc = run_table(c9, tail9);
+            if (rc) return rc;
+        }
+    } else
     if (!single && Cin < 32) {          // generic (channel-major) path: multi-source inputs with few channels
         WgradEpi e{dw, Kw};
         plan(Kw, &splits, &kps);
@@ -2496,7 +2561,9 @@ extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout
     const int Np = KH * KH * (Cin >= 64 ? Cin / 64 * 64 : Cin);
     const bool narrow = Cout <= 64 && Cin <= 64;
     const WgradPlan p = wgrad_plan(Cout, Np, (long)N * pad32(OH * OW), narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
-    return p.use_ws ? p.ws_need : 0;
+    W9Plan w9;
+    const long need9 = w9_plan(N, Cin / 64 * 64, H, W, Cout, KH, stride, pad, cap, &w9) ? w9.need : 0;
+    return std::max(p.use_ws ? p.ws_need : 0, need9);
 }
 
 // ---- weight-pack recording / replay (see do_pack).  `host_jobs`: caller-owned HOST buffer of max_jobs 64-byte records.

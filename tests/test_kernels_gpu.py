@@ -94,6 +94,11 @@ CONV_CASES = [
     (8, 128, 64, 64, 128, 1, 1, 0, 0, 1, True),     # P1 forward + dgrad, two stages, bias + relu
     (8, 64, 64, 96, 64, 1, 1, 0, 0, 0, False),      # P1 64-channel variant (8x32 pixel tiles), forward + dgrad
     (2, 192, 64, 64, 160, 1, 1, 0, 0, 2, True),     # P1: 3 stages, M tile tail (160), dgrad rows 192
+    (2, 128, 32, 64, 128, 3, 1, 1, 1, 0, True),     # W9 patch wgrad: 2 input-channel tiles, reflect, tiles at every border
+    (3, 192, 16, 32, 136, 3, 1, 1, 0, 0, False),    # W9: 3 input-channel tiles, Cout tail (136 = 128 + 8), zero pad, 3 images
+    (8, 256, 32, 32, 256, 3, 1, 1, 1, 2, True),     # W9: 4 x 2 output tiles, K split over the 64 pixel tiles
+    (2, 193, 16, 32, 128, 3, 1, 1, 1, 0, False),    # W9 on 192 channels + table pass for the 1-channel tail
+    (4, 128, 32, 64, 64, 3, 1, 1, 0, 0, False),     # W9 narrow variant (Cout <= 64: two K groups per workgroup), 2 channel tiles
 ]
 
 
