@@ -1638,6 +1638,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// W9 partials (Np % 4 == 0, Cp == Cin): 4 consecutive n per thread as one 16-byte load per slice, SL slice lanes per output
+// quad (blockDim = 64 x SL) so that few-output / many-slice layers still put enough loads in flight
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void wgrad_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ dw, int M,
+                                                               int Np, int splits, int Cp, int KHW, int c_off, int Ctot) {
+    __shared__ float4 part[SL][64];
+    const long total4 = (long)M * Np / 4;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long i4 = (long)blockIdx.x * 64 + tx;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < total4) {
+        const float4* p = reinterpret_cast<const float4*>(ws) + i4;
+#pragma unroll 4
+        for (int k = ty; k < splits; k += SL) {
+            const float4 v = p[(long)k * total4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if (SL > 1) {
+        part[ty][tx] = s;
+        __syncthreads();
+        if (ty != 0) return;
+#pragma unroll
+        for (int k = 1; k < SL; ++k) { const float4 v = part[k][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    }
+    if (i4 < total4) {
+        const long i = i4 * 4;
+        const int m = (int)(i / Np), n = (int)(i - (long)m * Np);
+        const int tap = n / Cp, ci = n - tap * Cp;          // the 4 values share the tap (Cp % 4 == 0)
+        float* q = dw + ((size_t)m * Ctot + c_off + ci) * KHW + tap;
+        q[0] += s.x; q[KHW] += s.y; q[2 * KHW] += s.z; q[3 * KHW] += s.w;
+    }
+}
+
 // many slices, few outputs (narrow layers: 16x144 outputs x ~700 slices): 64 outputs x 16 slice lanes per workgroup
 __global__ __launch_bounds__(1024) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                  int M, int Np, int splits, int Cp, int Cin, int KHW,
@@ -2367,12 +2401,13 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         if (pad_mode == JP_PAD_REFLECT) launch_w9<true>(dy, x0, ws, N, Cin, c9, H, W, Cout, w9, st);
         else launch_w9<false>(dy, x0, ws, N, Cin, c9, H, W, Cout, w9, st);
         const long total = (long)Cout * 9 * c9;
-        if (w9.slices >= 16)     // many slices: 16 slice lanes per output instead of one serial chain of loads
-            hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((int)((total + 63) / 64)), dim3(1024), 0, st, ws, dw, Cout, 9 * c9,
-                               w9.slices, c9, c9, 9, dw_coff, dw_ctot);
+        const int nblk = (int)((total / 4 + 63) / 64);
+        if (w9.slices >= 64 && nblk < 2048)          // few outputs, many slices: 8 slice lanes per output quad
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<8>, dim3(nblk), dim3(512), 0, st, ws, dw, Cout, 9 * c9, w9.slices, c9, 9,
+                               dw_coff, dw_ctot);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, ws,
-                               dw, Cout, 9 * c9, w9.slices, c9, c9, 9, dw_coff, dw_ctot);
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3(nblk), dim3(64), 0, st, ws, dw, Cout, 9 * c9, w9.slices, c9, 9,
+                               dw_coff, dw_ctot);
         if (tail9) {
             const int rc = run_table(c9, tail9);
             if (rc) return rc;

@@ -193,8 +193,12 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
     const int l31 = lane & 31, lhi = lane >> 5;
     const float* ap = As + lhi * LDA + wm * 64 + l31;
     const float* bp = Bs + lhi * LDB + wn * 64 + l31;
+    // a wave whose whole 64x64 sub-tile lies outside the problem (N = 147 in a 256-wide tile: the 7x7 stem wgrad) only
+    // stages data and meets the barriers; its MFMA slots go to the other workgroups resident on the SIMD
+    const bool wave_live = (m0 + wm * 64 < M) && (n0 + wn * 64 < N);
 
     auto compute = [&](int stage) {
+        if (!wave_live) return;
         const float* aq = ap + stage * (KC * LDA);
         const float* bq = bp + stage * (KC * LDB);
         // operands of step kk+2 are read from LDS before the MFMAs of step kk issue (the scheduling barriers keep
@@ -252,12 +256,14 @@ __global__ __launch_bounds__(64 * WM * WN) void jp_igemm_kernel(ALoad al, BLoad 
                     for (int r = s * NB / STEPS; r < (s + 1) * NB / STEPS; ++r) rb[r] = getB(r);
                 }
                 const int kk = 2 * s;
-                const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
-                const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                if (wave_live) {
+                    const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
+                    const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
             }
             __syncthreads();
         }
