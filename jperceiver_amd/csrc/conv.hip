@@ -100,18 +100,21 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             return pack_slot_sum(w + ((size_t)co * Cin + c_off + c) * 9, pl);
         }
         case PACK_FRAG: {      // p = Cout, Cin, for_dgrad, BMT, KHW (9 or 1): MFMA fragment order of the P9 / P1 kernel (igemm_p9.h):
-                               // wp[M tile][(chunk*KHW + tap)*16 + s (+ slack steps)][k parity][row in tile] =
-                               //   W(row, reduction channel chunk*32 + 2s + parity, tap); zero beyond the last step / row / channel
+                               // wp[M tile][quad Q (+ slack quads)][k parity][row in tile][j] = W(row, reduction channel
+                               // chunk*32 + 2s + parity, tap) for k-step 4Q + j = (chunk*KHW + tap)*16 + s: a lane's four
+                               // k-steps of a quad are one 16-byte load; zero beyond the last step / row / channel
             const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4];
             const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
-            const long per_tile = ((long)((red + 31) / 32) * KHW * 16 + P9_AHEAD + 1) * 2 * BMT;
+            const long per_tile = ((long)((red + 31) / 32) * KHW * 4 + P9_QAHEAD + 1) * 8 * BMT;
             const int mt = (int)(i / per_tile);
             long t = i - (long)mt * per_tile;
+            const int j = (int)(t & 3); t >>= 2;
             const int m = mt * BMT + (int)(t % BMT);
             t /= BMT;
-            const int par = (int)(t & 1); t >>= 1;          // t = global k-step
-            const int s_ = (int)(t & 15);
-            const long tc = t >> 4;                         // chunk*KHW + tap
+            const int par = (int)(t & 1); t >>= 1;          // t = quad
+            const long step = t * 4 + j;                    // global k-step
+            const int s_ = (int)(step & 15);
+            const long tc = step >> 4;                      // chunk*KHW + tap
             const int tap = (int)(tc % KHW);
             const int c = (int)(tc / KHW) * 32 + 2 * s_ + par;
             if (m >= rows || c >= red) return 0.f;
@@ -1758,13 +1761,13 @@ inline int p9_bmt(int rows) { return rows <= 64 ? 64 : 128; }        // channels
 inline long dgrad_tap_floats(int Cin, int Cout, int KH) { return ((long)(KH * KH + 16) * Cin + 512 + 64) * ((Cout + 31) / 32 * 32); }
 inline long p9_ws_floats(int rows, int red, int khw = 9) {
     const int bmt = p9_bmt(rows);
-    return ((long)jp_cdiv(red, 32) * khw * 16 + P9_AHEAD + 1) * 2 * bmt * jp_cdiv(rows, bmt);
+    return ((long)jp_cdiv(red, 32) * khw * 4 + P9_QAHEAD + 1) * 8 * bmt * jp_cdiv(rows, bmt);
 }
 // The 1x1 variant (TAPS = 1) measured 103 / 106 TF forward / dgrad on 256->256 @256^2 against 105 / 108 TF of the generic
 // engine (a 1x1 layer has only K = Cin: the workgroup's prologue / epilogue dominate, not the operand staging): it is
 // kept as an opt-in (JP_P1=1), the default path for 1x1 stays the generic engine.
 inline bool p1_enabled() {
-    static const int on = [] { const char* e = getenv("JP_P1"); return e ? atoi(e) : 0; }();
+    static const int on = [] { const char* e = getenv("JP_P1"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
 inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {

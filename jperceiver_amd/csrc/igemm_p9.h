@@ -6,8 +6,8 @@
 // 2-D pixel tile of TR rows x 32 columns; per 32-channel chunk it stages the (TR+2) x 34 input PATCH once -- padding
 // (zero or reflection) resolved while staging -- and all 9 taps read their MFMA B fragments from that patch at a
 // constant LDS offset (dy*PITCH + dx).  The weights (A operand) do not go through LDS at all: they are pre-packed in
-// MFMA fragment order [M tile][chunk][tap][k-pair][k parity][row in tile] (PACK_FRAG, conv.hip: a workgroup's weight
-// stream is one contiguous run, 1 KB per k-step), so a lane's A value for a k-step is ONE coalesced global load (L1/L2-resident: every workgroup of an M tile walks the same stream), prefetched a fixed
+// MFMA fragment order [M tile][quad of 4 k-steps][k parity][row in tile][4] (PACK_FRAG, conv.hip: a workgroup's weight
+// stream is one contiguous run, 1 KB per k-step), so a lane's A values for FOUR k-steps are ONE 16-byte global load (L1/L2-resident: every workgroup of an M tile walks the same stream), prefetched a fixed
 // number of k-steps ahead into a register ring.  Per 64 MFMAs a wave therefore issues 32 coalesced weight loads,
 // 2 x 16 ds_read_b32 and ~3 patch loads / LDS stores (vs 32 gathered loads + 32 LDS stores before), and a workgroup
 // meets 2 barriers per 576 MFMAs per wave instead of per 64.
@@ -20,12 +20,14 @@
 #include "igemm.h"
 
 constexpr int P9_PITCH = 36;          // patch row pitch in floats: [halo | 32 pixels | halo] + 2 pad
-constexpr int P9_AHEAD = 8;           // k-steps of weight prefetch (register ring of 2*P9_AHEAD values)
+constexpr int P9_QAHEAD = 1;          // quads (4 k-steps) of weight prefetch: register ring of (P9_QAHEAD + 1) x 2 x float4
+typedef float jp_p9_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned jp_p9_u32x4 __attribute__((ext_vector_type(4)));
 
 // TAPS = 9: 3x3 (patch with a one-pixel halo).  TAPS = 1: 1x1 convolution ("P1": no halo; CPB = 2 channel chunks are
 // staged per barrier pair so that the barrier density stays at 2 per 128 MFMAs).
 template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS = 9, int CPB = 1>
-__global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
                                                           Epi epi, int M, int C, int NCH, int H, int W) {
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
@@ -129,18 +131,30 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- weight stream of this M tile: k-step q (global over chunks) = 2 x BMT floats at wt + q*2*BMT, lane (l31, lhi)
-    // reads [lhi][wm*64 + i*32 + l31]: a wave-uniform base that advances by a compile-time 2*BMT per step + one
-    // per-lane offset register
-    constexpr int BMT = 64 * WM;
-    const float* wt = wp + (long)mt * ((long)NCH * STEPS + P9_AHEAD + 1) * 2 * BMT;     // NCH = number of STAGES here
-    const int aoff = lhi * BMT + wm * 64 + l31;
-    float ra[P9_AHEAD][2];
+    // ---- weight stream of this M tile: quad Q (4 k-steps, global over stages) = 2 x BMT float4 at wt + Q*2*BMT; lane
+    // (l31, lhi) reads [lhi][wm*64 + i*32 + l31] -- ONE global_load_dwordx4 per row block per 4 k-steps: a wave-uniform
+    // base that advances by a compile-time 2*BMT per quad + one per-lane offset register
+    constexpr int BMT = 64 * WM, QS = STEPS / 4, RING = P9_QAHEAD + 1;
+    static_assert(STEPS % 4 == 0 && QS % RING == 0, "ring slots must line up across stages");
+    // buffer addressing: SGPR resource of this M tile's stream + per-lane byte offset (constant) + scalar quad offset, so a
+    // load costs no VALU and no 64-bit address registers
+    constexpr int QBYTES = 2 * BMT * 16;                       // bytes per quad
+    const long tile_bytes = ((long)NCH * QS + P9_QAHEAD + 1) * QBYTES;                  // NCH = number of STAGES here
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)mt * tile_bytes, 0, (int)tile_bytes, 0x00020000);
+    const int avo = (lhi * BMT + wm * 64 + l31) * 16;
+    float ra[RING][2][4];
+    auto aload = [&](int slot, int quad_bytes) {
 #pragma unroll
-    for (int d = 0; d < P9_AHEAD; ++d) {
-        ra[d][0] = wt[d * 2 * BMT + aoff];
-        ra[d][1] = wt[d * 2 * BMT + aoff + 32];
-    }
+        for (int i = 0; i < 2; ++i) {
+            const jp_p9_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + 512 * i, quad_bytes, 0);
+            const jp_p9_f32x4 v = __builtin_bit_cast(jp_p9_f32x4, u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[slot][i][j] = v[j];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < P9_QAHEAD; ++d) aload(d, d * QBYTES);
     const float* bp = patch + (lhi * PR + 2 * wn) * P9_PITCH + l31;
 
     gload(0);
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
         lstore();
         __syncthreads();
         if (ch + 1 < NCH) gload(ch + 1);                   // next stage's patch: in flight during the MFMAs below
-        const float* aq = wt + (long)ch * STEPS * 2 * BMT;
+        const int aq = __builtin_amdgcn_readfirstlane(ch * QS * QBYTES);
         // B fragments are read one k-step ahead of the MFMAs that use them (offsets are compile-time: the loop over the
         // 144 k-steps of the chunk is fully unrolled)
         auto boff = [&](int q) -> int {
@@ -161,12 +175,14 @@ __global__ __launch_bounds__(256, WN == 4 ? 2 : 3) void jp_igemm_p9_kernel(const
         for (int q = 0; q < STEPS; ++q) {
             const int qn = q + 1 < STEPS ? q + 1 : q;
             const float nb0 = bp[boff(qn)], nb1 = bp[boff(qn) + P9_PITCH];
-            const float a0 = ra[q % P9_AHEAD][0], a1 = ra[q % P9_AHEAD][1];
-            // refill the ring slot with the weights of step q + AHEAD (the stream continues into the next chunk; the
-            // pack carries AHEAD steps of slack past the end)
-            ra[q % P9_AHEAD][0] = aq[(q + P9_AHEAD) * 2 * BMT + aoff];
-            ra[q % P9_AHEAD][1] = aq[(q + P9_AHEAD) * 2 * BMT + aoff + 32];
-            // keep the software pipeline as written (loads of step q+AHEAD / q+1 issue before the MFMAs of step q; the
+            const int Q = q / 4, j = q % 4;
+            if (j == 0) {
+                // refill the ring slot of quad Q - 1 with the weights of quad Q + QAHEAD (the stream continues into the next
+                // stage; the pack carries QAHEAD quads of slack past the end)
+                aload((Q + P9_QAHEAD) % RING, aq + (Q + P9_QAHEAD) * QBYTES);
+            }
+            const float a0 = ra[Q % RING][0][j], a1 = ra[Q % RING][1][j];
+            // keep the software pipeline as written (loads of quad Q+QAHEAD / step q+1 issue before the MFMAs of step q; the
             // scheduler must not hoist the whole unrolled chunk's loads to the front: 300+ live registers)
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);

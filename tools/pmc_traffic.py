@@ -34,10 +34,10 @@ def main(fetch_db, write_db, out_json):
     want = None
     if len(sys.argv) > 4:
         want = json.load(open(sys.argv[4]))["roofline"]["kernel"].split(" \u2014 ")[0].split(" — ")[0]
-    norm = lambda t: re.sub(r"\(anonymous namespace\)::", "", t).replace(" ", "")
+    norm = lambda t: re.sub(r"^void", "", re.sub(r"\(anonymous namespace\)::", "", t).replace(" ", ""))
     dom = [k for k in F if want and norm(k).startswith(norm(want))]
     if not dom:
-        ig = [k for k in F if "jp_igemm" in k]
+        ig = [k for k in F if "jp_igemm" in k or "jp_wgrad" in k]
         dom = [max(ig, key=lambda k: sum(v for v, _ in F[k]))]
     assert len(dom) == 1, dom
     fv = [v for v, _ in F[dom[0]]]
