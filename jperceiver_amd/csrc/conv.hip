@@ -1767,7 +1767,7 @@ inline long p9_ws_floats(int rows, int red, int khw = 9) {
 // engine (a 1x1 layer has only K = Cin: the workgroup's prologue / epilogue dominate, not the operand staging): it is
 // kept as an opt-in (JP_P1=1), the default path for 1x1 stays the generic engine.
 inline bool p1_enabled() {
-    static const int on = [] { const char* e = getenv("JP_P1"); return e ? atoi(e) : 1; }();
+    static const int on = [] { const char* e = getenv("JP_P1"); return e ? atoi(e) : 0; }();
     return on != 0;
 }
 inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {
