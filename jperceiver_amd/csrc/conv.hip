@@ -1778,16 +1778,16 @@ inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9_tag() { return __PRETTY_FUNCTION__; }       // profiler tag naming the instantiation
 template <bool REFLECT, bool REV, class E>
-void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st) {
+void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off = 0) {
     const int NCH = jp_cdiv(red, 32);
     jp_prof_before(rows <= 64 ? p9_tag<1, 4, REFLECT, REV, E>() : p9_tag<2, 2, REFLECT, REV, E>(),
                    2.0 * rows * (double)N * H * W * 9.0 * red, st);
     if (rows <= 64) {
         dim3 grid(N * (H / 8) * (W / 32), 1, 1);
-        hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W, mt_off);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
-        hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W, mt_off);
     }
     jp_prof_after(st);
 }
@@ -1799,10 +1799,10 @@ void launch_p1(const float* wp, const float* x, E e, int rows, int red, int N, i
                    2.0 * rows * (double)N * H * W * red, st);
     if (rows <= 64) {
         dim3 grid(N * (H / 8) * (W / 32), 1, 1);
-        hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, false, false, E, 1, 2>), grid, dim3(256), 0, st, wp, x, e, rows, red, NST, H, W);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, false, false, E, 1, 2>), grid, dim3(256), 0, st, wp, x, e, rows, red, NST, H, W, 0);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
-        hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, false, false, E, 1, 2>), grid, dim3(256), 0, st, wp, x, e, rows, red, NST, H, W);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, false, false, E, 1, 2>), grid, dim3(256), 0, st, wp, x, e, rows, red, NST, H, W, 0);
     }
     jp_prof_after(st);
 }
@@ -2176,12 +2176,14 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                         if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout, 1), Cout, Cin, 1, p9_bmt(Cin), 1, 0, st);
                         launch_p1(wfr, dy, e, Cin, Cout, N, H, W, st);
                     } else
-                    if (KH == 3 && pad == 1 && tail == 0 && p9_ok(Cin, Cout, N, H, W)) {
+                    if (KH == 3 && pad == 1 && (tail == 0 || Mm > 64) && p9_ok(Mm, Cout, N, H, W)) {
                         // P9 patch kernel on dY (taps mirrored, zero fill; the reflection fold stays with the border pass);
-                        // fragment-order pack behind the tap-major one (which the border pass still reads)
+                        // fragment-order pack behind the tap-major one (which the border pass still reads).  With a short
+                        // row tail (513 = 4*128 + 1) the kernel runs the full 128-row tiles of the same pack, the tail
+                        // its own launch below.
                         float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
                         if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin), 9, 0, st);
-                        launch_p9<false, true>(wfr, dy, e, Cin, Cout, N, H, W, st);
+                        launch_p9<false, true>(wfr, dy, e, Mm, Cout, N, H, W, st);
                     } else
                     if (KH == 3 && pad == 1 && Cout >= 32 && W % bn3 == 0 && npix > 64) {
                         // row-tile kernel on dY (taps mirrored, zero fill; the reflection fold stays with the border pass)
@@ -2273,6 +2275,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
     const int cx_up = up0 ? c0 : (up1 ? c1 : c2);
     DgradBT<3, true> b{dy, Cp, (int)npix, H, W, Cout, H, W, 1, 1, 1};
     int coff = 0;
+    bool frag_packed = false;
     for (int sidx = 0; sidx < 3; ++sidx) {
         const int C = cs[sidx];
         if (!C) continue;
@@ -2289,6 +2292,15 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             } else {
                 DgradEpi e{dx, C, H * W, accs[sidx]};
                 const int bn3 = C <= 64 ? 256 : 128;
+                if (Cin > 64 && C > 64 && coff % 128 == 0 && p9_ok(C, Cout, N, H, W)) {
+                    // P9 patch kernel on this segment's 128-row tiles of the whole bank's fragment-order pack
+                    float* wfr = ws + dgrad_tap_floats(Cin, Cout, 3);
+                    if (!ws_state && !frag_packed) {
+                        do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin), 9, 0, st);
+                        frag_packed = true;
+                    }
+                    launch_p9<false, true>(wfr, dy, e, C, Cout, N, H, W, st, coff / 128);
+                } else
                 if (W % bn3 == 0 && Cout >= 32) {     // row-tile kernel, see jp_conv2d_dgrad
                     const Src3 sdy = make_src(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, H, W);
                     if (C <= 64) { FwdBR3<false, true, 256> b3{sdy, H, W}; launch_r3<1, 4>(a, b3, e, C, (int)npix, Kp, st); }

@@ -16,6 +16,7 @@
 // block each) and 64 output channels (i = 0, 1): the same 2x2 grid of 32x32 accumulators as igemm.h.
 //   WM=2, WN=2: 128 channels x (4 rows x 32 cols);   WM=1, WN=4: 64 channels x (8 rows x 32 cols)
 // Preconditions (host-checked): W % 32 == 0, H % (2*WN) == 0, reduction channels padded to 32 in the pack.
+// mt_off: first M tile of the pack this launch works on (a channel segment of a wider filter bank: rows are relative).
 #pragma once
 #include "igemm.h"
 
@@ -28,7 +29,7 @@ typedef unsigned jp_p9_u32x4 __attribute__((ext_vector_type(4)));
 // staged per barrier pair so that the barrier density stays at 2 per 128 MFMAs).
 template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS = 9, int CPB = 1>
 __global__ __launch_bounds__(256, 2) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
-                                                          Epi epi, int M, int C, int NCH, int H, int W) {
+                                                          Epi epi, int M, int C, int NCH, int H, int W, int mt_off) {
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9_kernel(const float* __rest
     constexpr int QBYTES = 2 * BMT * 16;                       // bytes per quad
     const long tile_bytes = ((long)NCH * QS + P9_QAHEAD + 1) * QBYTES;                  // NCH = number of STAGES here
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)mt * tile_bytes, 0, (int)tile_bytes, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)(mt + mt_off) * tile_bytes, 0, (int)tile_bytes, 0x00020000);
     const int avo = (lhi * BMT + wm * 64 + l31) * 16;
     float ra[RING][2][4];
     auto aload = [&](int slot, int quad_bytes) {

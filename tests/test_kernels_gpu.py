@@ -99,6 +99,7 @@ CONV_CASES = [
     (8, 256, 32, 32, 256, 3, 1, 1, 1, 2, True),     # W9: 4 x 2 output tiles, K split over the 64 pixel tiles
     (2, 193, 16, 32, 128, 3, 1, 1, 1, 0, False),    # W9 on 192 channels + table pass for the 1-channel tail
     (4, 128, 32, 64, 64, 3, 1, 1, 0, 0, False),     # W9 narrow variant (Cout <= 64: two K groups per workgroup), 2 channel tiles
+    (4, 129, 64, 96, 64, 3, 1, 1, 1, 2, True),      # P9 dgrad on the 128-row tile of a 129-channel bank + its 1-row tail launch
 ]
 
 
@@ -136,6 +137,8 @@ def test_conv2d_fwd_bwd(case):
     (2, 32, 64, 32, 128, 72),     # per-segment wgrad: parity-class kernels on the upsampled segment (Cx % 128 == 0)
     (1, 64, 128, 128, 128, 136),  # ... + uniform-tap path on the reduce segment, two M tiles
     (1, 192, 256, 128, 64, 136),  # per-source dgrad with the row-tile kernel on the full-resolution segment (W % 128 == 0)
+    (1, 192, 256, 128, 64, 128),  # per-source dgrad: P9 patch kernel on the full-resolution segment's tiles of the bank's pack
+    (2, 64, 96, 256, 128, 64),    # ... two 128-row tiles, 2 images
 ])
 def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
     """iconv_k(cat(reduce, up(x), disp)) and its three input gradients (depth_decoder.py:76-77)."""
