@@ -1816,7 +1816,7 @@ static bool w9_enabled() {
 struct W9Plan { int splits, tps, ntiles, slices, narrow; long need; };
 static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W9Plan* p) {
     if (!w9_enabled() || KH != 3 || stride != 1 || pad != 1 || W % 32 || H % W9_TR || Cm < 64 || Cm % 64 || Cout < 48 ||
-        (long)N * H * W >= (1L << 31))
+        (long)N * Cout * H * W * 4 >= (1L << 31))
         return false;
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
     const int ntiles = N * (H / W9_TR) * (W / 32), kg = narrow ? 2 : 1;
@@ -1839,14 +1839,15 @@ template <bool REFLECT>
 static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
                       const W9Plan& p, hipStream_t st) {
     jp_prof_before(p.narrow ? w9_tag<1, 2, REFLECT>() : w9_tag<2, 1, REFLECT>(), 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+    const int dyb = (int)((long)N * Cout * H * W * 4);          // < 2^31 (w9_plan): dY is addressed through a buffer resource
     if (p.narrow) {
         dim3 grid(Cm / 64, jp_cdiv(Cout, 64), p.splits);
         hipLaunchKernelGGL((jp_wgrad_w9_kernel<1, 2, 2, REFLECT>), grid, dim3(768), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                           p.ntiles, p.tps);
+                           p.ntiles, p.tps, dyb);
     } else {
         dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
         hipLaunchKernelGGL((jp_wgrad_w9_kernel<2, 2, 1, REFLECT>), grid, dim3(768), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                           p.ntiles, p.tps);
+                           p.ntiles, p.tps, dyb);
     }
     jp_prof_after(st);
 }

@@ -27,11 +27,12 @@ constexpr int W9_TR = 4;              // pixel-tile rows
 constexpr int W9_AHEAD = 1;           // dY quads prefetched ahead (register ring of W9_AHEAD + 1 quads x 2 blocks x 4)
 
 typedef float jp_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned jp_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MW, int NB, int KG, bool REFLECT>
 __global__ __launch_bounds__(64 * KG * MW * 3 * NB, (KG * MW * 3 * NB) / 4) void jp_wgrad_w9_kernel(
         const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ ws, int Cout, int Cx, int Cm,
-        int H, int W, int ntiles, int tiles_per_split) {
+        int H, int W, int ntiles, int tiles_per_split, int dy_bytes) {
     constexpr int NWAVE = KG * MW * 3 * NB, NT = 64 * NWAVE;
     constexpr int TR = W9_TR, PR = TR + 2, PC = 34;
     constexpr int NC = 32 * NB, LDB = NC + 1;                       // patch: [PR*PC pixels][LDB]
@@ -74,9 +75,11 @@ __global__ __launch_bounds__(64 * KG * MW * 3 * NB, (KG * MW * 3 * NB) / 4) void
     const long HW = (long)H * W;
 
     // ---- dY fragment rows of this lane: channel m0 + wr*64 + a*32 + l31 (clamped; rows >= Cout are dropped in the epilogue)
-    long arow[2];
+    // buffer addressing (SGPR resource over dY + per-lane byte offset + scalar tile/quad offset): a load costs no VALU
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    int arow[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) arow[a] = (long)min(m0 + wr * 64 + a * 32 + l31, Cout - 1) * HW + 4 * lhi;
+    for (int a = 0; a < 2; ++a) arow[a] = (min(m0 + wr * 64 + a * 32 + l31, Cout - 1) * (int)HW + 4 * lhi) * 4;
     auto tile_org = [&](int T, int& img, int& y0, int& x0) {
         const int Tc = min(T, ntiles - 1);
         img = Tc / tiles_img;
@@ -84,11 +87,16 @@ __global__ __launch_bounds__(64 * KG * MW * 3 * NB, (KG * MW * 3 * NB) / 4) void
         y0 = (r / tiles_x) * TR;
         x0 = (r % tiles_x) * 32;
     };
-    jp_f32x4 ra[RING][2];
-    auto aload = [&](int slot, long tbase, int qd) {       // quad qd (0..QT-1) of the tile at dY offset tbase
-        const long o = tbase + (long)(qd / 4) * W + 8 * (qd % 4);
+    float ra[RING][2][4];
+    auto aload = [&](int slot, int tbase, int qd) {        // quad qd (0..QT-1) of the tile at dY element offset tbase
+        const int o = __builtin_amdgcn_readfirstlane((tbase + (qd / 4) * W + 8 * (qd % 4)) * 4);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) ra[slot][a] = *reinterpret_cast<const jp_f32x4*>(dy + o + arow[a]);
+        for (int a = 0; a < 2; ++a) {
+            const jp_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(drs, arow[a], o, 0);
+            const jp_f32x4 v = __builtin_bit_cast(jp_f32x4, u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[slot][a][j] = v[j];
+        }
     };
 
     // ---- patch staging map: the NT/32 half-waves split as PR patch rows x HPR half-waves per row; a half-wave loads the 32
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(64 * KG * MW * 3 * NB, (KG * MW * 3 * NB) / 4) void
     if (T0 < T1) {
         int img, y0, x0;
         tile_org(T0, img, y0, x0);
-        long tb = ((long)img * Cout) * HW + (long)(y0 + kg * TRG) * W + x0;      // dY offset of this K group's rows (channel 0)
+        int tb = (img * Cout) * (int)HW + (y0 + kg * TRG) * W + x0;      // dY element offset of this K group's rows (channel 0)
 #pragma unroll
         for (int d = 0; d < W9_AHEAD; ++d) aload(d, tb, d);
         gload(T0);
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(64 * KG * MW * 3 * NB, (KG * MW * 3 * NB) / 4) void
             __syncthreads();
             gload(T + 1);                                           // next tile's patch: in flight during the MFMAs below
             tile_org(T + 1, img, y0, x0);
-            const long tbn = ((long)img * Cout) * HW + (long)(y0 + kg * TRG) * W + x0;
+            const int tbn = (img * Cout) * (int)HW + (y0 + kg * TRG) * W + x0;
             // B fragments are read one k-step ahead of the MFMAs that use them; all offsets are compile-time (the 64
             // k-steps of a tile are fully unrolled)
             auto boff = [&](int s) -> int {
