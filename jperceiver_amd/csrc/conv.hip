@@ -24,6 +24,7 @@
 //   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
 #include "igemm_p9.h"
 #include "igemm_w9.h"
+#include "igemm_p9u.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -42,7 +43,7 @@ __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 // The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
 // launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
 // tiny launches per step become one.
-enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5 };
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6 };
 struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
     const float* w;
     float* wp;
@@ -120,6 +121,26 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             if (m >= rows || c >= red) return 0.f;
             const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
             return w[((size_t)co * Cin + ci) * KHW + tap];
+        }
+        case PACK_FRAGSEG: {   // p = Cout, Cin, c_off, C, KP, up: one channel segment of an iconv bank in the fragment order of
+                               // the P9U kernel (igemm_p9u.h): [class (up only)][M tile of 128][quad][k parity][row][4],
+                               // k-step 4*quad + j = (stage, tap | slot, k-pair s) with 2*KP channels per stage
+            const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], KP = p[4], up = p[5];
+            const int T = up ? 4 : 9, MT = Cout / 128;
+            const long tile = (long)((C + 2 * KP - 1) / (2 * KP)) * T * KP / 4 * 1024;
+            const int cm = (int)(i / tile);
+            long t = i - (long)cm * tile;
+            const int cls = cm / MT, mt = cm - cls * MT;
+            const int j = (int)(t & 3); t >>= 2;
+            const int row = (int)(t & 127); t >>= 7;
+            const int par = (int)(t & 1); t >>= 1;          // t = quad
+            const long step = t * 4 + j;
+            const int stage = (int)(step / (T * KP)), rem = (int)(step - (long)stage * (T * KP));
+            const int tap = rem / KP, s_ = rem - tap * KP;
+            const int c = stage * 2 * KP + 2 * s_ + par, co = mt * 128 + row;
+            if (c >= C || co >= Cout) return 0.f;
+            const float* wc = w + ((size_t)co * Cin + c_off + c) * 9;
+            return up ? pack_slot_sum(wc, cls * 4 + tap) : wc[tap];
         }
         default: {             // PACK_FLIP, p = Cout, Cin, c_off, C: wf[c][co][t] = w[co][c_off + c][8 - t]
             const int Cout = p[0], Cin = p[1], c_off = p[2];
@@ -1757,6 +1778,12 @@ inline bool p9_enabled() {
     static const int on = [] { const char* e = getenv("JP_P9"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
+inline bool p9u_enabled() {
+    static const int on = [] { const char* e = getenv("JP_P9U"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+template <class E>
+const char* p9u_tag() { return __PRETTY_FUNCTION__; }
 inline int p9_bmt(int rows) { return rows <= 64 ? 64 : 128; }        // channels per M tile: 64 x (8x32 px) or 128 x (4x32 px)
 inline long dgrad_tap_floats(int Cin, int Cout, int KH) { return ((long)(KH * KH + 16) * Cin + 512 + 64) * ((Cout + 31) / 32 * 32); }
 inline long p9_ws_floats(int rows, int red, int khw = 9) {
@@ -1968,6 +1995,23 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         else if (CP == 4) JP_BC(3, 4)
         else JP_BC(3, 8)
 #undef JP_BC
+        JP_LAUNCH_CHECK();
+    }
+    // P9U patch kernel for the iconv layers: cat(skip (full res), up2x(x), disparity channel) -> Cout, reflection pad
+    if (ws && p9_enabled() && KH == 3 && stride == 1 && pad == 1 && pad_mode == JP_PAD_REFLECT && c0 >= 32 && c0 % 32 == 0 &&
+        !up0 && c1 >= 32 && c1 % 32 == 0 && up1 && c2 <= 8 && !(c2 && up2) && Cout % 128 == 0 && H % 4 == 0 && W % 64 == 0 &&
+        (long)(Cout / 128) * N * (H / 4) * (W / 64) >= 128 && p9u_enabled()) {
+        const int MT = Cout / 128;
+        const long fS = (long)MT * (c0 / 32) * 36 * 1024, fU = 4L * MT * (c1 / 32) * 16 * 1024, fD = (long)MT * 9 * 1024;
+        if (!ws_state) {
+            do_pack(PACK_FRAGSEG, w, ws, fS, Cout, Cin, 0, c0, 16, 0, st);
+            do_pack(PACK_FRAGSEG, w, ws + fS, fU, Cout, Cin, c0, c1, 16, 1, st);
+            if (c2) do_pack(PACK_FRAGSEG, w, ws + fS + fU, fD, Cout, Cin, c0 + c1, c2, 4, 0, st);
+        }
+        jp_prof_before(p9u_tag<FwdEpi>(), 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * c2), st);
+        dim3 grid(N * (H / 4) * (W / 64), MT, 1);
+        hipLaunchKernelGGL((jp_igemm_p9u_kernel<FwdEpi>), grid, dim3(512), 0, st, ws, x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+        jp_prof_after(st);
         JP_LAUNCH_CHECK();
     }
     {   // upsample-aware parity-class path (iconv layers)

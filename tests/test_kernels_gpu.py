@@ -139,6 +139,8 @@ def test_conv2d_fwd_bwd(case):
     (1, 192, 256, 128, 64, 136),  # per-source dgrad with the row-tile kernel on the full-resolution segment (W % 128 == 0)
     (1, 192, 256, 128, 64, 128),  # per-source dgrad: P9 patch kernel on the full-resolution segment's tiles of the bank's pack
     (2, 64, 96, 256, 128, 64),    # ... two 128-row tiles, 2 images
+    (2, 64, 128, 64, 96, 256),    # P9U patch kernel forward: 2 skip stages + 3 upsampled stages + disparity stage, 2 M tiles
+    (1, 128, 128, 32, 32, 128),   # P9U: one stage of each kind, tiles at every image border
 ])
 def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
     """iconv_k(cat(reduce, up(x), disp)) and its three input gradients (depth_decoder.py:76-77)."""
