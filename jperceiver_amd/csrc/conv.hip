@@ -1848,7 +1848,8 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
     const int ntiles = N * (H / W9_TR) * (W / 32), kg = narrow ? 2 : 1;
     const long out_tiles = (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128), per = (long)Cout * 9 * Cm;
-    long sp = std::max<long>(1, std::min<long>(256 / std::max<long>(1, out_tiles), ntiles / 2));
+    static const long wgs = [] { const char* e = getenv("JP_W9_WGS"); return e ? atol(e) : 256L; }();
+    long sp = std::max<long>(1, std::min<long>(wgs / std::max<long>(1, out_tiles), ntiles / 2));
     sp = std::min<long>(sp, ws_floats / (per * kg));
     if (sp < 1 || ntiles < 8) return false;
     const int tps = (int)jp_cdiv(ntiles, sp);
