@@ -25,6 +25,7 @@
 #include "igemm_p9.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
+#include "igemm_w7.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -1880,6 +1881,36 @@ static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx,
     jp_prof_after(st);
 }
 
+// ---- W7 stem wgrad (igemm_w7.h): 7x7 stride 2 pad 3, 3 or 6 input channels -> 64
+struct W7Plan { int splits, tps, ntiles, slices; long need; };
+static inline bool w7_plan(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W7Plan* p) {
+    if (!w9_enabled() || KH != 7 || stride != 2 || pad != 3 || (Cin != 3 && Cin != 6) || Cout != 64 || H % 2 || W % 2 ||
+        (W / 2) % 32 || (H / 2) % 4 || (long)N * 64 * (H / 2) * (W / 2) * 4 >= (1L << 31) || (long)N * Cin * H * W >= (1L << 31))
+        return false;
+    const int ntiles = N * (H / 8) * (W / 64), kg = Cin == 3 ? 2 : 1, np = (49 * Cin + 31) / 32 * 32;
+    long sp = std::max<long>(1, std::min<long>(512, ntiles / 4));
+    sp = std::min<long>(sp, ws_floats / (64L * np * kg));
+    if (sp < 1 || ntiles < 16) return false;
+    p->tps = (int)jp_cdiv(ntiles, sp);
+    p->splits = jp_cdiv(ntiles, p->tps);
+    p->ntiles = ntiles;
+    p->slices = p->splits * kg;
+    p->need = (long)p->slices * 64 * np;
+    return true;
+}
+template <int CIN>
+const char* w7_tag() { return __PRETTY_FUNCTION__; }
+template <int CIN>
+static void launch_w7(const float* dy, const float* x, float* dw, float* ws, int N, int H, int W, const W7Plan& p,
+                      hipStream_t st) {
+    jp_prof_before(w7_tag<CIN>(), 2.0 * 64 * 49.0 * CIN * (double)N * (H / 2) * (W / 2), st);
+    hipLaunchKernelGGL((jp_wgrad_w7_kernel<CIN>), dim3(p.splits), dim3(640), 0, st, dy, x, ws, H, W, p.ntiles, p.tps,
+                       (int)((long)N * 64 * (H / 2) * (W / 2) * 4));
+    jp_prof_after(st);
+    constexpr int NP = (49 * CIN + 31) / 32 * 32;
+    hipLaunchKernelGGL((w7_reduce_kernel<CIN>), dim3(64 * NP / 64), dim3(1024), 0, st, ws, dw, p.slices);
+}
+
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
               int up2, int H, int W) {
     Src3 s;
@@ -2453,6 +2484,12 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         return 0;
     };
     JP_CHECK_ARG(whole || single, "conv2d_wgrad: internal sub-range call must be single-source");
+    W7Plan w7;
+    if (single && whole && ws && w7_plan(N, Cin, H, W, Cout, KH, stride, pad, ws_floats, &w7)) {
+        if (Cin == 3) launch_w7<3>(dy, x0, dw, ws, N, H, W, w7, st);
+        else launch_w7<6>(dy, x0, dw, ws, N, H, W, w7, st);
+        JP_LAUNCH_CHECK();
+    }
     W9Plan w9;
     // W9 patch kernel on the 64-aligned channels (+ a table pass for a short channel tail, e.g. 513 = 512 + 1): input patch
     // staged once per pixel tile for all 9 taps, dY fragments straight from global memory
@@ -2653,6 +2690,8 @@ extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
 extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW, cap = 32L << 20;
+    W7Plan w7;
+    if (w7_plan(N, Cin, H, W, Cout, KH, stride, pad, cap, &w7)) return w7.need;
     if (Cout % 8 != 0 || Cin < 16) return 0;
     const int Np = KH * KH * (Cin >= 64 ? Cin / 64 * 64 : Cin);
     const bool narrow = Cout <= 64 && Cin <= 64;
