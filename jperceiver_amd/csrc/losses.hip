@@ -241,8 +241,10 @@ __global__ __launch_bounds__(TPB) void scale_bwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(TPB) void layout_fwd_kernel(const float* __restrict__ logits,
                                                          const float* __restrict__ label,
                                                          const float* __restrict__ sdf, double* __restrict__ sums,
-                                                         int B, int hw, float w0, float w1) {
+                                                         int B, int hw, float w0, float w1, float ra, float ralpha,
+                                                         float rbeta) {
     __shared__ double sm[4];
+    const bool focal = ra < 0.f;          // FocalLoss (focal_loss.py:36-92): ralpha = alpha, rbeta = gamma, smooth 1e-5
     const int b = blockIdx.y;
     const float* z0 = logits + (size_t)b * 2 * hw;
     const float* z1 = z0 + hw;
@@ -259,6 +261,11 @@ __global__ __launch_bounds__(TPB) void layout_fwd_kernel(const float* __restrict
         const bool fg = lb[p] > 0.5f;
         // dice_loss.py:62-64: tp_c = p_c*oh_c, fp_c = p_c*(1-oh_c), fn_c = (1-p_c)*oh_c
         // a = {tp0, fp0, fn0, tp1, fp1, fn1}
+        if (focal) {
+            // pt = sum_c clamp(onehot_c, s, 1-s) * p_c + s;  loss = -alpha[t] * (1-pt)^gamma * log(pt), alpha = (a, 1-a)
+            const float s_ = 1e-5f, pt = (1.f - s_) * (fg ? p1 : p0) + s_ * (fg ? p0 : p1) + s_;
+            a[0] += (double)(-(fg ? 1.f - ralpha : ralpha) * powf(1.f - pt, rbeta) * __logf(pt));
+        } else
         if (fg) { a[3] += p1; a[1] += p0; a[5] += 1.f - p1; }   // oh = (0,1)
         else    { a[0] += p0; a[4] += p1; a[2] += 1.f - p0; }   // oh = (1,0)
         const float logp = (fg ? u1 : u0) - m - __logf(e0 + e1);
@@ -280,12 +287,17 @@ __global__ void layout_finalize_kernel(const double* __restrict__ sums, float* _
                                        float lw, float cew, float l2w, float ra, float ralpha, float rbeta) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double iou = 0.0;
-    for (int b = 0; b < B; ++b)
-        for (int c = 0; c < 2; ++c) {
-            const double tp = sums[8 * b + 3 * c], fp = sums[8 * b + 3 * c + 1], fn = sums[8 * b + 3 * c + 2];
-            iou += ((double)ra * tp + 1.0) / ((double)ra * tp + (double)ralpha * fp + (double)rbeta * fn + 1.0);
-        }
-    iou = -iou / (2.0 * B);
+    if (ra < 0.f) {                      // focal: mean over all pixels of the per-pixel terms (size_average)
+        for (int b = 0; b < B; ++b) iou += sums[8 * b];
+        iou /= (double)B * hw;
+    } else {
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < 2; ++c) {
+                const double tp = sums[8 * b + 3 * c], fp = sums[8 * b + 3 * c + 1], fn = sums[8 * b + 3 * c + 2];
+                iou += ((double)ra * tp + 1.0) / ((double)ra * tp + (double)ralpha * fp + (double)rbeta * fn + 1.0);
+            }
+        iou = -iou / (2.0 * B);
+    }
     const double ce = sums[8 * B + 1] > 0.0 ? sums[8 * B] / sums[8 * B + 1] : 0.0;
     const double bd = sums[8 * B + 2] / ((double)B * hw);
     loss[0] = (float)(lw * iou + cew * ce + l2w * bd);
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(TPB) void layout_bwd_kernel(const float* __restrict
         Tc[c] = (float)((double)ra * tp + 1.0);
     }
     const float kiou = -lw * go / (2.f * (float)B);
+    const float kfoc = lw * go / ((float)B * (float)hw);
     const float kce = cew * go / (float)sums[8 * B + 1];
     const float kbd = l2w * go / ((float)B * (float)hw);
     const float* z0 = logits + (size_t)b * 2 * hw;
@@ -326,8 +339,19 @@ __global__ __launch_bounds__(TPB) void layout_bwd_kernel(const float* __restrict
         const float p0 = e0 * inv, p1 = e1 * inv;
         const bool fg = lb[p] > 0.5f;
         const float oh0 = fg ? 0.f : 1.f, oh1 = fg ? 1.f : 0.f;
-        float dp0 = kiou * (ra * oh0 * Dc[0] - Tc[0] * (ra * oh0 + ralpha * (1.f - oh0) - rbeta * oh0)) / (Dc[0] * Dc[0]);
-        float dp1 = kiou * (ra * oh1 * Dc[1] - Tc[1] * (ra * oh1 + ralpha * (1.f - oh1) - rbeta * oh1)) / (Dc[1] * Dc[1]);
+        float dp0, dp1;
+        if (ra < 0.f) {
+            // f(pt) = -al * (1-pt)^g * log(pt):  f' = al * (g * (1-pt)^(g-1) * log(pt) - (1-pt)^g / pt);  d pt / d p_t = 1-s,
+            // d pt / d p_other = s
+            const float s_ = 1e-5f, pt = (1.f - s_) * (fg ? p1 : p0) + s_ * (fg ? p0 : p1) + s_;
+            const float al = fg ? 1.f - ralpha : ralpha, om = 1.f - pt;
+            const float fp = al * (rbeta * powf(om, rbeta - 1.f) * __logf(pt) - powf(om, rbeta) / pt) * kfoc;
+            dp0 = fp * (fg ? s_ : 1.f - s_);
+            dp1 = fp * (fg ? 1.f - s_ : s_);
+        } else {
+            dp0 = kiou * (ra * oh0 * Dc[0] - Tc[0] * (ra * oh0 + ralpha * (1.f - oh0) - rbeta * oh0)) / (Dc[0] * Dc[0]);
+            dp1 = kiou * (ra * oh1 * Dc[1] - Tc[1] * (ra * oh1 + ralpha * (1.f - oh1) - rbeta * oh1)) / (Dc[1] * Dc[1]);
+        }
         if (sd) dp1 += kbd * sd[p];
         const float dot = p0 * dp0 + p1 * dp1;          // softmax Jacobian
         float g0 = p0 * (dp0 - dot), g1 = p1 * (dp1 - dot);
@@ -525,7 +549,7 @@ extern "C" int jp_layout_loss_fwd(const float* logits, const float* label, const
     JP_ST;
     JP_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (8 * B + 3), st));
     hipLaunchKernelGGL(layout_fwd_kernel, dim3(std::min(jp_cdiv(h * w, TPB), 256), B), dim3(TPB), 0, st, logits, label,
-                       sdf, sums, B, h * w, w0, w1);
+                       sdf, sums, B, h * w, w0, w1, ra, ralpha, rbeta);
     hipLaunchKernelGGL(layout_finalize_kernel, dim3(1), dim3(64), 0, st, sums, loss, B, h * w, lw, cew, l2w, ra, ralpha, rbeta);
     JP_LAUNCH_CHECK();
 }

@@ -35,7 +35,8 @@ def main(fetch_db, write_db, out_json):
     if len(sys.argv) > 4:
         want = json.load(open(sys.argv[4]))["roofline"]["kernel"].split(" \u2014 ")[0].split(" — ")[0]
     norm = lambda t: re.sub(r"^void", "", re.sub(r"\(anonymous namespace\)::", "", t).replace(" ", ""))
-    dom = [k for k in F if want and norm(k).startswith(norm(want))]
+    # (default template arguments are printed by rocprofv3 but not by bench.py: match without the closing '>')
+    dom = [k for k in F if want and norm(k).startswith(norm(want).rstrip('>'))]
     if not dom:
         ig = [k for k in F if "jp_igemm" in k or "jp_wgrad" in k]
         dom = [max(ig, key=lambda k: sum(v for v, _ in F[k]))]
