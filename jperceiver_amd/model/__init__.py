@@ -1,6 +1,6 @@
 from .registry import MONO
 from .net import Baseline
 from . import modules
-from .losses import IoULoss, SoftDiceLoss, TverskyLoss, BDLoss
+from .losses import IoULoss, SoftDiceLoss, TverskyLoss, FocalLoss, BDLoss
 
-__all__ = ["MONO", "Baseline", "modules", "IoULoss", "SoftDiceLoss", "TverskyLoss", "BDLoss"]
+__all__ = ["MONO", "Baseline", "modules", "IoULoss", "SoftDiceLoss", "TverskyLoss", "FocalLoss", "BDLoss"]

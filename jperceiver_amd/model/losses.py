@@ -99,6 +99,25 @@ class TverskyLoss(_RegionLoss):
         self.alpha, self.beta = 0.3, 0.7
 
 
+class FocalLoss(nn.Module):
+    """focal_loss.py:7-92 as the reference builds it (net.py:568-570: `FocalLoss(apply_nonlin=softmax_helper)`):
+    mean over all pixels of -alpha[t] * (1 - pt)^gamma * log(pt) with pt = sum_c clamp(onehot_c, s/(C-1), 1-s) * p_c + s,
+    alpha = (alpha, 1 - alpha) for balance_index 0."""
+
+    def __init__(self, apply_nonlin=None, alpha=0.25, gamma=2, balance_index=0, smooth=1e-5, size_average=True):
+        super().__init__()
+        if not _is_softmax_dim1(apply_nonlin):
+            raise NotImplementedError("apply_nonlin must be softmax over dim 1 (fused into the kernel)")
+        if not isinstance(alpha, float) or balance_index != 0 or smooth != 1e-5 or not size_average:
+            raise NotImplementedError("only the reference's call pattern FocalLoss(apply_nonlin=softmax) (+ alpha / gamma) is built")
+        self.apply_nonlin, self.alpha, self.gamma = apply_nonlin, float(alpha), float(gamma)
+        self.balance_index, self.smooth, self.size_average = 0, 1e-5, True
+
+    def forward(self, logit, target):
+        x, y, B, h, w = _two_class(logit, target)
+        return _LayoutLossFn.apply(x, y, None, 1.0, 0.0, 0.0, 1.0, 1.0, (-1.0, self.alpha, self.gamma))
+
+
 def compute_sdf(label: torch.Tensor) -> torch.Tensor:
     """boundary_loss.py:121-147 for the foreground class on the GPU: label (B,1,h,w) or (B,h,w) {0,1} -> (B,h,w)."""
     B, h, w = label.shape[0], label.shape[-2], label.shape[-1]

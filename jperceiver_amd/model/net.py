@@ -275,7 +275,7 @@ class Baseline(nn.Module):
         use_bd = 0.0 if lsum == 1 else 1.0
         region = o.get("loss_type", "iou")                # net.py:562-573: 'iou' | 'dice' | 'tversky' | 'focal'
         if region not in ops_loss.REGION:
-            raise NotImplementedError(f"loss_type={region!r}: only iou / dice / tversky are built (the north-star configs use iou)")
+            raise NotImplementedError(f"loss_type={region!r}: iou / dice / tversky / focal are built (net.py:562-573)")
         if o.get("loss2_type", "boundary") != "boundary":
             raise NotImplementedError("loss2_type must be 'boundary' (net.py:574-575)")
 

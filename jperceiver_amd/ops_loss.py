@@ -310,12 +310,13 @@ def signed_distance(label: torch.Tensor) -> torch.Tensor:
     return sdf
 
 
-REGION = {"iou": (1.0, 1.0, 1.0), "dice": (2.0, 1.0, 1.0), "tversky": (1.0, 0.3, 0.7)}   # (a, alpha, beta) of the overlap score
+REGION = {"iou": (1.0, 1.0, 1.0), "dice": (2.0, 1.0, 1.0), "tversky": (1.0, 0.3, 0.7),   # (a, alpha, beta) of the overlap score
+          "focal": (-1.0, 0.25, 2.0)}        # a < 0: FocalLoss (focal_loss.py), (alpha, gamma) = (0.25, 2), smooth 1e-5
 
 
 def layout_loss(lv: LossVec, slot, logits: Var, label: torch.Tensor, sdf, w0, w1, lw, cew, l2w, region="iou"):
     """compute_topview_loss (net.py:554-585): lw*region + cew*CE(w0,w1) + l2w*BD in one fused pass; region =
-    opt.loss_type: IoULoss / SoftDiceLoss / TverskyLoss (dice_loss.py:255-372)."""
+    opt.loss_type: IoULoss / SoftDiceLoss / TverskyLoss (dice_loss.py:255-372) / FocalLoss (focal_loss.py:7-92)."""
     B, C, h, w = logits.t.shape
     assert C == 2
     ra, ral, rbe = REGION[region]

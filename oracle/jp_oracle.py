@@ -548,18 +548,52 @@ def iou_loss(logits, gt):
     return -((tp + 1.0) / (tp + fp + fn + 1.0)).mean()
 
 
+def region_loss(logits, gt, a=1.0, alpha=1.0, beta=1.0):
+    """dice_loss.py's overlap losses in one formula, -mean_{b,c} (a*tp + 1) / (a*tp + alpha*fp + beta*fn + 1):
+    IoULoss (1,1,1) :293-331, SoftDiceLoss (2,1,1) :255-290, TverskyLoss (1,0.3,0.7) :333-372."""
+    p = F.softmax(logits, 1)
+    oh = torch.zeros_like(p).scatter_(1, gt.unsqueeze(1), 1)
+    tp = (p * oh).sum((2, 3))
+    fp = (p * (1 - oh)).sum((2, 3))
+    fn = ((1 - p) * oh).sum((2, 3))
+    return -((a * tp + 1.0) / (a * tp + alpha * fp + beta * fn + 1.0)).mean()
+
+
+def focal_loss(logits, gt, alpha=0.25, gamma=2.0, smooth=1e-5):
+    """focal_loss.py:36-92 as built by net.py:568-570 (softmax non-linearity, float alpha with balance_index 0,
+    size_average): pt = sum_c clamp(onehot_c, smooth/(C-1), 1-smooth) * p_c + smooth."""
+    p = F.softmax(logits, 1)
+    C = p.shape[1]
+    pf = p.permute(0, 2, 3, 1).reshape(-1, C)
+    t = gt.reshape(-1, 1)
+    al = torch.full((C,), 1.0 - alpha)
+    al[0] = alpha
+    oh = torch.zeros_like(pf).scatter_(1, t, 1).clamp(smooth / (C - 1), 1.0 - smooth)
+    pt = (oh * pf).sum(1) + smooth
+    return (-al[t.squeeze(1)] * (1 - pt) ** gamma * pt.log()).mean()
+
+
+_REGION = {"iou": (1.0, 1.0, 1.0), "dice": (2.0, 1.0, 1.0), "tversky": (1.0, 0.3, 0.7)}
+
+
+def _loss_type(opt, logits, gt):
+    """net.py:562-573: opt.loss_type picks the region / focal term."""
+    ty = opt.get("loss_type", "iou")
+    return focal_loss(logits, gt) if ty == "focal" else region_loss(logits, gt, *_REGION[ty])
+
+
 def topview_loss(opt, logits, label, class_weight, wS=True):
     """net.py:554-617.  loss_weightS/loss2_weightS fall back to loss_weight/loss2_weight (N2)."""
     gt = label.long().squeeze(1)
     lw = opt.get("loss_weightS", opt["loss_weight"]) if wS else opt["loss_weight"]
     l2w = opt.get("loss2_weightS", opt["loss2_weight"]) if wS else opt["loss2_weight"]
     if opt["loss_sum"] == 1:
-        out = iou_loss(logits, gt) * lw
+        out = _loss_type(opt, logits, gt) * lw
     elif opt["loss_sum"] == 2:
-        out = iou_loss(logits, gt) * lw + bd_loss(logits, gt) * l2w
+        out = _loss_type(opt, logits, gt) * lw + bd_loss(logits, gt) * l2w
     else:  # 3 (and the reference-undefined 0, SURVEY N2)
         ce = F.cross_entropy(logits, gt, weight=torch.tensor([1.0, float(class_weight)]))
-        out = iou_loss(logits, gt) * lw + ce + bd_loss(logits, gt) * l2w
+        out = _loss_type(opt, logits, gt) * lw + ce + bd_loss(logits, gt) * l2w
     return out.mean()
 
 

@@ -38,6 +38,11 @@ CONFIGS = {
                              full_hw=(375, 1242), seed=24),
     "dynamic_head_only": dict(HW=256, B=2, FR=[0, -1], type="dynamic", split="odometry", loss_sum=3,
                               full_hw=(375, 1242), seed=25),
+    # the other loss_type variants of the 48 non-north-star configs (net.py:562-573), full step each
+    "loss_type_focal": dict(HW=256, B=2, FR=[0, -1], type="static", split="odometry", loss_sum=3, full_hw=(375, 1242), seed=27,
+                            loss_type="focal"),
+    "loss_type_dice": dict(HW=256, B=2, FR=[0, -1], type="static", split="odometry", loss_sum=2, full_hw=(375, 1242), seed=28,
+                           loss_type="dice"),
     "cfg4_argo_full_frame": dict(HW=256, B=1, FR=[0, -1], type="Argo_both", split="argo", loss_sum=3,
                                  full_hw=(2056, 2464), seed=26),
 }
@@ -48,6 +53,8 @@ def _opt(c):
                       type=c["type"], split=c["split"], loss_sum=c["loss_sum"])
     if c["type"] == "Argo_both":
         o.update(loss_weightS=20, loss2_weightS=20)
+    if "loss_type" in c:
+        o.update(loss_type=c["loss_type"])
     return o
 
 

@@ -672,7 +672,11 @@ def test_iou_and_bd_loss_classes_match_reference_vectors(golden_dir):
     logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
     gt = torch.from_numpy(masks[:, 0]).long()
     softmax_helper = lambda t: F.softmax(t, 1)       # noqa: E731  (the reference's own helper, net.py:563)
-    for cls, key, orc in ((lambda: IoULoss(apply_nonlin=softmax_helper), "loss/iou", J.iou_loss), (BDLoss, "loss/bd", J.bd_loss)):
+    from jperceiver_amd.model import SoftDiceLoss, TverskyLoss, FocalLoss
+    for cls, key, orc in ((lambda: IoULoss(apply_nonlin=softmax_helper), "loss/iou", J.iou_loss), (BDLoss, "loss/bd", J.bd_loss),
+                          (lambda: SoftDiceLoss(apply_nonlin=softmax_helper), "loss/dice", lambda z, t: J.region_loss(z, t, 2.0, 1.0, 1.0)),
+                          (lambda: TverskyLoss(apply_nonlin=softmax_helper), "loss/tversky", lambda z, t: J.region_loss(z, t, 1.0, 0.3, 0.7)),
+                          (lambda: FocalLoss(apply_nonlin=softmax_helper), "loss/focal", J.focal_loss)):
         z = logits.to(DEV).requires_grad_(True)
         loss = cls()(z, gt.to(DEV))
         assert loss.dim() == 0

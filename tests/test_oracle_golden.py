@@ -84,6 +84,10 @@ def test_unit_vectors():
     logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
     gt = torch.from_numpy(masks[:, 1]).long()
     assert float(J.iou_loss(logits, gt)) == pytest.approx(float(g["loss/iou"]), rel=1e-6)
+    # the other loss_type variants of net.py:562-573, each against the reference's own class
+    assert float(J.region_loss(logits, gt, 2.0, 1.0, 1.0)) == pytest.approx(float(g["loss/dice"]), rel=1e-6)
+    assert float(J.region_loss(logits, gt, 1.0, 0.3, 0.7)) == pytest.approx(float(g["loss/tversky"]), rel=1e-6)
+    assert float(J.focal_loss(logits, gt)) == pytest.approx(float(g["loss/focal"]), rel=1e-6)
     assert float(J.bd_loss(logits, gt)) == pytest.approx(float(g["loss/bd"]), rel=1e-6)
     Bn, H, W = 2, 12, 20
     K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]).repeat(Bn, 1, 1)

@@ -255,6 +255,11 @@ def unit_vectors(net):
     logits = torch.from_numpy((syn.hash_uniform(7, "logits", (5, 2, n, n)) - 0.5) * 4)
     gt = torch.from_numpy(masks[:, 1]).long()
     g["loss/iou"] = np.float64(dl.IoULoss(apply_nonlin=lambda t: F.softmax(t, 1))(logits, gt).item())
+    sm = lambda t: F.softmax(t, 1)          # noqa: E731
+    g["loss/dice"] = np.float64(dl.SoftDiceLoss(apply_nonlin=sm)(logits, gt).item())
+    g["loss/tversky"] = np.float64(dl.TverskyLoss(apply_nonlin=sm)(logits, gt).item())
+    fl = sys.modules["mono.model.mono_baseline.focal_loss"]
+    g["loss/focal"] = np.float64(fl.FocalLoss(apply_nonlin=sm)(logits, gt).item())
     g["loss/bd"] = np.float64(bl.BDLoss()(logits, gt).item())
     g["loss/ce"] = np.float64(nn.CrossEntropyLoss(weight=torch.tensor([1.0, 5.0]))(logits, gt).item())
     # Backproject / Project / grid_sample (layers.py:41-82, net.py:690-702) on a tiny case
