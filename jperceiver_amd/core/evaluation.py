@@ -132,8 +132,10 @@ def eval_layout(logits, label):
     return [(_iu_from_counts(ci), _prec_from_counts(ci)) for ci in c]
 
 
-def eval_depth(disp, gt_depth, stereo_scale=False, min_depth=0.1, max_depth=100):
-    """eval_hooks.py:147-179 for one sample: disp (1,1,h,w) network output, gt_depth (H,W)."""
+def eval_depth(disp, gt_depth, stereo_scale=False, min_depth=0.1, max_depth=100, mask_min=MIN_DEPTH, mask_max=MAX_DEPTH,
+               stereo_factor=36.0):
+    """eval_hooks.py:147-179 for one sample: disp (1,1,h,w) network output, gt_depth (H,W).  mask_min / mask_max /
+    stereo_factor default to the hook's constants (1e-3, 80, 36); scripts/eval_depth_eigen.py uses (0.1, 80, 1)."""
     disp, gt = _dev(disp), _dev(gt_depth)
     assert disp.dim() == 4 and disp.shape[:2] == (1, 1) and gt.dim() == 2
     h, w = disp.shape[2:]
@@ -147,14 +149,14 @@ def eval_depth(disp, gt_depth, stereo_scale=False, min_depth=0.1, max_depth=100)
     pred = torch.empty((H, W), device=disp.device, dtype=torch.float32)
     valid = torch.empty((H, W), device=disp.device, dtype=torch.uint8)
     call("jp_depth_eval_prepare", res, gt, pred, valid, H, W, int(crop[0]), int(crop[1]), int(crop[2]), int(crop[3]),
-         float(MIN_DEPTH), float(MAX_DEPTH))
+         float(mask_min), float(mask_max))
     med_g = torch.empty(2, device=disp.device, dtype=torch.float32)
     med_p = torch.empty(2, device=disp.device, dtype=torch.float32)
     call("jp_masked_median", gt, valid, H * W, med_g)
     call("jp_masked_median", pred, valid, H * W, med_p)
     sums = torch.empty(8, device=disp.device, dtype=torch.float64)
-    call("jp_depth_errors", gt, pred, valid, H * W, med_g, med_p, 36.0 if stereo_scale else 0.0, float(MIN_DEPTH),
-         float(MAX_DEPTH), sums)
+    call("jp_depth_errors", gt, pred, valid, H * W, med_g, med_p, float(stereo_factor) if stereo_scale else 0.0,
+         float(mask_min), float(mask_max), sums)
     s = sums.cpu().tolist()
     mg, mp = med_g.cpu().tolist(), med_p.cpu().tolist()
     abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 = _errors_from_sums(s)

@@ -122,6 +122,8 @@ def _wgrad_stream():
 
 def join_param_grad_streams():
     """Make the current stream wait for the parameter-gradient kernels launched on its companion stream so far."""
+    if not _WG_STREAMS:              # no companion stream was ever created (CPU-side tests of the tape / exchange logic)
+        return
     base = torch.cuda.current_stream()
     st = _WG_STREAMS.get((base.device, base.cuda_stream))
     if st is not None:

@@ -1,0 +1,110 @@
+"""Inference entry points: scripts/eval_depth_eigen.py's evaluation loop and scripts/draw_odometry.py's
+pose chaining, restated on the HIP kernels (jperceiver_amd/apis/inference.py).
+
+* `pose_between`: the 4x4 transform of a frame pair from eval-mode pose nets == the oracle's
+  `transformation_from_parameters` (net.py:704-725 restated) on the oracle's own eval-mode pose-net outputs.
+* `chain_poses` / `odometry`: global_pose <- global_pose @ inv(T_k) (draw_odometry.py:62-76), with a hand-made
+  known answer (pure translations accumulate with the opposite sign).
+* `evaluate_depth`: a numpy restatement of eval_depth_eigen.py:62-104 (mask 0.1..80 m + Garg crop, median scaling,
+  clamp, 7 metrics) on the model's own disparities.
+* `pose_nets_from_checkpoint`: the PoseEncoder.* / PoseDecoder.* copy out of a training checkpoint."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from jperceiver_amd import synthetic as syn                                                   # noqa: E402
+from jperceiver_amd.model import MONO                                                         # noqa: E402
+from jperceiver_amd.model.modules import PoseEncoder, PoseDecoder                             # noqa: E402
+from jperceiver_amd.apis import (evaluate_depth, pose_between, chain_poses, odometry,        # noqa: E402
+                                 pose_nets_from_checkpoint)
+from oracle import jp_oracle as J                                                             # noqa: E402
+
+DEV = "cuda"
+
+
+def _model(HW=256, B=1):
+    opt = J.default_opt(frame_ids=[0, -1, 1], imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type="static",
+                        split="odometry")
+    model = MONO.module_dict["Baseline"](opt)
+    model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=3, bn_stats=True))
+    return opt, model.to(DEV).eval()
+
+
+def test_pose_between_and_chain_match_oracle():
+    opt, model = _model()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    enc, dec = PoseEncoder(18, None, 2), PoseDecoder(np.array([64, 64, 128, 256, 512]))
+    pose_nets_from_checkpoint({"state_dict": sd, "meta": {}}, enc, dec)
+    enc, dec = enc.to(DEV).eval(), dec.to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    frames = torch.rand(4, 3, 192, 640, generator=gen)
+    T = torch.stack([pose_between(enc, dec, frames[k:k + 1].to(DEV), frames[k + 1:k + 2].to(DEV))[0] for k in range(3)])
+    # oracle: eval-mode pose nets of the CPU restatement on the same weights
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    P, Bf = J.make_params(shapes, sd)
+    cx = J.Ctx(P, Bf, training=False)
+    for k in range(3):
+        pair = torch.cat([frames[k:k + 1], frames[k + 1:k + 2]], 1)
+        with torch.no_grad():
+            feats = J.resnet18_features(cx, "PoseEncoder.encoder.", pair)
+            aa, tr = J.pose_decoder(cx, feats)
+            Tr = J.transformation_from_parameters(aa[:, 0], tr[:, 0], invert=False)
+        assert float((T[k].cpu() - Tr[0]).abs().max()) < 2e-5, k
+    poses = odometry(enc, dec, frames.to(DEV))
+    assert poses.shape == (4, 12)
+    g = np.identity(4)
+    ref = [g[:3].reshape(12)]
+    for k in range(3):
+        g = g @ np.linalg.inv(T[k].cpu().double().numpy())
+        ref.append(g[:3].reshape(12))
+    np.testing.assert_allclose(poses, np.stack(ref), rtol=1e-6, atol=1e-7)
+    # known answer: pure translations by +t move the global pose by -t each step
+    Tt = np.tile(np.identity(4), (3, 1, 1))
+    Tt[:, 0, 3] = [1.0, 2.0, 3.0]
+    out = chain_poses(Tt)
+    np.testing.assert_allclose(out[:, 3], [0.0, -1.0, -3.0, -6.0], atol=1e-12)
+    with pytest.raises(RuntimeError):
+        pose_between(enc.train(), dec, frames[:1].to(DEV), frames[1:2].to(DEV))
+    with pytest.raises(KeyError):
+        pose_nets_from_checkpoint({"state_dict": {}}, PoseEncoder(18, None, 2), dec)
+
+
+def test_evaluate_depth_matches_script_restatement():
+    opt, model = _model()
+    inp = syn.make_batch(1, 256, 256, [0, -1, 1], 64, (375, 1242), "odometry", seed=9)
+    inp = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    gen = np.random.default_rng(4)
+    gts = []
+    for _ in range(2):
+        gt = gen.uniform(0.0, 90.0, size=(94, 311)).astype(np.float32)
+        gt[gen.uniform(size=gt.shape) < 0.6] = 0.0                      # sparse LiDAR
+        gts.append(gt)
+    errs, med, std = evaluate_depth(model, [inp, inp], gts)
+    with torch.no_grad():
+        disp = model(inp)[("disp", 0, 0)]
+    pd = (0.01 + (10.0 - 0.01) * disp)[0, 0].cpu().numpy()
+    exp, ratios = [], []
+    for gt in gts:
+        H, W = gt.shape
+        # cv2.resize(INTER_LINEAR) == half-pixel bilinear without antialiasing
+        p = torch.nn.functional.interpolate(torch.from_numpy(pd)[None, None], (H, W), mode="bilinear", align_corners=False)[0, 0].numpy()
+        depth = 1.0 / p
+        mask = (gt > 0.1) & (gt < 80.0)
+        crop = np.array([0.40810811 * H, 0.99189189 * H, 0.03594771 * W, 0.96405229 * W]).astype(np.int32)
+        cm = np.zeros_like(mask)
+        cm[crop[0]:crop[1], crop[2]:crop[3]] = True
+        mask &= cm
+        d, g = depth[mask].astype(np.float64), gt[mask].astype(np.float64)
+        ratio = np.median(g) / np.median(d)
+        ratios.append(ratio)
+        d = np.clip(d * ratio, 0.1, 80.0)
+        th = np.maximum(g / d, d / g)
+        exp.append([np.mean(np.abs(g - d) / g), np.mean((g - d) ** 2 / g), np.sqrt(np.mean((g - d) ** 2)),
+                    np.sqrt(np.mean((np.log(g) - np.log(d)) ** 2)), (th < 1.25).mean(), (th < 1.25 ** 2).mean(),
+                    (th < 1.25 ** 3).mean()])
+    exp = np.asarray(exp).mean(0)
+    np.testing.assert_allclose([errs[k] for k in ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")], exp, rtol=5e-4)
+    assert med == pytest.approx(float(np.median(ratios)), rel=1e-4)
+    assert std == pytest.approx(float(np.std(np.asarray(ratios) / np.median(ratios))), rel=1e-3, abs=1e-6)
