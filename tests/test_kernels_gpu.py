@@ -187,9 +187,11 @@ def test_disparity_head_on_upsampled_source(N, C, h, w):
 
 
 # ------------------------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize("shape", [(3, 48, 14, 18), (3, 64, 14, 18),
+                                   (8, 128, 24, 80)])    # a pose-encoder layer2 shape: float4 path, float runs folded into doubles
 @pytest.mark.parametrize("relu,res,nup", [(True, False, 1), (True, True, 1), (False, False, 2)])
-def test_batchnorm_train(relu, res, nup):
-    N, C, H, W = 3, 48, 14, 18
+def test_batchnorm_train(relu, res, nup, shape):
+    N, C, H, W = shape
     x = rnd(N, C, H, W, seed=1) * 2 + 0.5
     g, b = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.1
     r = rnd(N, C, H, W, seed=4) if res else None
