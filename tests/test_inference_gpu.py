@@ -108,3 +108,27 @@ def test_evaluate_depth_matches_script_restatement():
     np.testing.assert_allclose([errs[k] for k in ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")], exp, rtol=5e-4)
     assert med == pytest.approx(float(np.median(ratios)), rel=1e-4)
     assert std == pytest.approx(float(np.std(np.asarray(ratios) / np.median(ratios))), rel=1e-3, abs=1e-6)
+
+
+def test_lazy_log_vars_reads_like_a_dict_of_floats():
+    """apis.trainer.LazyLogVars: the step's loss terms travel with one asynchronous D2H copy and resolve on first read
+    (no `.item()` sync between forward and backward, mono/apis/trainer.py:44-53 has one per term)."""
+    import json
+    import pickle
+    from collections import OrderedDict
+    from jperceiver_amd.apis.trainer import LazyLogVars
+    names = ["topview_loss", ("min_reconstruct_loss", 0), "layout_loss"]
+    vals = torch.tensor([1.5, 0.25, -3.0], device=DEV)
+    lv = LazyLogVars(names, vals)
+    assert lv._pending
+    assert lv["loss"] == pytest.approx(-1.25) and not lv._pending
+    assert list(lv.keys()) == ["topview_loss", "('min_reconstruct_loss', 0)", "layout_loss", "loss"]
+    assert len(lv) == 4 and "layout_loss" in lv and lv.get("nope", 7) == 7
+    assert json.loads(json.dumps(dict(lv.items())))["topview_loss"] == 1.5
+    assert pickle.loads(pickle.dumps(lv)) == OrderedDict(lv.items())
+    # the pinned ring has two slots: a third instance makes the first one's owner read its values before the buffer is reused
+    a = LazyLogVars(names, vals * 2)
+    b = LazyLogVars(names, vals * 3)
+    c = LazyLogVars(names, vals * 4)
+    assert not a._pending and b._pending
+    assert a["loss"] == pytest.approx(-2.5) and b["loss"] == pytest.approx(-3.75) and c["loss"] == pytest.approx(-5.0)
