@@ -2406,7 +2406,8 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             DgradUPBorderB bb{dy, Nb, h2, w2, Cout};
             DgradEdgeEpi be{dx, C, h2, w2, Nb, 0};
             const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
-            const int bsp = border_splits(btiles, KpU / KC);
+            // 16 slots x Cout: a long K loop of branchy gathers on a few dozen tiles -- up to 4 K slices (atomic epilogue)
+            const int bsp = (int)std::max<long>(border_splits(btiles, KpU / KC), std::min<long>(4, jp_cdiv(256, btiles)));
             const int bkps = jp_cdiv(jp_cdiv(KpU, bsp), KC) * KC;
             be.split = jp_cdiv(KpU, bkps) > 1;
             launch_auto(a, bb, be, C, Nb, KpU, jp_cdiv(KpU, bkps), bkps, st);
