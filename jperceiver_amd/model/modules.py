@@ -40,11 +40,11 @@ class BatchNorm2d(nn.BatchNorm2d):
         super()._load_from_state_dict(*a, **k)
 
 
-def bn_apply(bn: BatchNorm2d, x: Var, residual=None, relu=False, n_updates=1) -> Var:
+def bn_apply(bn: BatchNorm2d, x: Var, residual=None, relu=False, n_updates=1, groups=1) -> Var:
     if bn.training:
-        bn._pending += n_updates
+        bn._pending += n_updates * groups
         return ops.batchnorm_train(x, P(bn.weight), P(bn.bias), bn.running_mean, bn.running_var, residual, relu,
-                                   bn.momentum, bn.eps, n_updates)
+                                   bn.momentum, bn.eps, n_updates, groups)
     return ops.batchnorm_eval(x, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, residual, relu, bn.eps)
 
 
@@ -206,13 +206,13 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def _fwd(self, x, n_updates=1):
-        out = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates)
+    def _fwd(self, x, n_updates=1, groups=1):
+        out = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates, groups=groups)
         out = conv_apply(self.conv2, out)
         res = x
         if self.downsample is not None:
-            res = bn_apply(self.downsample[1], conv_apply(self.downsample[0], x), n_updates=n_updates)
-        return bn_apply(self.bn2, out, residual=res, relu=True, n_updates=n_updates)
+            res = bn_apply(self.downsample[1], conv_apply(self.downsample[0], x), n_updates=n_updates, groups=groups)
+        return bn_apply(self.bn2, out, residual=res, relu=True, n_updates=n_updates, groups=groups)
 
 
 class ResNet(nn.Module):
@@ -242,20 +242,21 @@ class ResNet(nn.Module):
             layers.append(BasicBlock(planes, planes))
         return nn.Sequential(*layers)
 
-    def features(self, img: Var, n_updates=1, ready_tag=None):
+    def features(self, img: Var, n_updates=1, ready_tag=None, groups=1):
         """(x-0.45)/0.225 -> stem -> 4 stages; returns the 5-level pyramid (depth_encoder.py:35-44).
-        `ready_tag`: report gradient completion in two steps (layer4, then the rest) to the data-parallel hook."""
+        `ready_tag`: report gradient completion in two steps (layer4, then the rest) to the data-parallel hook.
+        `groups`: the batch stacks that many independent passes (BatchNorm statistics per group, ops.batchnorm_train)."""
         if ready_tag:
             ops.grad_ready(ready_tag + ".lo")
         x = ops.affine(img, 1.0 / 0.225, -0.45 / 0.225)
-        f0 = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates)
+        f0 = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates, groups=groups)
         feats = [f0]
         x = ops.maxpool(f0, 3, 2, 1)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             if ready_tag and layer is self.layer4:
                 ops.grad_ready(ready_tag + ".l4")
             for blk in layer:
-                x = blk._fwd(x, n_updates)
+                x = blk._fwd(x, n_updates, groups)
             feats.append(x)
         return feats
 
@@ -293,8 +294,8 @@ class PoseEncoder(nn.Module):
             loaded["conv1.weight"] = torch.cat([loaded["conv1.weight"]] * num_input_images, 1) / num_input_images
             self.encoder.load_state_dict(loaded)
 
-    def _fwd(self, img, n_updates=1):
-        return self.encoder.features(img, n_updates)
+    def _fwd(self, img, n_updates=1, groups=1):
+        return self.encoder.features(img, n_updates, groups=groups)
 
     def forward(self, input_image):
         return [f.t for f in self._fwd(Var(input_image))]

@@ -95,6 +95,7 @@ def _broadcast_scalar(s, out):
 
 
 _POSE_STREAM = os.environ.get("JP_POSE_STREAM", "1") != "0"
+_POSE_BATCH = os.environ.get("JP_POSE_BATCH", "1") != "0"       # both pose pairs through the pose nets in one stacked pass
 _LAYOUT_ENC_SIDE = os.environ.get("JP_LAYOUT_ENC_SIDE", "1") != "0"
 
 
@@ -233,10 +234,25 @@ class Baseline(nn.Module):
         def pose_branch():
             ops.grad_ready("Pose")
             pf = {f: ops.bilinear_resize(Var(inputs[("color_aug", f, 0)]), 192, 640) for f in o.frame_ids}
+            ats = {}
+            if _POSE_BATCH and len(src_frames) > 1 and self.training:
+                # all pairs through the pose nets in ONE pass, stacked along the batch: the convolutions run once on k*B
+                # images (twice the workgroups per launch on these small maps, half the launches), BatchNorm keeps the
+                # reference's per-call statistics and running-stat update order (groups = pairs, net.py:630-642)
+                k = len(src_frames)
+                stack = torch.empty((k * B, 6, 192, 640), device=dev0)
+                for i, f in enumerate(src_frames):
+                    first, second = (pf[f], pf[0]) if f < 0 else (pf[0], pf[f])
+                    call("jp_copy_channels", first.t, stack[i * B:(i + 1) * B], B, 3, 192 * 640, 3, 0, 6, 0, 0)
+                    call("jp_copy_channels", second.t, stack[i * B:(i + 1) * B], B, 3, 192 * 640, 3, 0, 6, 3, 0)
+                at_all = self.PoseDecoder._fwd(self.PoseEncoder._fwd(Var(stack), groups=k))      # (k*B, 6)
+                ats = dict(zip(src_frames, ops.split_rows(at_all, B)))
             for f in src_frames:
-                pair = [pf[f], pf[0]] if f < 0 else [pf[0], pf[f]]
-                pfe = self.PoseEncoder._fwd(ops.cat_channels(pair))
-                at = self.PoseDecoder._fwd(pfe)                            # (B,6)
+                if f in ats:
+                    at = ats[f]
+                else:
+                    pair = [pf[f], pf[0]] if f < 0 else [pf[0], pf[f]]
+                    at = self.PoseDecoder._fwd(self.PoseEncoder._fwd(ops.cat_channels(pair)))   # (B,6)
                 aa, tr = _split6(at)
                 pp = ops_loss.pose(aa, tr, K, invert=(f < 0))
                 poses.append(pp)

@@ -409,15 +409,22 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
 
 # ------------------------------------------------------------------------------------------- batch norm
 def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, residual: Var | None = None,
-                    relu=False, momentum=0.1, eps=1e-5, n_updates=1) -> Var:
+                    relu=False, momentum=0.1, eps=1e-5, n_updates=1, groups=1) -> Var:
+    """Train-mode BatchNorm2d (+ residual, ReLU).  `groups` > 1: the batch holds `groups` independent forward passes of the
+    same network stacked along N (the two pose pairs): statistics, running-stat updates (in order) and the backward
+    reductions are taken per group -- exactly what separate calls would do -- while the convolutions around it run once."""
     N, C, H, W = x.t.shape
+    assert N % groups == 0
+    Ng = N // groups
     y = torch.empty_like(x.t)
-    mean = _new((C,), x.t)
-    invstd = _new((C,), x.t)
-    nbw = int(_jplib().fn["jp_bn_ws_doubles"](N, C, H * W))
-    ws = _new((nbw,), x.t, torch.float64)
-    call("jp_bn_train_fwd", x.t, gamma.t, beta.t, residual.t if residual is not None else None, y, running_mean,
-         running_var, mean, invstd, ws, N, C, H * W, momentum, eps, int(relu), n_updates)
+    mean = _new((groups, C), x.t)
+    invstd = _new((groups, C), x.t)
+    nbw = int(_jplib().fn["jp_bn_ws_doubles"](Ng, C, H * W))
+    for g in range(groups):
+        sl = slice(g * Ng, (g + 1) * Ng)
+        ws = _new((nbw,), x.t, torch.float64)
+        call("jp_bn_train_fwd", x.t[sl], gamma.t, beta.t, residual.t[sl] if residual is not None else None, y[sl], running_mean,
+             running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates)
     out = Var(y, x.rg or gamma.rg or (residual is not None and residual.rg))
 
     def bwd():
@@ -426,11 +433,13 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
         dx = torch.empty_like(x.t)
         need_res = residual is not None and residual.rg
         dres = torch.empty_like(x.t) if need_res else None
-        ws2 = _new((nbw,), x.t, torch.float64)
-        # residual-free ReLU layers: the kernel recomputes the mask from x (fmaf(x, sc, sh) > 0, bit-identical to the
-        # forward's) instead of reading y
-        call("jp_bn_train_bwd", out.g, x.t, y if (relu and residual is not None) else None, gamma.t, beta.t, mean, invstd, dx,
-             dres, gamma.g, beta.g, ws2, N, C, H * W, int(relu), 1)
+        for g in range(groups):
+            sl = slice(g * Ng, (g + 1) * Ng)
+            ws2 = _new((nbw,), x.t, torch.float64)
+            # residual-free ReLU layers: the kernel recomputes the mask from x (fmaf(x, sc, sh) > 0, bit-identical to the
+            # forward's) instead of reading y
+            call("jp_bn_train_bwd", out.g[sl], x.t[sl], y[sl] if (relu and residual is not None) else None, gamma.t, beta.t,
+                 mean[g], invstd[g], dx[sl], dres[sl] if need_res else None, gamma.g, beta.g, ws2, Ng, C, H * W, int(relu), 1)
         if x.rg:
             x.add_grad(dx)
         if need_res:
@@ -439,6 +448,30 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
 
     _rec(out.rg, bwd)
     return out
+
+
+def split_rows(v: Var, n: int):
+    """(k*n, ...) -> k Vars of n rows each (views of v's storage); their gradients are gathered back into v's."""
+    k = v.t.shape[0] // n
+    parts = [Var(v.t[i * n:(i + 1) * n], v.rg) for i in range(k)]
+
+    def bwd():
+        if all(p.g is None for p in parts):
+            return
+        g, acc = v.grad_buf()
+        for i, p in enumerate(parts):
+            dst = g[i * n:(i + 1) * n]
+            if p.g is None:
+                if not acc:
+                    dst.zero_()
+            elif acc:
+                dst.add_(p.g)
+            else:
+                dst.copy_(p.g)
+            p.g = None
+
+    _rec(v.rg, bwd)
+    return parts
 
 
 # ------------------------------------------------------------------------------------------- pooling etc.
