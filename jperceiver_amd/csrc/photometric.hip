@@ -273,26 +273,19 @@ __global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------ SSIM + L1 forward
 // block = 4 waves; wave w of block (bx, by, b) owns columns [64*(4*bx+w), +64) and rows [ROWS*by, +ROWS)
-constexpr int SSIM_ROWS = 16;
+constexpr int SSIM_ROWS = 4;
 
 struct RowSums { float x, y, xx, yy, xy; };
 
-__device__ __forceinline__ RowSums ssim_hsum(const float* __restrict__ xr, const float* __restrict__ yr, int x,
-                                             int W, int lane, float& xc, float& yc) {
-    // centre value from this lane, neighbours from the adjacent lanes; strip / image edges reload
-    const int xs = min(x, W - 1);
-    xc = xr[xs];
-    yc = yr[xs];
-    float xl = __shfl_up(xc, 1, 64), yl = __shfl_up(yc, 1, 64);
-    float xrn = __shfl_down(xc, 1, 64), yrn = __shfl_down(yc, 1, 64);
-    if (lane == 0 || x == 0) {
-        const int j = jp_reflect(x - 1, W);
-        xl = xr[min(j, W - 1)]; yl = yr[min(j, W - 1)];
-    }
-    if (lane == 63 || x >= W - 1) {
-        const int j = jp_reflect(min(x, W - 1) + 1, W);
-        xrn = xr[j]; yrn = yr[j];
-    }
+// One row of the 3x3 window sums at column x.  The three column indices (x-1, x, x+1 with ReflectionPad2d(1) resolved)
+// are per-lane constants, so a row costs six independent, coalesced loads and no branch: the row loop below is
+// straight-line code whose loads the compiler can keep in flight (the earlier version took the neighbours from
+// adjacent lanes and reloaded at strip edges inside per-row branches -- one dependent load step per row: 1.6 TB/s).
+__device__ __forceinline__ RowSums ssim_hsum(const float* __restrict__ xr, const float* __restrict__ yr, int il, int ic,
+                                             int ir, float& xc, float& yc) {
+    const float xl = xr[il], xrn = xr[ir], yl = yr[il], yrn = yr[ir];
+    xc = xr[ic];
+    yc = yr[ic];
     RowSums s;
     s.x = xl + xc + xrn;
     s.y = yl + yc + yrn;
@@ -311,6 +304,9 @@ __global__ __launch_bounds__(TPB) void ssim_l1_fwd_kernel(const float* __restric
     const int b = blockIdx.z;
     const int ybeg = blockIdx.y * SSIM_ROWS, yend = min(H, ybeg + SSIM_ROWS);
     const size_t HW = (size_t)H * W;
+    const int ic = min(x, W - 1), il = jp_reflect(ic - 1, W), ir = jp_reflect(ic + 1, W);
+    // row offsets of the window rows -1 .. SSIM_ROWS (reflection at the image border; rows past the strip end are
+    // clamped to a valid row and their results dropped)
     float accS[SSIM_ROWS], accL[SSIM_ROWS];
 #pragma unroll
     for (int r = 0; r < SSIM_ROWS; ++r) accS[r] = accL[r] = 0.f;
@@ -319,31 +315,29 @@ __global__ __launch_bounds__(TPB) void ssim_l1_fwd_kernel(const float* __restric
         const float* xp = pred + ((size_t)b * 3 + ch) * HW;
         const float* yp = target + ((size_t)b * 3 + ch) * HW;
         RowSums r0, r1, r2;
-        float xc, yc, xc1 = 0.f, yc1 = 0.f;
+        float xc, yc, xc1, yc1;
         {
-            const int ya = jp_reflect(ybeg - 1, H);
-            r0 = ssim_hsum(xp + (size_t)ya * W, yp + (size_t)ya * W, x, W, lane, xc, yc);
-            r1 = ssim_hsum(xp + (size_t)ybeg * W, yp + (size_t)ybeg * W, x, W, lane, xc1, yc1);
+            const size_t oa = (size_t)jp_reflect(ybeg - 1, H) * W, ob = (size_t)ybeg * W;
+            r0 = ssim_hsum(xp + oa, yp + oa, il, ic, ir, xc, yc);
+            r1 = ssim_hsum(xp + ob, yp + ob, il, ic, ir, xc1, yc1);
         }
 #pragma unroll
         for (int r = 0; r < SSIM_ROWS; ++r) {
-            const int y = ybeg + r;
-            if (y < yend) {   // wave-uniform
-                const int yn = jp_reflect(y + 1, H);
-                float xc2, yc2;
-                r2 = ssim_hsum(xp + (size_t)yn * W, yp + (size_t)yn * W, x, W, lane, xc2, yc2);
-                const float k = 1.f / 9.f;
-                const float mx = (r0.x + r1.x + r2.x) * k, my = (r0.y + r1.y + r2.y) * k;
-                const float sx = (r0.xx + r1.xx + r2.xx) * k - mx * mx;
-                const float sy = (r0.yy + r1.yy + r2.yy) * k - my * my;
-                const float sxy = (r0.xy + r1.xy + r2.xy) * k - mx * my;
-                const float n = (2.f * mx * my + SSIM_C1) * (2.f * sxy + SSIM_C2);
-                const float d = (mx * mx + my * my + SSIM_C1) * (sx + sy + SSIM_C2);
-                accS[r] += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
-                const float df = yc1 - xc1;
-                accL[r] += sqrtf(df * df + 1e-6f);
-                r0 = r1; r1 = r2; xc1 = xc2; yc1 = yc2;
-            }
+            const int y = min(ybeg + r, H - 1);
+            const size_t on = (size_t)jp_reflect(y + 1, H) * W;
+            float xc2, yc2;
+            r2 = ssim_hsum(xp + on, yp + on, il, ic, ir, xc2, yc2);
+            const float k = 1.f / 9.f;
+            const float mx = (r0.x + r1.x + r2.x) * k, my = (r0.y + r1.y + r2.y) * k;
+            const float sx = (r0.xx + r1.xx + r2.xx) * k - mx * mx;
+            const float sy = (r0.yy + r1.yy + r2.yy) * k - my * my;
+            const float sxy = (r0.xy + r1.xy + r2.xy) * k - mx * my;
+            const float n = (2.f * mx * my + SSIM_C1) * (2.f * sxy + SSIM_C2);
+            const float d = (mx * mx + my * my + SSIM_C1) * (sx + sy + SSIM_C2);
+            accS[r] += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
+            const float df = yc1 - xc1, v = df * df + 1e-6f;
+            accL[r] += v * rsqrtf(v);                  // sqrt(v), v >= 1e-6: one v_rsq_f32 instead of the IEEE sqrt sequence
+            r0 = r1; r1 = r2; xc1 = xc2; yc1 = yc2;
         }
     }
     if (x < W) {
@@ -357,99 +351,116 @@ __global__ __launch_bounds__(TPB) void ssim_l1_fwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------ SSIM + L1 backward
 // dpred = d( sum_q g_q * reproj(q) ) / d pred, g_q = gscale * [min_index(q) == cand] (or 1 if no index).
-// LDS tile: outputs 32 x 16, V-coefficients on (32+2) x (16+2), inputs on (32+4) x (16+4).
-constexpr int BT_W = 32, BT_H = 16;
+// Two nested 3x3 stencils: the SSIM value of window centre q depends on the 3x3 neighbourhood of q (reflection padded),
+// so pixel r collects  SA + x_r*SB + y_r*SG  with S* = sum over the (in-image) centres q around r of w(r,q) * (A,B,G)_q --
+// w counts how often the reflection padding shows r to window q (twice when q sits on the border and r next to it).
+// Row-streaming form (like the forward): a wave owns 64 coefficient columns c0-1 .. c0+62 and marches down the rows.
+// Per row it loads the six input values of its column (per-lane constant, reflection-resolved column indices: no
+// branches), forms the window sums from a 3-row register window, the coefficients (A, B, G), their weighted horizontal
+// 3-sums through wave shuffles, and -- two rows later -- the output row from a 3-row window of those.  Lanes 1..62
+// produce outputs (neighbouring strips overlap by two columns).  No LDS, no barrier; the earlier LDS-tile version ran
+// three barrier-separated phases per channel on 32x16 tiles (1.4 TB/s).
+constexpr int SSIMB_ROWS = 8;
 
 __global__ __launch_bounds__(TPB) void ssim_l1_bwd_kernel(const float* __restrict__ pred,
                                                           const float* __restrict__ target,
                                                           const int64_t* __restrict__ min_index, int cand,
                                                           const float* __restrict__ gout, float gscale,
                                                           float* __restrict__ dpred, int H, int W) {
-    __shared__ float xs[BT_H + 4][BT_W + 4];
-    __shared__ float ys[BT_H + 4][BT_W + 4];
-    __shared__ float va[BT_H + 2][BT_W + 2];
-    __shared__ float vb[BT_H + 2][BT_W + 2];
-    __shared__ float vg[BT_H + 2][BT_W + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wv;
+    if (strip * 62 >= W) return;                             // wave-uniform
+    const int cq = strip * 62 - 1 + lane;                    // this lane's coefficient / output column
+    const bool col_in = cq >= 0 && cq < W;
+    const bool col_out = col_in && lane >= 1 && lane <= 62;
+    const int ic = min(max(cq, 0), W - 1), il = jp_reflect(ic - 1, W), ir = jp_reflect(ic + 1, W);
+    const float wl = (cq == 1) ? 2.f : 1.f, wr = (cq == W - 2) ? 2.f : 1.f;       // weights of the columns cq-1 / cq+1
     const int b = blockIdx.z;
-    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const int ybeg = blockIdx.y * SSIMB_ROWS, yend = min(H, ybeg + SSIMB_ROWS);
     const size_t HW = (size_t)H * W;
     const float gs = gscale * (gout ? gout[0] : 1.f);
-    const int64_t* mi = min_index ? min_index + (size_t)b * HW : nullptr;
+    const int* mi32 = min_index ? reinterpret_cast<const int*>(min_index + (size_t)b * HW) : nullptr;   // low dwords
+#pragma unroll 1
     for (int ch = 0; ch < 3; ++ch) {
         const float* xp = pred + ((size_t)b * 3 + ch) * HW;
         const float* yp = target + ((size_t)b * 3 + ch) * HW;
-        __syncthreads();
-        for (int i = threadIdx.x; i < (BT_H + 4) * (BT_W + 4); i += TPB) {
-            const int ly = i / (BT_W + 4), lx = i - ly * (BT_W + 4);
-            // padded coordinate (y0-2+ly): clamp far-outside to keep indices legal, then reflect
-            int gy = min(max(y0 - 2 + ly, -1), H), gx = min(max(x0 - 2 + lx, -1), W);
-            gy = jp_reflect(gy, H); gx = jp_reflect(gx, W);
-            xs[ly][lx] = xp[(size_t)gy * W + gx];
-            ys[ly][lx] = yp[(size_t)gy * W + gx];
+        float* dp = dpred + ((size_t)b * 3 + ch) * HW;
+        RowSums r0, r1, r2;
+        float xc1, yc1, xc2, yc2;                         // centre values of the window rows
+        {
+            float xd, yd;
+            const size_t oa = (size_t)jp_reflect(min(max(ybeg - 2, -1), H), H) * W;
+            const size_t ob = (size_t)jp_reflect(ybeg - 1, H) * W;
+            r0 = ssim_hsum(xp + oa, yp + oa, il, ic, ir, xd, yd);
+            r1 = ssim_hsum(xp + ob, yp + ob, il, ic, ir, xc1, yc1);
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < (BT_H + 2) * (BT_W + 2); i += TPB) {
-            const int ly = i / (BT_W + 2), lx = i - ly * (BT_W + 2);
-            const int qy = y0 - 1 + ly, qx = x0 - 1 + lx;
-            float A = 0.f, Bc = 0.f, Gc = 0.f;
-            if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
-                float g = gs;
-                if (mi) g = (mi[(size_t)qy * W + qx] == cand) ? gs : 0.f;
-                if (g != 0.f) {
-                    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const float xv = xs[ly + dy][lx + dx], yv = ys[ly + dy][lx + dx];
-                            sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
-                        }
-                    const float k = 1.f / 9.f;
-                    const float mx = sx * k, my = sy * k;
-                    const float vx = sxx * k - mx * mx, vy = syy * k - my * my, cxy = sxy * k - mx * my;
-                    const float n1 = 2.f * mx * my + SSIM_C1, n2 = 2.f * cxy + SSIM_C2;
-                    const float d1 = mx * mx + my * my + SSIM_C1, d2 = vx + vy + SSIM_C2;
-                    const float n = n1 * n2, d = d1 * d2;
-                    const float val = (1.f - n / d) * 0.5f;
-                    if (val >= 0.f && val <= 1.f) {
-                        const float k2 = 2.f / 9.f;
-                        Gc = g * k2 * n1 / d;
-                        Bc = -g * k2 * n * d1 / (d * d);
-                        A = g * k2 * (my * (n2 - n1) / d - n * mx * (d2 - d1) / (d * d));
-                    }
+        float hA0 = 0.f, hB0 = 0.f, hG0 = 0.f, hA1 = 0.f, hB1 = 0.f, hG1 = 0.f;
+        float xo = 0.f, yo = 0.f, go = 0.f;               // centre values / mask of the row that is output next
+        // software prefetch: the six values of the NEXT step's row (and its mask word) are requested one step ahead
+        auto rowoff = [&](int t) -> size_t { return (size_t)jp_reflect(min(ybeg + t, H), H) * W; };   // row q+1 of step t
+        auto qrow = [&](int t) -> int { return min(max(ybeg - 1 + t, 0), H - 1); };
+        size_t on = rowoff(0);
+        float nxl = xp[on + il], nxc = xp[on + ic], nxr = xp[on + ir], nyl = yp[on + il], nyc = yp[on + ic], nyr = yp[on + ir];
+        int nmi = mi32 ? mi32[2 * ((size_t)qrow(0) * W + ic)] : cand;
+        // a real loop (not unrolled): unrolled, the compiler hoists every row's loads to the top and needs 246 VGPRs;
+        // rolled, the body keeps ~70 and eight waves per SIMD hide what the one-step prefetch does not
+#pragma unroll 1
+        for (int t = 0; t < SSIMB_ROWS + 2; ++t) {
+            const int q = ybeg - 1 + t;                    // coefficient row of this step (wave-uniform)
+            const float xl = nxl, xr = nxr, yl = nyl, yr = nyr;
+            xc2 = nxc; yc2 = nyc;
+            const int miv = nmi;
+            if (t + 1 < SSIMB_ROWS + 2) {
+                on = rowoff(t + 1);
+                nxl = xp[on + il]; nxc = xp[on + ic]; nxr = xp[on + ir];
+                nyl = yp[on + il]; nyc = yp[on + ic]; nyr = yp[on + ir];
+                if (mi32) nmi = mi32[2 * ((size_t)qrow(t + 1) * W + ic)];
+            }
+            r2.x = xl + xc2 + xr;
+            r2.y = yl + yc2 + yr;
+            r2.xx = xl * xl + xc2 * xc2 + xr * xr;
+            r2.yy = yl * yl + yc2 * yc2 + yr * yr;
+            r2.xy = xl * yl + xc2 * yc2 + xr * yr;
+            // ---- coefficients of window centre (q, cq)
+            const bool q_in = q >= 0 && q < H && col_in;
+            const float g = (q_in && miv == cand) ? gs : 0.f;
+            const float k = 1.f / 9.f;
+            const float mx = (r0.x + r1.x + r2.x) * k, my = (r0.y + r1.y + r2.y) * k;
+            const float vx = (r0.xx + r1.xx + r2.xx) * k - mx * mx, vy = (r0.yy + r1.yy + r2.yy) * k - my * my;
+            const float cxy = (r0.xy + r1.xy + r2.xy) * k - mx * my;
+            const float n1 = 2.f * mx * my + SSIM_C1, n2 = 2.f * cxy + SSIM_C2;
+            const float d1 = mx * mx + my * my + SSIM_C1, d2 = vx + vy + SSIM_C2;
+            const float n = n1 * n2, d = d1 * d2;
+            // one IEEE division per window (the reciprocal of d); the five quotients of the formulas are products with it
+            const float invd = 1.f / d, nd = n * invd;
+            const float val = (1.f - nd) * 0.5f;
+            const float gk = (val >= 0.f && val <= 1.f) ? g * (2.f / 9.f) : 0.f;
+            const float G = gk * n1 * invd;
+            const float Bc = -gk * nd * d1 * invd;
+            const float A = gk * (my * (n2 - n1) * invd - nd * mx * (d2 - d1) * invd);
+            // ---- weighted horizontal 3-sums (columns outside the image carry zeros: gk == 0 there)
+            const float hA2 = wl * __shfl_up(A, 1, 64) + A + wr * __shfl_down(A, 1, 64);
+            const float hB2 = wl * __shfl_up(Bc, 1, 64) + Bc + wr * __shfl_down(Bc, 1, 64);
+            const float hG2 = wl * __shfl_up(G, 1, 64) + G + wr * __shfl_down(G, 1, 64);
+            // ---- output row ry = q - 1 from the coefficient rows q-2 (h*0), q-1 (h*1), q (h*2)
+            if (t >= 2) {
+                const int ry = q - 1;
+                if (ry < yend && col_out) {
+                    const float wu = (ry == 1) ? 2.f : 1.f, wd = (ry == H - 2) ? 2.f : 1.f;
+                    const float SA = wu * hA0 + hA1 + wd * hA2;
+                    const float SB = wu * hB0 + hB1 + wd * hB2;
+                    const float SG = wu * hG0 + hG1 + wd * hG2;
+                    const float df = xo - yo;
+                    const float l1 = go * df * rsqrtf(df * df + 1e-6f);
+                    dp[(size_t)ry * W + cq] = -0.5f * (0.85f / 3.f) * (SA + xo * SB + yo * SG) + (0.15f / 3.f) * l1;
                 }
             }
-            va[ly][lx] = A; vb[ly][lx] = Bc; vg[ly][lx] = Gc;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < BT_H * BT_W; i += TPB) {
-            const int ly = i / BT_W, lx = i - ly * BT_W;
-            const int ry = y0 + ly, rx = x0 + lx;
-            if (ry >= H || rx >= W) continue;
-            float SA = 0.f, SB = 0.f, SG = 0.f;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int qy = ry + dy;
-                if (qy < 0 || qy >= H) continue;
-                const float wy = 1.f + ((ry == 1 && qy == 0) ? 1.f : 0.f) + ((ry == H - 2 && qy == H - 1) ? 1.f : 0.f);
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int qx = rx + dx;
-                    if (qx < 0 || qx >= W) continue;
-                    const float w = wy * (1.f + ((rx == 1 && qx == 0) ? 1.f : 0.f) +
-                                          ((rx == W - 2 && qx == W - 1) ? 1.f : 0.f));
-                    SA += w * va[ly + 1 + dy][lx + 1 + dx];
-                    SB += w * vb[ly + 1 + dy][lx + 1 + dx];
-                    SG += w * vg[ly + 1 + dy][lx + 1 + dx];
-                }
-            }
-            const float xr = xs[ly + 2][lx + 2], yr = ys[ly + 2][lx + 2];
-            float g = gs;
-            if (mi) g = (mi[(size_t)ry * W + rx] == cand) ? gs : 0.f;
-            const float df = xr - yr;
-            const float l1 = g * df / sqrtf(df * df + 1e-6f);
-            dpred[((size_t)b * 3 + ch) * HW + (size_t)ry * W + rx] =
-                -0.5f * (0.85f / 3.f) * (SA + xr * SB + yr * SG) + (0.15f / 3.f) * l1;
+            // the row whose coefficients were just formed (q) is output next step: keep its centre values and mask
+            xo = xc1; yo = yc1; go = g;
+            hA0 = hA1; hB0 = hB1; hG0 = hG1;
+            hA1 = hA2; hB1 = hB2; hG1 = hG2;
+            r0 = r1; r1 = r2;
+            xc1 = xc2; yc1 = yc2;
         }
     }
 }
@@ -614,7 +625,7 @@ extern "C" int jp_ssim_l1_bwd(const float* pred, const float* target, const int6
                               const float* gout, float gscale, float* dpred, int B, int H, int W, void* stream) {
     JP_CHECK_ARG(pred && target && dpred && B > 0 && H >= 2 && W >= 2, "ssim_l1_bwd: bad args");
     JP_ST;
-    dim3 grid(jp_cdiv(W, BT_W), jp_cdiv(H, BT_H), B);
+    dim3 grid(jp_cdiv(jp_cdiv(W, 62), 4), jp_cdiv(H, SSIMB_ROWS), B);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, grid, dim3(TPB), 0, st, pred, target, min_index, cand, gout, gscale, dpred,
                        H, W);
     JP_LAUNCH_CHECK();
