@@ -548,7 +548,8 @@ extern "C" int jp_layout_loss_fwd(const float* logits, const float* label, const
     JP_CHECK_ARG(logits && label && sums && loss && B > 0, "layout_loss_fwd: bad args");
     JP_ST;
     JP_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (8 * B + 3), st));
-    hipLaunchKernelGGL(layout_fwd_kernel, dim3(std::min(jp_cdiv(h * w, TPB), 256), B), dim3(TPB), 0, st, logits, label,
+    // 16 pixels per thread: the nine block reductions + double atomics per workgroup are what this small kernel costs
+    hipLaunchKernelGGL(layout_fwd_kernel, dim3(std::max(1, std::min(jp_cdiv(h * w, TPB * 16), 64)), B), dim3(TPB), 0, st, logits, label,
                        sdf, sums, B, h * w, w0, w1, ra, ralpha, rbeta);
     hipLaunchKernelGGL(layout_finalize_kernel, dim3(1), dim3(64), 0, st, sums, loss, B, h * w, lw, cew, l2w, ra, ralpha, rbeta);
     JP_LAUNCH_CHECK();

@@ -45,13 +45,23 @@ __global__ void bias_act_rows_kernel(float* __restrict__ y, const float* __restr
         y[i] = jp_act(y[i] + (bias ? bias[i % N] : 0.f), act);
 }
 
-// out[c] (+)= sum_r x[r][c]
-__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// out[c] (+)= sum_r x[r][c]: 64 columns x 16 row lanes per workgroup (fixed summation order: deterministic), so a tall
+// matrix (the linear layers' bias gradient: M = B*C rows) is not one thread's serial loop over M rows
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                      int accumulate) {
+    __shared__ float part[16][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int r = 0; r < M; ++r) s += x[(size_t)r * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < N)
+        for (int r = ty; r < M; r += 16) s += x[(size_t)r * N + c];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += part[k][tx];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // E (B, R, Cn): val[b][j] = max_i E[b][i][j], arg = first argmax (torch.max(dim=1) on CPU/GPU returns
@@ -202,7 +212,7 @@ extern "C" int jp_bias_act_rows(float* y, const float* bias, int M, int N, int a
 extern "C" int jp_colsum(const float* x, float* out, int M, int N, int accumulate, void* stream) {
     JP_CHECK_ARG(x && out && M > 0 && N > 0, "colsum: bad args");
     JP_ST;
-    hipLaunchKernelGGL(colsum_kernel, dim3(jp_cdiv(N, 64)), dim3(64), 0, st, x, out, M, N, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(jp_cdiv(N, 64)), dim3(1024), 0, st, x, out, M, N, accumulate);
     JP_LAUNCH_CHECK();
 }
 
