@@ -52,3 +52,20 @@ print(f"# idle total {sum(g[0] for g in gaps) / 1e6:.3f} ms in {len(gaps)} gaps;
       f"{sum(g[0] for g in gaps if g[0] > 20000) / 1e6:.3f} ms")
 for g, a, b in gaps[:15]:
     print(f"  {g / 1e3:7.1f} us  after {short(a)}  before {short(b)}")
+
+# ---- which kernels run ALONE (nothing else in flight): the step's un-overlapped, i.e. critical, time by kernel name
+solo = {}
+evs = sorted([(max(s_, t0), 1, i) for i, (n, s_, e, q) in enumerate(step)] + [(e, -1, i) for i, (n, s_, e, q) in enumerate(step)])
+live, last = set(), t0
+for t, d, i in evs:
+    if len(live) == 1:
+        n = short(step[next(iter(live))][0])
+        solo[n] = solo.get(n, 0) + (t - last)
+    last = t
+    if d > 0:
+        live.add(i)
+    else:
+        live.discard(i)
+print(f"# time with exactly one kernel in flight, by kernel (total {sum(solo.values()) / 1e6:.3f} ms):")
+for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:25]:
+    print(f"  {v / 1e3:8.1f} us  {n}")
