@@ -156,17 +156,51 @@ __global__ __launch_bounds__(256) void pack_one_kernel(JpPackJob job) {
         job.wp[i] = pack_elem(job.mode, job.w, i, job.p);
 }
 
-// every pack of the model in one launch: workgroup-sized pieces of the concatenated element range, job found by
-// binary search over the prefix offsets (wave-uniform: a 256-element piece never straddles ... it may: per-thread search)
+// every pack of the model in one launch.  The concatenated element range is walked in groups of FOUR consecutive elements
+// (the host aligns every job's begin to a multiple of 4, jp_pack_replay contract): one binary search over the prefix
+// offsets per group, and for the fragment-order packs -- most of the elements -- one index decode per group (the four
+// elements are the four k-steps j of one quad: same tile, row, parity and tap) and one 16-byte store.
 __global__ __launch_bounds__(256) void pack_replay_kernel(const JpPackJob* __restrict__ jobs, int njobs, long total) {
-    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long groups = (total + 3) >> 2;
+    for (long g4 = (long)blockIdx.x * 256 + threadIdx.x; g4 < groups; g4 += (long)gridDim.x * 256) {
+        const long g = g4 << 2;
         int lo = 0, hi = njobs - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (jobs[mid].begin <= g) lo = mid; else hi = mid - 1;
         }
         const JpPackJob& j = jobs[lo];
-        j.wp[g - j.begin] = pack_elem(j.mode, j.w, g - j.begin, j.p);
+        const long i = g - j.begin;
+        if (i >= j.total) continue;                         // alignment padding between two jobs
+        if (j.mode == PACK_FRAG && i + 4 <= j.total) {
+            const int* p = j.p;
+            const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4];
+            const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+            const long per_tile = ((long)((red + 31) / 32) * KHW * 4 + P9_QAHEAD + 1) * 8 * BMT;
+            const int mt = (int)(i / per_tile);
+            long t = (i - (long)mt * per_tile) >> 2;
+            const int m = mt * BMT + (int)(t % BMT);
+            t /= BMT;
+            const int par = (int)(t & 1); t >>= 1;          // t = quad
+            const long step = t * 4;                        // k-steps step .. step+3 share (chunk, tap)
+            const int s0 = (int)(step & 15);
+            const long tc = step >> 4;
+            const int tap = (int)(tc % KHW), c0 = (int)(tc / KHW) * 32 + 2 * s0 + par;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < rows) {
+                const size_t cs = for_dgrad ? (size_t)Cin * KHW : (size_t)KHW;      // stride of the reduction channel in w
+                const float* wb = j.w + (for_dgrad ? (size_t)m * KHW : (size_t)m * Cin * KHW) + tap;
+                if (c0 < red) v.x = wb[(size_t)c0 * cs];
+                if (c0 + 2 < red) v.y = wb[(size_t)(c0 + 2) * cs];
+                if (c0 + 4 < red) v.z = wb[(size_t)(c0 + 4) * cs];
+                if (c0 + 6 < red) v.w = wb[(size_t)(c0 + 6) * cs];
+            }
+            *reinterpret_cast<float4*>(j.wp + i) = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < j.total) j.wp[i + k] = pack_elem(j.mode, j.w, i + k, j.p);
+        }
     }
 }
 
@@ -2722,7 +2756,7 @@ extern "C" int jp_pack_record_end(void) {
 // jobs: DEVICE copy of `njobs` records whose `begin` fields hold the exclusive prefix sum of `total`; total_elems = the sum.
 extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, void* stream) {
     JP_CHECK_ARG(jobs && njobs > 0 && total_elems > 0, "pack_replay: bad args");
-    hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 1023) / 1024, 8192)), dim3(256), 0,
+    hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 4095) / 4096, 16384)), dim3(256), 0,
                        (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
     JP_LAUNCH_CHECK();
 }

@@ -213,9 +213,11 @@ class PackRegistry:
             jobs = np.concatenate([e.jobs for e in live]) if live else None
             if jobs is None or len(jobs) == 0:
                 return
-            jobs["begin"] = np.concatenate([[0], np.cumsum(jobs["total"])[:-1]])
+            # jp_pack_replay walks the concatenated range in groups of 4 elements: every job begins on a multiple of 4
+            padded = (jobs["total"] + 3) // 4 * 4
+            jobs["begin"] = np.concatenate([[0], np.cumsum(padded)[:-1]])
             dev = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
-            self.table = (dev, len(jobs), int(jobs["total"].sum()), live)
+            self.table = (dev, len(jobs), int(padded.sum()), live)
         dev, n, total, live = self.table
         call("jp_pack_replay", dev, n, total)
         for e in live:
