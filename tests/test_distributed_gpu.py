@@ -138,5 +138,6 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["scaling"] == "weak" and j["value"] > 0
-    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1 and "jp_igemm" in j["roofline"]["kernel"]
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    assert any(k in j["roofline"]["kernel"] for k in ("jp_igemm", "jp_wgrad"))
     assert j["roofline"]["step_frac_fp32"] > 0 and j["families"]
