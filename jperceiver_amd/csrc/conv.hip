@@ -2244,9 +2244,13 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     DgradEpi e{dx, Cin, H * W, accumulate};
     if (ws && Cout >= 16) {
         const int Cp = pad32(Cout), Kp = KH * KH * Cp;
-        if (!ws_state) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
-        PackA a{ws, Cin, Kp, Cp, KH * KH};
         const int sp = small_grid_splits(Cin, npix, Kp);
+        // zero-padded 3x3 stride-1 layers that the P9 main pass covers completely (no row tail, no reflection border pass)
+        // never read the tap-major pack: it is neither built nor replayed for them
+        const bool p9_only = KH == 3 && stride == 1 && pad == 1 && pad_mode != JP_PAD_REFLECT && sp <= 1 &&
+                             !(Cin > 128 && Cin % 128 <= 16 && Cin % 128 != 0) && p9_ok(Cin, Cout, N, H, W);
+        if (!ws_state && !p9_only) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
+        PackA a{ws, Cin, Kp, Cp, KH * KH};
         const long Nc = (long)N * (H / 2) * (W / 2);
         if (KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 && Nc % 256 == 0 &&
             2 * OH == H && 2 * OW == W) {
