@@ -138,6 +138,8 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["scaling"] == "weak" and j["value"] > 0
-    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    # (two processes time-slice one GPU here and the maps are 256x256: a kernel's HIP-event time can be mostly waiting for
+    # the other rank, so the fraction may round to 0.0 -- only its range is checked on this smoke configuration)
+    assert j["roofline"]["bound"] == "mfma" and 0 <= j["roofline"]["frac"] < 1 and j["roofline"]["launches"] >= 1
     assert any(k in j["roofline"]["kernel"] for k in ("jp_igemm", "jp_wgrad"))
     assert j["roofline"]["step_frac_fp32"] > 0 and j["families"]
