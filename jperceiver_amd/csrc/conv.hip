@@ -1819,10 +1819,23 @@ inline bool p9u_enabled() {
 }
 template <class E>
 const char* p9u_tag() { return __PRETTY_FUNCTION__; }
-inline int p9_bmt(int rows) { return rows <= 64 ? 64 : 128; }        // channels per M tile: 64 x (8x32 px) or 128 x (4x32 px)
+// channels per M tile of a bank with `rows` rows: 64 x (8x32 px), 128 x (4x32 px), or -- 3x3 banks whose row count is a
+// multiple of 256 -- 256 x (4x32 px) on 8 waves (JP_P9_M256=0 turns that variant off)
+inline bool p9_m256() {
+    static const int on = [] { const char* e = getenv("JP_P9_M256"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+// `ptiles` = N * (H/4) * (W/32) pixel tiles of the launch (the conv entry points know it when they pack: a layer's pack is
+// keyed by its shape on the host side); the 8-wave variant needs >= 256 workgroups or it leaves CUs empty
+// (512->512 @32x32: 141 -> 92 TF), where it has them it is 2-4 % faster (256->256 @128x128: 141 -> 146 TF)
+inline int p9_bmt(int rows, int khw = 9, long ptiles = 0) {
+    if (rows <= 64) return 64;
+    return (khw == 9 && p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256) ? 256 : 128;
+}
+inline long p9_ptiles(int N, int H, int W) { return (long)N * (H / 4) * (W / 32); }
 inline long dgrad_tap_floats(int Cin, int Cout, int KH) { return ((long)(KH * KH + 16) * Cin + 512 + 64) * ((Cout + 31) / 32 * 32); }
 inline long p9_ws_floats(int rows, int red, int khw = 9) {
-    const int bmt = p9_bmt(rows);
+    const int bmt = rows <= 64 ? 64 : 128;          // the 256-row tiling of the same bank never needs more
     return ((long)jp_cdiv(red, 32) * khw * 4 + P9_QAHEAD + 1) * 8 * bmt * jp_cdiv(rows, bmt);
 }
 // The 1x1 variant (TAPS = 1) measured 103 / 106 TF forward / dgrad on 256->256 @256^2 against 105 / 108 TF of the generic
@@ -1840,13 +1853,18 @@ inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9_tag() { return __PRETTY_FUNCTION__; }       // profiler tag naming the instantiation
 template <bool REFLECT, bool REV, class E>
-void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off = 0) {
+void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off = 0,
+               int bank_rows = -1) {
     const int NCH = jp_cdiv(red, 32);
-    jp_prof_before(rows <= 64 ? p9_tag<1, 4, REFLECT, REV, E>() : p9_tag<2, 2, REFLECT, REV, E>(),
+    const int bmt = p9_bmt(bank_rows < 0 ? rows : bank_rows, 9, p9_ptiles(N, H, W));   // the M tile of the PACK (the bank's rows)
+    jp_prof_before(bmt == 64 ? p9_tag<1, 4, REFLECT, REV, E>() : (bmt == 256 ? p9_tag<4, 2, REFLECT, REV, E>() : p9_tag<2, 2, REFLECT, REV, E>()),
                    2.0 * rows * (double)N * H * W * 9.0 * red, st);
-    if (rows <= 64) {
+    if (bmt == 64) {
         dim3 grid(N * (H / 8) * (W / 32), 1, 1);
         hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W, mt_off);
+    } else if (bmt == 256) {
+        dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<4, 2, REFLECT, REV, E>), grid, dim3(512), 0, st, wp, x, e, rows, red, NCH, H, W, mt_off);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
         hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, REFLECT, REV, E>), grid, dim3(256), 0, st, wp, x, e, rows, red, NCH, H, W, mt_off);
@@ -2115,14 +2133,14 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         const bool use_p1 = KH == 1 && stride == 1 && pad == 0 && !((c0 && up0) || (c1 && up1) || (c2 && up2)) && c1 == 0 &&
                             c2 == 0 && p9_ok(Cout, Cin, N, H, W, 1);
         if (use_p1) {      // 1x1: weights stream in fragment order, two channel chunks of the pixel tile staged per barrier pair
-            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin, 1), Cout, Cin, 0, p9_bmt(Cout), 1, 0, st);
+            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin, 1), Cout, Cin, 0, p9_bmt(Cout, 1), 1, 0, st);
             launch_p1(ws, x0, e, Cout, Cin, N, H, W, st);
             JP_LAUNCH_CHECK();
         }
         if (use_p9) {
             // P9 patch kernel: the input patch of a 4x32 pixel tile is staged once per channel chunk for all 9 taps,
             // weights stream from L2 in MFMA fragment order (igemm_p9.h); its pack takes the place of the tap-major one
-            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin), Cout, Cin, 0, p9_bmt(Cout), 9, 0, st);
+            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin), Cout, Cin, 0, p9_bmt(Cout, 9, p9_ptiles(N, H, W)), 9, 0, st);
             if (pad_mode == JP_PAD_REFLECT) launch_p9<true, false>(ws, x0, e, Cout, Cin, N, H, W, st);
             else launch_p9<false, false>(ws, x0, e, Cout, Cin, N, H, W, st);
             JP_LAUNCH_CHECK();
@@ -2288,7 +2306,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                     const int bn3 = Mm <= 64 ? 256 : 128;
                     if (KH == 1 && pad == 0 && tail == 0 && p9_ok(Cin, Cout, N, H, W, 1)) {
                         float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
-                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout, 1), Cout, Cin, 1, p9_bmt(Cin), 1, 0, st);
+                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout, 1), Cout, Cin, 1, p9_bmt(Cin, 1), 1, 0, st);
                         launch_p1(wfr, dy, e, Cin, Cout, N, H, W, st);
                     } else
                     if (KH == 3 && pad == 1 && (tail == 0 || Mm > 64) && p9_ok(Mm, Cout, N, H, W)) {
@@ -2297,8 +2315,8 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                         // row tail (513 = 4*128 + 1) the kernel runs the full 128-row tiles of the same pack, the tail
                         // its own launch below.
                         float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
-                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin), 9, 0, st);
-                        launch_p9<false, true>(wfr, dy, e, Mm, Cout, N, H, W, st);
+                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin, 9, p9_ptiles(N, H, W)), 9, 0, st);
+                        launch_p9<false, true>(wfr, dy, e, Mm, Cout, N, H, W, st, 0, Cin);
                     } else
                     if (KH == 3 && pad == 1 && Cout >= 32 && W % bn3 == 0 && npix > 64) {
                         // row-tile kernel on dY (taps mirrored, zero fill; the reflection fold stays with the border pass)
@@ -2407,14 +2425,14 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             } else {
                 DgradEpi e{dx, C, H * W, accs[sidx]};
                 const int bn3 = C <= 64 ? 256 : 128;
-                if (Cin > 64 && C > 64 && coff % 128 == 0 && p9_ok(C, Cout, N, H, W)) {
+                if (Cin > 64 && C > 64 && coff % p9_bmt(Cin, 9, p9_ptiles(N, H, W)) == 0 && p9_ok(C, Cout, N, H, W)) {
                     // P9 patch kernel on this segment's 128-row tiles of the whole bank's fragment-order pack
                     float* wfr = ws + dgrad_tap_floats(Cin, Cout, 3);
                     if (!ws_state && !frag_packed) {
-                        do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin), 9, 0, st);
+                        do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin, 9, p9_ptiles(N, H, W)), 9, 0, st);
                         frag_packed = true;
                     }
-                    launch_p9<false, true>(wfr, dy, e, C, Cout, N, H, W, st, coff / 128);
+                    launch_p9<false, true>(wfr, dy, e, C, Cout, N, H, W, st, coff / p9_bmt(Cin, 9, p9_ptiles(N, H, W)), Cin);
                 } else
                 if (W % bn3 == 0 && Cout >= 32) {     // row-tile kernel, see jp_conv2d_dgrad
                     const Src3 sdy = make_src(dy, Cout, 0, nullptr, 0, 0, nullptr, 0, 0, H, W);

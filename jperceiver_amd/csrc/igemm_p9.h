@@ -28,14 +28,16 @@ typedef unsigned jp_p9_u32x4 __attribute__((ext_vector_type(4)));
 // TAPS = 9: 3x3 (patch with a one-pixel halo).  TAPS = 1: 1x1 convolution ("P1": no halo; CPB = 2 channel chunks are
 // staged per barrier pair so that the barrier density stays at 2 per 128 MFMAs).
 template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS = 9, int CPB = 1>
-__global__ __launch_bounds__(256, 2) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9_kernel(const float* __restrict__ wp, const float* __restrict__ x,
                                                           Epi epi, int M, int C, int NCH, int H, int W, int mt_off) {
-    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(WM * WN == 4 || (WM == 4 && WN == 2), "4 waves, or 8 waves = 256 channels x 4 rows");
+    constexpr int NT = 64 * WM * WN, NHW = NT / 32;         // threads, half-waves per block
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     constexpr int HALO = TAPS == 9 ? 1 : 0;
     constexpr int CS = 32 * CPB;                            // channels staged per barrier pair
     constexpr int TR = 2 * WN, PR = TR + 2 * HALO;          // tile rows, patch rows
-    constexpr int NROW = CS * PR / 8;                       // patch rows (c, pr) per 8-row group of the block: loads per thread
+    constexpr int NROW = CS * PR / NHW;                     // patch rows (c, pr) per NHW-row group of the block: loads per thread
+    static_assert(CS % NHW == 0, "channel groups per patch row");
     constexpr int STEPS = TAPS * 16 * CPB;                  // k-steps (of 2) per stage
     __shared__ float patch[CS * PR * P9_PITCH];
 
@@ -74,23 +76,23 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9_kernel(const float* __rest
         if (REFLECT) yy = jp_reflect(yy, H);
         rowoff[pr] = (yy >= 0 && yy < H) ? (long)yy * W : -1;
     }
-    const long lane_off = (long)w8 * HW + x0 + l32;        // + 8*(r%4)*HW + rowoff[pr] + chunk*32*HW
+    const long lane_off = (long)w8 * HW + x0 + l32;        // + NHW*(r%(CS/NHW))*HW + rowoff[pr] + chunk*32*HW
     // halo columns: element e = t + 256*q < 64*PR: side = e & 1, rho' = e >> 1
     int xl = x0 - 1, xr = x0 + 32;
     if (REFLECT) { xl = jp_reflect(xl, W); xr = jp_reflect(xr, W); }
     const bool okl = xl >= 0, okr = xr < W;
 
-    constexpr int NHALO = HALO ? (2 * CS * PR + 255) / 256 : 0;
+    constexpr int NHALO = HALO ? (2 * CS * PR + NT - 1) / NT : 0;
     float rb[NROW], rh[NHALO > 0 ? NHALO : 1];
     // (Measured and rejected: spreading the next patch's loads one by one over the current chunk's k-steps instead of
     // issuing them as one burst behind the barrier -- 128 -> 83 TF.)
     auto gload_row = [&](const float* xc, int r) {
-        const int pr = r / (CS / 8);
+        const int pr = r / (CS / NHW);
         const long ro = rowoff[pr];
-        rb[r] = ro >= 0 ? xc[lane_off + (long)(8 * (r % (CS / 8))) * HW + ro] : 0.f;
+        rb[r] = ro >= 0 ? xc[lane_off + (long)(NHW * (r % (CS / NHW))) * HW + ro] : 0.f;
     };
     auto gload_halo = [&](const float* xc, int q) {
-        const int e = t + 256 * q;
+        const int e = t + NT * q;
         float v = 0.f;
         if (e < 2 * CS * PR) {
             const int side = e & 1, rp = e >> 1, pr = rp / CS, c = rp % CS;
@@ -111,12 +113,12 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9_kernel(const float* __rest
     auto lstore = [&]() {
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-            const int pr = r / (CS / 8), c = 8 * (r % (CS / 8)) + w8;
+            const int pr = r / (CS / NHW), c = NHW * (r % (CS / NHW)) + w8;
             patch[(c * PR + pr) * P9_PITCH + 1 + l32] = rb[r];
         }
 #pragma unroll
         for (int q = 0; q < NHALO; ++q) {
-            const int e = t + 256 * q;
+            const int e = t + NT * q;
             if (e < 2 * CS * PR) {
                 const int side = e & 1, rp = e >> 1, pr = rp / CS, c = rp % CS;
                 patch[(c * PR + pr) * P9_PITCH + (side ? 33 : 0)] = rh[q];
