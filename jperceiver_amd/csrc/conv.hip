@@ -1830,7 +1830,7 @@ inline bool p9_m256() {
 // (512->512 @32x32: 141 -> 92 TF), where it has them it is 2-4 % faster (256->256 @128x128: 141 -> 146 TF)
 inline int p9_bmt(int rows, int khw = 9, long ptiles = 0) {
     if (rows <= 64) return 64;
-    return (khw == 9 && p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256) ? 256 : 128;
+    return (p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256) ? 256 : 128;
 }
 inline long p9_ptiles(int N, int H, int W) { return (long)N * (H / 4) * (W / 32); }
 inline long dgrad_tap_floats(int Cin, int Cout, int KH) { return ((long)(KH * KH + 16) * Cin + 512 + 64) * ((Cout + 31) / 32 * 32); }
@@ -1838,16 +1838,16 @@ inline long p9_ws_floats(int rows, int red, int khw = 9) {
     const int bmt = rows <= 64 ? 64 : 128;          // the 256-row tiling of the same bank never needs more
     return ((long)jp_cdiv(red, 32) * khw * 4 + P9_QAHEAD + 1) * 8 * bmt * jp_cdiv(rows, bmt);
 }
-// The 1x1 variant (TAPS = 1) measured 103 / 106 TF forward / dgrad on 256->256 @256^2 against 105 / 108 TF of the generic
-// engine (a 1x1 layer has only K = Cin: the workgroup's prologue / epilogue dominate, not the operand staging): it is
-// kept as an opt-in (JP_P1=1), the default path for 1x1 stays the generic engine.
-inline bool p1_enabled() {
-    static const int on = [] { const char* e = getenv("JP_P1"); return e ? atoi(e) : 0; }();
-    return on != 0;
+// JP_P1: 1 = every eligible 1x1 layer, 0 = none, unset = only banks that get the 256-channel 8-wave tiles (there the
+// patch kernel wins: 256->256 @256x256 forward 101 -> 107 TF, dgrad 106 -> 113 TF; with 128-channel tiles it does not)
+inline int p1_mode() {
+    static const int m = [] { const char* e = getenv("JP_P1"); return e ? atoi(e) : 2; }();
+    return m;
 }
 inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {
     const int tr = rows <= 64 ? 8 : 4;
-    return p9_enabled() && (khw == 9 || p1_enabled()) && rows >= 32 && red >= 32 && red % (khw == 1 ? 64 : 32) == 0 && W % 32 == 0 && H % tr == 0 &&
+    const bool p1 = p1_mode() == 1 || (p1_mode() == 2 && p9_bmt(rows, 1, p9_ptiles(N, H, W)) == 256);
+    return p9_enabled() && (khw == 9 || p1) && rows >= 32 && red >= 32 && red % (khw == 1 ? 64 : 32) == 0 && W % 32 == 0 && H % tr == 0 &&
            (long)jp_cdiv(rows, p9_bmt(rows)) * N * (H / tr) * (W / 32) >= 192;
 }
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
@@ -1874,12 +1874,16 @@ void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, i
 // 1x1 stride-1 convolution / its dgrad through the same kernel (TAPS = 1, two channel chunks per stage)
 template <class E>
 void launch_p1(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st) {
-    const int NST = red / 64;
-    jp_prof_before(rows <= 64 ? p9_tag<1, 4, false, false, E, 1>() : p9_tag<2, 2, false, false, E, 1>(),
+    const int NST = jp_cdiv(red, 64);
+    const int bmt = p9_bmt(rows, 1, p9_ptiles(N, H, W));
+    jp_prof_before(bmt == 64 ? p9_tag<1, 4, false, false, E, 1>() : (bmt == 256 ? p9_tag<4, 2, false, false, E, 1>() : p9_tag<2, 2, false, false, E, 1>()),
                    2.0 * rows * (double)N * H * W * red, st);
-    if (rows <= 64) {
+    if (bmt == 64) {
         dim3 grid(N * (H / 8) * (W / 32), 1, 1);
         hipLaunchKernelGGL((jp_igemm_p9_kernel<1, 4, false, false, E, 1, 2>), grid, dim3(256), 0, st, wp, x, e, rows, red, NST, H, W, 0);
+    } else if (bmt == 256) {
+        dim3 grid(N * (H / 4) * (W / 32), rows / 256, 1);
+        hipLaunchKernelGGL((jp_igemm_p9_kernel<4, 2, false, false, E, 1, 2>), grid, dim3(512), 0, st, wp, x, e, rows, red, NST, H, W, 0);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
         hipLaunchKernelGGL((jp_igemm_p9_kernel<2, 2, false, false, E, 1, 2>), grid, dim3(256), 0, st, wp, x, e, rows, red, NST, H, W, 0);
@@ -2133,7 +2137,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         const bool use_p1 = KH == 1 && stride == 1 && pad == 0 && !((c0 && up0) || (c1 && up1) || (c2 && up2)) && c1 == 0 &&
                             c2 == 0 && p9_ok(Cout, Cin, N, H, W, 1);
         if (use_p1) {      // 1x1: weights stream in fragment order, two channel chunks of the pixel tile staged per barrier pair
-            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin, 1), Cout, Cin, 0, p9_bmt(Cout, 1), 1, 0, st);
+            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin, 1), Cout, Cin, 0, p9_bmt(Cout, 1, p9_ptiles(N, H, W)), 1, 0, st);
             launch_p1(ws, x0, e, Cout, Cin, N, H, W, st);
             JP_LAUNCH_CHECK();
         }
@@ -2306,7 +2310,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                     const int bn3 = Mm <= 64 ? 256 : 128;
                     if (KH == 1 && pad == 0 && tail == 0 && p9_ok(Cin, Cout, N, H, W, 1)) {
                         float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
-                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout, 1), Cout, Cin, 1, p9_bmt(Cin, 1), 1, 0, st);
+                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout, 1), Cout, Cin, 1, p9_bmt(Cin, 1, p9_ptiles(N, H, W)), 1, 0, st);
                         launch_p1(wfr, dy, e, Cin, Cout, N, H, W, st);
                     } else
                     if (KH == 3 && pad == 1 && (tail == 0 || Mm > 64) && p9_ok(Mm, Cout, N, H, W)) {

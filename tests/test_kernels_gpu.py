@@ -101,6 +101,8 @@ CONV_CASES = [
     (4, 128, 32, 64, 64, 3, 1, 1, 0, 0, False),     # W9 narrow variant (Cout <= 64: two K groups per workgroup), 2 channel tiles
     (4, 129, 64, 96, 64, 3, 1, 1, 1, 2, True),      # P9 dgrad on the 128-row tile of a 129-channel bank + its 1-row tail launch
     (4, 64, 64, 128, 256, 3, 1, 1, 1, 2, True),     # P9 forward, 256-channel 8-wave tiles (>= 256 workgroups), reflect
+    (4, 64, 64, 128, 256, 1, 1, 0, 0, 1, True),     # 1x1 through the patch kernel on 256-channel 8-wave tiles (default for such banks): forward
+    (4, 256, 64, 128, 128, 1, 1, 0, 0, 0, False),   # ... dgrad (256 rows), 4 stages
     (4, 256, 64, 128, 64, 3, 1, 1, 0, 0, False),    # P9 dgrad on 256-row 8-wave tiles, zero pad (no tap-major pack built)
     (2, 6, 64, 128, 64, 7, 2, 3, 0, 1, True),       # W7 stem wgrad, 6 input channels (10 column blocks, one K group)
     (3, 3, 96, 192, 64, 7, 2, 3, 0, 0, False),      # W7 stem wgrad, 3 input channels (5 column blocks x 2 K groups), 3 images
