@@ -1967,6 +1967,26 @@ static void launch_w7(const float* dy, const float* x, float* dw, float* ws, int
     hipLaunchKernelGGL((w7_reduce_kernel<CIN>), dim3(64 * NP / 64), dim3(1024), 0, st, ws, dw, p.slices);
 }
 
+// ---- W1 (igemm_w9.h): 1x1 stride-1 wgrad, single full-resolution source, 128-aligned input channels
+struct W1Plan { int splits, tps, ntiles; long need; };
+static inline bool w1_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W1Plan* p) {
+    static const bool on = [] { const char* e = getenv("JP_W1"); return !(e && e[0] == '0'); }();
+    if (!on || !w9_enabled() || KH != 1 || stride != 1 || pad != 0 || W % 32 || H % 4 || Cm < 128 || Cm % 128 || Cout < 192 ||
+        (long)N * Cout * H * W * 4 >= (1L << 31))
+        return false;
+    const int ntiles = N * (H / 4) * (W / 32);
+    const long out_tiles = (long)(Cm / 128) * jp_cdiv(Cout, 256), per = (long)Cout * Cm;
+    long sp = std::max<long>(1, std::min<long>(256 / std::max<long>(1, out_tiles), ntiles / 4));
+    sp = std::min<long>(sp, ws_floats / per);
+    if (sp < 1 || ntiles < 16) return false;
+    p->tps = (int)jp_cdiv(ntiles, sp);
+    p->splits = jp_cdiv(ntiles, p->tps);
+    p->ntiles = ntiles;
+    p->need = (long)p->splits * per;
+    return true;
+}
+static const char* w1_tag() { return "const char *w1_tag() [K = 1]"; }
+
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
               int up2, int H, int W) {
     Src3 s;
@@ -2545,6 +2565,22 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         return 0;
     };
     JP_CHECK_ARG(whole || single, "conv2d_wgrad: internal sub-range call must be single-source");
+    W1Plan w1;
+    if (single && ws && w1_plan(N, Cin, H, W, Cout, KH, stride, pad, ws_floats, &w1)) {
+        jp_prof_before(w1_tag(), 2.0 * Cout * (double)Cin * N * H * W, st);
+        hipLaunchKernelGGL(jp_wgrad_w1_kernel, dim3(Cin / 128, jp_cdiv(Cout, 256), w1.splits), dim3(512), 0, st, dy, x0, ws, Cout, Cin,
+                           Cin, H, W, w1.ntiles, w1.tps, (int)((long)N * Cout * H * W * 4));
+        jp_prof_after(st);
+        const long total = (long)Cout * Cin;
+        const int nblk = (int)((total / 4 + 63) / 64);
+        if (w1.splits >= 64 && nblk < 2048)
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<8>, dim3(nblk), dim3(512), 0, st, ws, dw, Cout, Cin, w1.splits, Cin, 1, dw_coff,
+                               dw_ctot);
+        else
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3(nblk), dim3(64), 0, st, ws, dw, Cout, Cin, w1.splits, Cin, 1, dw_coff,
+                               dw_ctot);
+        JP_LAUNCH_CHECK();
+    }
     W7Plan w7;
     if (single && whole && ws && w7_plan(N, Cin, H, W, Cout, KH, stride, pad, ws_floats, &w7)) {
         if (Cin == 3) launch_w7<3>(dy, x0, dw, ws, N, H, W, w7, st);
@@ -2753,13 +2789,15 @@ extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout
     const long npix = (long)N * OH * OW, cap = 32L << 20;
     W7Plan w7;
     if (w7_plan(N, Cin, H, W, Cout, KH, stride, pad, cap, &w7)) return w7.need;
+    W1Plan w1;
+    const long need1 = w1_plan(N, Cin, H, W, Cout, KH, stride, pad, cap, &w1) ? w1.need : 0;
     if (Cout % 8 != 0 || Cin < 16) return 0;
     const int Np = KH * KH * (Cin >= 64 ? Cin / 64 * 64 : Cin);
     const bool narrow = Cout <= 64 && Cin <= 64;
     const WgradPlan p = wgrad_plan(Cout, Np, (long)N * pad32(OH * OW), narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
     W9Plan w9;
     const long need9 = w9_plan(N, Cin / 64 * 64, H, W, Cout, KH, stride, pad, cap, &w9) ? w9.need : 0;
-    return std::max(p.use_ws ? p.ws_need : 0, need9);
+    return std::max(std::max(p.use_ws ? p.ws_need : 0, need9), need1);
 }
 
 // ---- weight-pack recording / replay (see do_pack).  `host_jobs`: caller-owned HOST buffer of max_jobs 64-byte records.

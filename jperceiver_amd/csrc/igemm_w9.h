@@ -218,3 +218,142 @@ __global__ __launch_bounds__(64 * KG * MW * 3 * NB, (KG * MW * 3 * NB) / 4) void
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "W1": the same scheme for 1x1 stride-1 weight gradients (dW[co][ci] = sum_p dY[co][p] * X[ci][p]; the CRP / reduce
+// layers).  No taps, so a staged input value is only reused across output channels: the workgroup therefore spans 256
+// output channels (4 wave rows) x 128 input channels (2 wave columns of 2 blocks): 8 waves, 2x2 accumulators each, a
+// 4x32-pixel tile of the 128 input channels transposed to [pixel][channel] in LDS (no halo), dY fragments from global.
+// Output: ws[split][m][ci] (wgrad_reduce4_kernel with one "tap").  Preconditions: Cout % 256 == 0 is NOT required (rows
+// are clamped / masked), Cm % 128 == 0, W % 32 == 0, H % 4 == 0.
+__global__ __launch_bounds__(512, 2) void jp_wgrad_w1_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
+                                                            int ntiles, int tiles_per_split, int dy_bytes) {
+    constexpr int NT = 512, TR = 4, NC = 128, LDB = NC + 1, QT = TR * 4;
+    constexpr int NROWS = NC * TR * 32 / NT;                          // 32 staged values per thread and tile
+    __shared__ float patch[TR * 32 * LDB];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, cbw = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int mt, nt, zs;
+    {   // every XCD owns whole K slices, see jp_wgrad_w9_kernel
+        const int gx = gridDim.x, gy = gridDim.y, T = gx * gy, SG = gridDim.z & ~7;
+        const int L3 = blockIdx.x + blockIdx.y * gx + blockIdx.z * T;
+        int tile;
+        if (L3 < SG * T) {
+            const int idx = L3 >> 3;
+            zs = (idx / T) * 8 + (L3 & 7);
+            tile = idx % T;
+        } else {
+            const int r = L3 - SG * T;
+            zs = SG + r / T;
+            tile = r % T;
+        }
+        mt = tile % gy;
+        nt = tile / gy;
+    }
+    const int m0 = mt * 256, c0 = nt * NC;
+    const int T0 = zs * tiles_per_split, T1 = min(ntiles, T0 + tiles_per_split);
+    const int tiles_x = W / 32, tiles_img = tiles_x * (H / TR);
+    const long HW = (long)H * W;
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    int arow[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) arow[a] = (min(m0 + wr * 64 + a * 32 + l31, Cout - 1) * (int)HW + 4 * lhi) * 4;
+    auto tile_org = [&](int T, int& img, int& y0, int& x0) {
+        const int Tc = min(T, ntiles - 1);
+        img = Tc / tiles_img;
+        const int r = Tc - img * tiles_img;
+        y0 = (r / tiles_x) * TR;
+        x0 = (r % tiles_x) * 32;
+    };
+    float ra[2][2][4];
+    auto aload = [&](int slot, int tbase, int qd) {
+        const int o = __builtin_amdgcn_readfirstlane((tbase + (qd / 4) * W + 8 * (qd % 4)) * 4);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const jp_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(drs, arow[a], o, 0);
+            const jp_f32x4 v = __builtin_bit_cast(jp_f32x4, u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[slot][a][j] = v[j];
+        }
+    };
+    // staging: half-wave hw takes tile row hw/4 and channels (hw%4) + 4*r, lanes along the 32 columns
+    const int hw = t >> 5, l32 = t & 31;
+    const int prw = hw >> 2, hsub = hw & 3;
+    float rb[NROWS];
+    auto gload = [&](int T) {
+        int img, y0, x0;
+        tile_org(T, img, y0, x0);
+        const float* xr0 = x + ((long)img * Cx + c0 + hsub) * HW + (long)(y0 + prw) * W + x0 + l32;
+#pragma unroll
+        for (int r = 0; r < NROWS; ++r) rb[r] = xr0[(long)(4 * r) * HW];
+    };
+    auto lstore = [&]() {
+        float* pd = patch + (prw * 32 + l32) * LDB + hsub;
+#pragma unroll
+        for (int r = 0; r < NROWS; ++r) pd[4 * r] = rb[r];
+    };
+    jp_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
+    const float* bp = patch + (4 * lhi) * LDB + cbw * 64 + l31;
+    if (T0 < T1) {
+        int img, y0, x0;
+        tile_org(T0, img, y0, x0);
+        int tb = (img * Cout) * (int)HW + y0 * W + x0;
+        aload(0, tb, 0);
+        gload(T0);
+        for (int T = T0; T < T1; ++T) {
+            lstore();
+            __syncthreads();
+            gload(T + 1);
+            tile_org(T + 1, img, y0, x0);
+            const int tbn = (img * Cout) * (int)HW + y0 * W + x0;
+            auto boff = [&](int s) -> int {
+                const int qd = s / 4, j = s % 4;
+                return ((qd / 4) * 32 + 8 * (qd % 4) + j) * LDB;
+            };
+            float b0 = bp[boff(0)], b1 = bp[boff(0) + 32];
+#pragma unroll
+            for (int s = 0; s < 4 * QT; ++s) {
+                const int qd = s / 4, j = s % 4;
+                if (j == 0) {
+                    const int qa = qd + 1;
+                    if (qa < QT) aload(qa % 2, tb, qa);
+                    else aload(qa % 2, tbn, qa - QT);
+                }
+                const int sn = s + 1 < 4 * QT ? s + 1 : s;
+                const float nb0 = bp[boff(sn)], nb1 = bp[boff(sn) + 32];
+                const float a0 = ra[qd % 2][0][j], a1 = ra[qd % 2][1][j];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                b0 = nb0; b1 = nb1;
+            }
+            tb = tbn;
+            __syncthreads();
+        }
+    }
+    float* wz = ws + (long)zs * Cout * Cm;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long n = c0 + cbw * 64 + j * 32 + l31;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < Cout) wz[(long)m * Cm + n] = acc[a][j][r];
+            }
+    }
+}

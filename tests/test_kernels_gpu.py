@@ -103,6 +103,8 @@ CONV_CASES = [
     (4, 64, 64, 128, 256, 3, 1, 1, 1, 2, True),     # P9 forward, 256-channel 8-wave tiles (>= 256 workgroups), reflect
     (4, 64, 64, 128, 256, 1, 1, 0, 0, 1, True),     # 1x1 through the patch kernel on 256-channel 8-wave tiles (default for such banks): forward
     (4, 256, 64, 128, 128, 1, 1, 0, 0, 0, False),   # ... dgrad (256 rows), 4 stages
+    (2, 128, 32, 64, 256, 1, 1, 0, 0, 0, True),     # W1 patch wgrad (1x1): one 256 x 128 output tile, K split over 32 pixel tiles
+    (2, 256, 32, 32, 200, 1, 1, 0, 0, 1, True),     # W1: two input-channel tiles, 200 output channels (clamped / masked rows)
     (4, 256, 64, 128, 64, 3, 1, 1, 0, 0, False),    # P9 dgrad on 256-row 8-wave tiles, zero pad (no tap-major pack built)
     (2, 6, 64, 128, 64, 7, 2, 3, 0, 1, True),       # W7 stem wgrad, 6 input channels (10 column blocks, one K group)
     (3, 3, 96, 192, 64, 7, 2, 3, 0, 0, False),      # W7 stem wgrad, 3 input channels (5 column blocks x 2 K groups), 3 images
