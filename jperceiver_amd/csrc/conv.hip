@@ -1976,7 +1976,8 @@ static inline bool w1_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
         return false;
     const int ntiles = N * (H / 4) * (W / 32);
     const long out_tiles = (long)(Cm / 128) * jp_cdiv(Cout, 256), per = (long)Cout * Cm;
-    long sp = std::max<long>(1, std::min<long>(256 / std::max<long>(1, out_tiles), ntiles / 4));
+    static const long wgs = [] { const char* e = getenv("JP_W1_WGS"); return e ? atol(e) : 256L; }();
+    long sp = std::max<long>(1, std::min<long>(wgs / std::max<long>(1, out_tiles), ntiles / 4));
     sp = std::min<long>(sp, ws_floats / per);
     if (sp < 1 || ntiles < 16) return false;
     p->tps = (int)jp_cdiv(ntiles, sp);
