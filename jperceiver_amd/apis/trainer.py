@@ -209,12 +209,17 @@ class Runner(object):
     """The slice of mmcv.Runner the hot loop needs: model, batch_processor, optimizer, outputs, one iteration, the
     step-policy learning-rate hook, and checkpoints in mmcv's layout (save / load / resume)."""
 
-    def __init__(self, model, batch_processor, optimizer, optimizer_hook, lr_config=None, work_dir=None):
+    def __init__(self, model, batch_processor, optimizer, optimizer_hook, lr_config=None, work_dir=None,
+                 checkpoint_config=None):
+        """`checkpoint_config` = the configs' `dict(interval=1)` (mmcv CheckpointHook): `train_epoch` then saves from its
+        after-train-epoch point, i.e. BEFORE the epoch counter is incremented, exactly where mmcv's hook runs."""
         self.model, self.batch_processor, self.optimizer, self.hook = model, batch_processor, optimizer, optimizer_hook
         self.outputs = None
         self.iter = 0
         self.epoch = 0
         self.work_dir = work_dir
+        self.checkpoint_config = dict(checkpoint_config) if checkpoint_config else None
+        self.after_train_epoch_hooks = []          # callables(runner), run before the epoch counter moves (mmcv order)
         self.lr_hook = StepLrUpdaterHook(**lr_config) if lr_config else None
         if self.lr_hook is not None:
             self.lr_hook.before_run(self)
@@ -235,15 +240,29 @@ class Runner(object):
         return self.outputs
 
     def train_epoch(self, data_loader):
-        """mmcv.Runner.train: before_train_epoch hooks, one pass over the loader, epoch += 1."""
+        """mmcv.Runner.train: before_train_epoch hooks, one pass over the loader, after_train_epoch hooks (the checkpoint
+        hook among them), THEN epoch += 1 -- so the file written after the first epoch is epoch_1.pth with meta.epoch = 1,
+        and `resume()` continues with epoch 1 (second epoch), the step-LR schedule and the samplers' set_epoch in step with
+        the reference."""
         if self.lr_hook is not None:
             self.lr_hook.before_train_epoch(self)
+        if hasattr(getattr(data_loader, "sampler", None), "set_epoch"):
+            data_loader.sampler.set_epoch(self.epoch)
         for batch in data_loader:
             self.train_iter(batch)
+        for h in self.after_train_epoch_hooks:
+            h(self)
+        cc = self.checkpoint_config
+        if cc is not None and (self.epoch + 1) % int(cc.get("interval", 1)) == 0:
+            self.save_checkpoint(cc.get("out_dir"), save_optimizer=cc.get("save_optimizer", True))
         self.epoch += 1
 
     # ---- checkpoints (mmcv.Runner.save_checkpoint / load_checkpoint / resume)
     def save_checkpoint(self, out_dir=None, filename_tmpl="epoch_{}.pth", save_optimizer=True, meta=None):
+        """mmcv.Runner.save_checkpoint: names the file and stamps meta.epoch with `self.epoch + 1`, because mmcv calls it
+        from the after-train-epoch point of epoch `self.epoch`, before the counter moves.  Call it there too
+        (`checkpoint_config=` / `after_train_epoch_hooks`); a manual call AFTER `train_epoch()` returned would label the file
+        one epoch ahead, which `resume()` would then take at face value."""
         from .checkpoint import save_checkpoint
         import os
         meta = dict(meta or {}, epoch=self.epoch + 1, iter=self.iter)

@@ -43,7 +43,10 @@ def _world():
 
 
 def _bucket_floats(bucket_size_mb):
-    return int((bucket_size_mb if bucket_size_mb and bucket_size_mb > 0 else 64) * 1024 * 1024 // 4)
+    """bucket length in floats, a multiple of 64 (256 B): every bucket start stays aligned for the 16-byte norm kernel
+    whatever (fractional) bucket_size_mb the config carries."""
+    n = int((bucket_size_mb if bucket_size_mb and bucket_size_mb > 0 else 64) * 1024 * 1024 // 4)
+    return max(64, (n + 63) // 64 * 64)
 
 
 class _Exchange:
@@ -94,10 +97,14 @@ def allreduce_grads(model, coalesce=True, bucket_size_mb=-1, average_in_place=Tr
 
 
 class DistOptimizerHook(object):
-    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1):
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, force_exchange=False):
+        """`force_exchange` (not a reference option): run the bucketed all-reduce even in a single-rank process group, so
+        that the RCCL path -- communicator stream, async work handles, stream waits -- can be exercised on one GPU
+        (tests/test_distributed_gpu.py::test_rccl_single_rank_exchange)."""
         self.grad_clip = grad_clip
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
+        self.force_exchange = force_exchange
 
     def after_train_iter(self, runner):
         """zero_grad -> backward (+ overlapped all-reduce) -> global norm -> clip + Adam (dist_utils.py:54-60)."""
@@ -107,7 +114,7 @@ class DistOptimizerHook(object):
         if isinstance(opt, FlatAdam):
             max_norm = self.grad_clip.get("max_norm") if self.grad_clip else None
             ex = None
-            if world > 1:
+            if world > 1 or (self.force_exchange and dist.is_available() and dist.is_initialized()):
                 ex = _Exchange(opt.arena, self.bucket_size_mb)
                 prev = ops.set_grad_ready_hook(ex.launch)
                 try:

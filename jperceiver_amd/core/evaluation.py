@@ -58,6 +58,12 @@ def _dev(t):
 
 def _errors_from_sums(s):
     n = s[7]
+    if n == 0:
+        # no valid pixel (e.g. no LiDAR return inside the Garg crop): the reference's numpy path yields NaNs with a
+        # RuntimeWarning (mean of an empty slice, pixel_error.py:27-40) and the evaluation carries on
+        import warnings
+        warnings.warn("depth metrics over an empty set of valid pixels: returning NaN", RuntimeWarning)
+        return (float("nan"),) * 7
     return (s[5] / n, s[6] / n, math.sqrt(s[3] / n), math.sqrt(s[4] / n), s[0] / n, s[1] / n, s[2] / n)
 
 
@@ -160,5 +166,6 @@ def eval_depth(disp, gt_depth, stereo_scale=False, min_depth=0.1, max_depth=100,
     s = sums.cpu().tolist()
     mg, mp = med_g.cpu().tolist(), med_p.cpu().tolist()
     abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 = _errors_from_sums(s)
-    return dict(abs_rel=abs_rel, sq_rel=sq_rel, rmse=rmse, rmse_log=rmse_log, a1=a1, a2=a2, a3=a3, scale=mg[1] / mp[1],
+    scale = mg[1] / mp[1] if (s[7] > 0 and mp[1] != 0) else float("nan")
+    return dict(abs_rel=abs_rel, sq_rel=sq_rel, rmse=rmse, rmse_log=rmse_log, a1=a1, a2=a2, a3=a3, scale=scale,
                 n_valid=int(s[7]))

@@ -5,9 +5,13 @@ are uploaded once (pinned, asynchronous — datasets/loader.py) and resized / co
   resize          transforms.Resize((H, W), Image.ANTIALIAS): Pillow's 8-bit Lanczos resampler, bit-exact (the
                   fixed-point coefficient tables are built here exactly like libImaging/Resample.c builds them)
   to_tensor       HWC uint8 -> CHW float32 / 255
-  ColorJitter     brightness / contrast / saturation (0.8, 1.2), hue (-0.1, 0.1), random order; ONE parameter draw per
-                  item shared by all its frames (mono_dataset.py:137-141).  Applied in torchvision's float-tensor
-                  arithmetic (the reference applies it to the 8-bit PIL image: values differ by <= ~1/255 rounding)
+  ColorJitter     brightness / contrast / saturation (0.8, 1.2), hue (-0.1, 0.1), random order.  Decided PER ITEM
+                  (`do_color_aug = random.random() > 0.5`, mono_dataset.py:202); the parameters are drawn PER FRAME:
+                  the reference hands `preprocess` a `transforms.ColorJitter` object (its `get_params` line is commented
+                  out, mono_dataset.py:338-339) and such an object re-draws order + factors on every call, i.e. for
+                  every frame of the item (mono_dataset.py:153-156).  `jitter="per_item"` gives what the docstring there
+                  intends (one draw shared by an item's frames).  Applied in torchvision's float-tensor arithmetic (the
+                  reference applies it to the 8-bit PIL image: values differ by <= ~1/255 rounding)
   process_topview luma, binarise, NEAREST resize to H/4
 """
 from __future__ import annotations
@@ -131,23 +135,43 @@ class DevicePreprocessor:
         call("jp_topview_u8", label_u8.contiguous(), out, N, h, w, C, size, int(both))
         return out
 
-    def __call__(self, raw: dict, frame_ids, full_hw, do_color_aug=None, generator=None):
+    def __call__(self, raw: dict, frame_ids, full_hw, do_color_aug=None, generator=None, jitter="per_frame"):
         """raw: {("color", f, -1): (N, h, w, 3) uint8, ("bothS"|"bothD"|"both_dynamic", 0, 0): uint8 labels, calibration
-        tensors ...} already on the device -> the input dict Baseline.forward expects."""
+        tensors ...} already on the device -> the input dict Baseline.forward expects.
+        do_color_aug: None -> one coin per ITEM (mono_dataset.py:202); a bool -> every item; a sequence -> per item.
+        jitter: "per_frame" (the reference's actual behaviour: every frame of an augmented item gets its own draw) or
+        "per_item" (one draw shared by the item's frames).  Draw order (generator): the N coins, then per item, per frame."""
+        if jitter not in ("per_frame", "per_item"):
+            raise ValueError(f"jitter={jitter!r}")
         out = {}
         FH, FW = full_hw
+        N = raw[("color", frame_ids[0], -1)].shape[0]
         if do_color_aug is None:
-            do_color_aug = float(torch.rand(1, generator=generator)) > 0.5
-        params = ColorJitterParams(generator=generator) if do_color_aug else None
+            coins = (torch.rand(N, generator=generator) > 0.5).tolist()
+        elif isinstance(do_color_aug, (bool, int)):
+            coins = [bool(do_color_aug)] * N
+        else:
+            coins = [bool(c) for c in do_color_aug]
+            if len(coins) != N:
+                raise ValueError(f"do_color_aug has {len(coins)} entries for {N} items")
+        params = {}                      # (item, frame) -> ColorJitterParams
+        for i, c in enumerate(coins):
+            if not c:
+                continue
+            shared = ColorJitterParams(generator=generator) if jitter == "per_item" else None
+            for f in frame_ids:
+                params[(i, f)] = shared if shared is not None else ColorJitterParams(generator=generator)
+        self.last_jitter = params        # for loggers / tests
         for f in frame_ids:
             full, full8 = self.resize_u8(raw[("color", f, -1)], FH, FW, want_u8=True)     # resize_full, then resize from it
             if f == 0:
                 out[("color", 0, -1)] = full
             img = self.resize_u8(full8, self.h, self.w)
             out[("color", f, 0)] = img
-            aug = img.clone() if params is not None else img
-            if params is not None:
-                self.color_jitter_(aug, params)
+            aug = img.clone() if any(coins) else img
+            for i, c in enumerate(coins):
+                if c:
+                    self.color_jitter_(aug[i:i + 1], params[(i, f)])
             out[("color_aug", f, 0)] = aug
         for k, v in raw.items():
             if k[0] in ("bothS", "bothD"):

@@ -1,122 +1,132 @@
-"""Samplers with the reference's semantics (mono/datasets/loader/sampler.py): `DistributedGroupSampler` (:82-163, the one
-`build_dataloader(dist=True, shuffle=True)` uses), `DistributedSampler` (:15-38) and `GroupSampler` (:41-79).
-Pure host logic on torch / numpy generators: given the same epoch they emit exactly the reference's index sequence, so
-a run here visits the data in the same order as the reference would (tests/golden/sampler.npz holds sequences produced
-by the reference classes themselves).  Each rank of the data-parallel job takes a contiguous block of whole per-GPU
-batches of an epoch-seeded permutation; groups (`dataset.flag`) never mix inside a batch."""
-from __future__ import annotations
+"""Index samplers that visit the data in the reference's order (mono/datasets/loader/sampler.py: `DistributedSampler`
+:15-38, `GroupSampler` :41-79, `DistributedGroupSampler` :82-163 -- the one `build_dataloader(dist=True)` uses).
 
-import math
+Own structure: every sampler is "a plan of whole per-GPU batches" built from three array helpers --
+
+    _groups(flag)            members of each non-empty group (`dataset.flag`), ascending group id, as index arrays
+    _cycle_to(idx, n)        idx extended cyclically with its own head to length n (the reference's padding)
+    _reorder_batches(...)    a flat plan cut into batches of `b` and emitted in a given batch order
+
+-- and the only thing taken over from the reference is what index-exact parity forces: which random generator is asked
+for which permutation, in which order (tests/golden/sampler.npz holds 78 sequences emitted by the reference's own
+classes).  Ranks of a data-parallel job own a contiguous run of whole batches of the epoch plan; a batch never mixes
+groups."""
+from __future__ import annotations
 
 import numpy as np
 import torch
 from torch.utils.data import Sampler
 
 
-def _dist_info(num_replicas, rank):
+def _groups(flag) -> list:
+    flag = np.asarray(flag, dtype=np.int64)
+    by_group = np.argsort(flag, kind="stable")                       # members of group 0, then 1, ... each ascending
+    counts = np.bincount(flag)
+    return [m for m in np.split(by_group, np.cumsum(counts)[:-1]) if len(m)]
+
+
+def _cycle_to(idx: np.ndarray, n: int) -> np.ndarray:
+    return np.resize(idx, n) if n != len(idx) else idx
+
+
+def _ceil_to(n: int, multiple: int) -> int:
+    return -(-n // multiple) * multiple
+
+
+def _reorder_batches(plan: np.ndarray, b: int, batch_order) -> np.ndarray:
+    return plan.reshape(-1, b)[np.asarray(batch_order, dtype=np.int64)].reshape(-1)
+
+
+def _world(num_replicas, rank):
     import torch.distributed as dist
-    if num_replicas is None:
-        num_replicas = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-    if rank is None:
-        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    return num_replicas, rank
+    live = dist.is_available() and dist.is_initialized()
+    return (num_replicas if num_replicas is not None else (dist.get_world_size() if live else 1),
+            rank if rank is not None else (dist.get_rank() if live else 0))
 
 
-class DistributedSampler(Sampler):
-    """sampler.py:15-38: epoch-seeded permutation (or arange), padded to a multiple of the world size, strided by rank."""
+class _EpochSampler(Sampler):
+    """Common shell: a per-epoch plan (`_plan() -> int64 array`) of `num_samples` indices, `set_epoch`."""
+    epoch = 0
+    num_samples = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        plan = self._plan()
+        if len(plan) != self.num_samples:
+            raise RuntimeError(f"{type(self).__name__}: planned {len(plan)} indices, expected {self.num_samples}")
+        return iter(plan.tolist())
+
+    def _epoch_generator(self):
+        g = torch.Generator()
+        g.manual_seed(self.epoch)          # identical on every rank: the ranks cut ONE shared plan
+        return g
+
+
+class DistributedSampler(_EpochSampler):
+    """Whole data set, epoch-seeded permutation (or identity), padded cyclically to a multiple of the world size, rank r
+    takes elements r, r + world, ..."""
 
     def __init__(self, dataset, num_replicas=None, rank=None, shuffle=True):
-        self.dataset = dataset
-        self.num_replicas, self.rank = _dist_info(num_replicas, rank)
-        self.epoch, self.shuffle = 0, shuffle
-        self.num_samples = int(math.ceil(len(dataset) * 1.0 / self.num_replicas))
-        self.total_size = self.num_samples * self.num_replicas
+        self.dataset, self.shuffle = dataset, shuffle
+        self.num_replicas, self.rank = _world(num_replicas, rank)
+        self.total_size = _ceil_to(len(dataset), self.num_replicas)
+        self.num_samples = self.total_size // self.num_replicas
 
-    def __iter__(self):
-        if self.shuffle:
-            g = torch.Generator()
-            g.manual_seed(self.epoch)
-            indices = torch.randperm(len(self.dataset), generator=g).tolist()
-        else:
-            indices = torch.arange(len(self.dataset)).tolist()
-        indices += indices[:(self.total_size - len(indices))]
-        indices = indices[self.rank:self.total_size:self.num_replicas]
-        assert len(indices) == self.num_samples
-        return iter(indices)
-
-    def __len__(self):
-        return self.num_samples
-
-    def set_epoch(self, epoch):
-        self.epoch = epoch
+    def _plan(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self._epoch_generator()).numpy() if self.shuffle else np.arange(n)
+        return _cycle_to(order, self.total_size)[self.rank::self.num_replicas]
 
 
-class GroupSampler(Sampler):
-    """sampler.py:41-79 (numpy global RNG, like the reference)."""
+class GroupSampler(_EpochSampler):
+    """Single process: each group shuffled (numpy's global generator, as the reference), padded to whole batches; then the
+    batches of all groups are shuffled among each other."""
 
     def __init__(self, dataset, samples_per_gpu=1):
-        assert hasattr(dataset, "flag")
+        if not hasattr(dataset, "flag"):
+            raise AttributeError("GroupSampler needs dataset.flag")
         self.dataset, self.samples_per_gpu = dataset, samples_per_gpu
-        self.flag = dataset.flag.astype(np.int64)
+        self.flag = np.asarray(dataset.flag).astype(np.int64)
         self.group_sizes = np.bincount(self.flag)
-        self.num_samples = sum(int(np.ceil(s / samples_per_gpu)) * samples_per_gpu for s in self.group_sizes)
+        self.num_samples = int(sum(_ceil_to(int(s), samples_per_gpu) for s in self.group_sizes))
 
-    def __iter__(self):
-        indices = []
-        for i, size in enumerate(self.group_sizes):
-            if size == 0:
-                continue
-            indice = np.where(self.flag == i)[0]
-            np.random.shuffle(indice)
-            num_extra = int(np.ceil(size / self.samples_per_gpu)) * self.samples_per_gpu - len(indice)
-            indices.append(np.concatenate([indice, indice[:num_extra]]))
-        indices = np.concatenate(indices)
-        indices = np.concatenate([indices[i * self.samples_per_gpu:(i + 1) * self.samples_per_gpu]
-                                  for i in np.random.permutation(range(len(indices) // self.samples_per_gpu))])
-        assert len(indices) == self.num_samples
-        return iter(torch.from_numpy(indices).long())
-
-    def __len__(self):
-        return self.num_samples
+    def _plan(self):
+        b = self.samples_per_gpu
+        parts = []
+        for members in _groups(self.flag):
+            members = members.copy()
+            np.random.shuffle(members)
+            parts.append(_cycle_to(members, _ceil_to(len(members), b)))
+        plan = np.concatenate(parts)
+        return _reorder_batches(plan, b, np.random.permutation(len(plan) // b))
 
 
-class DistributedGroupSampler(Sampler):
-    """sampler.py:82-163."""
+class DistributedGroupSampler(_EpochSampler):
+    """Data parallel: each group permuted with the epoch generator and padded to whole batches for EVERY rank, all batches
+    shuffled with the same generator, rank r owns batches [r * k, (r + 1) * k)."""
 
     def __init__(self, dataset, samples_per_gpu=1, num_replicas=None, rank=None):
-        self.num_replicas, self.rank = _dist_info(num_replicas, rank)
-        self.dataset, self.samples_per_gpu, self.epoch = dataset, samples_per_gpu, 0
-        assert hasattr(dataset, "flag")
-        self.flag = dataset.flag
+        if not hasattr(dataset, "flag"):
+            raise AttributeError("DistributedGroupSampler needs dataset.flag")
+        self.dataset, self.samples_per_gpu = dataset, samples_per_gpu
+        self.num_replicas, self.rank = _world(num_replicas, rank)
+        self.flag = np.asarray(dataset.flag)
         self.group_sizes = np.bincount(self.flag)
-        self.num_samples = 0
-        for size in self.group_sizes:
-            self.num_samples += int(math.ceil(size * 1.0 / samples_per_gpu / self.num_replicas)) * samples_per_gpu
-        self.total_size = self.num_samples * self.num_replicas
+        per_round = samples_per_gpu * self.num_replicas              # one batch on every rank
+        self.total_size = int(sum(_ceil_to(int(s), per_round) for s in self.group_sizes))
+        self.num_samples = self.total_size // self.num_replicas
 
-    def __iter__(self):
-        g = torch.Generator()
-        g.manual_seed(self.epoch)                 # deterministic shuffle per epoch, identical on every rank
-        indices = []
-        for i, size in enumerate(self.group_sizes):
-            if size > 0:
-                indice = np.where(self.flag == i)[0]
-                indice = indice[list(torch.randperm(int(size), generator=g))].tolist()
-                extra = int(math.ceil(size * 1.0 / self.samples_per_gpu / self.num_replicas)) * self.samples_per_gpu * \
-                    self.num_replicas - len(indice)
-                indice += indice[:extra]
-                indices += indice
-        assert len(indices) == self.total_size
-        spg = self.samples_per_gpu
-        indices = [indices[j] for i in list(torch.randperm(len(indices) // spg, generator=g))
-                   for j in range(i * spg, (i + 1) * spg)]
-        offset = self.num_samples * self.rank       # this rank's contiguous block of whole batches
-        indices = indices[offset:offset + self.num_samples]
-        assert len(indices) == self.num_samples
-        return iter(indices)
-
-    def __len__(self):
-        return self.num_samples
-
-    def set_epoch(self, epoch):
-        self.epoch = epoch
+    def _plan(self):
+        g = self._epoch_generator()
+        b, per_round = self.samples_per_gpu, self.samples_per_gpu * self.num_replicas
+        parts = [_cycle_to(m[torch.randperm(len(m), generator=g).numpy()], _ceil_to(len(m), per_round))
+                 for m in _groups(self.flag)]
+        plan = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        plan = _reorder_batches(plan, b, torch.randperm(len(plan) // b, generator=g).numpy())
+        lo = self.num_samples * self.rank
+        return plan[lo:lo + self.num_samples]

@@ -161,7 +161,7 @@ def weights_changed():
 
 
 class _PackEntry:
-    __slots__ = ("ws", "jobs", "ptr", "epoch", "param")
+    __slots__ = ("ws", "jobs", "ptr", "epoch", "param", "ver")
 
 
 class PackRegistry:
@@ -188,7 +188,7 @@ class PackRegistry:
         ptr = w.t.data_ptr()
         if e is None or e.ptr != ptr or e.ws.numel() != nfloats:
             e = _PackEntry()
-            e.ws, e.jobs, e.ptr, e.epoch, e.param = _new((nfloats,), w.t), None, ptr, -1, w.p
+            e.ws, e.jobs, e.ptr, e.epoch, e.param, e.ver = _new((nfloats,), w.t), None, ptr, -1, w.p, -1
             self.entries[key] = e
             self.table = None
         return e
@@ -221,7 +221,7 @@ class PackRegistry:
         dev, n, total, live = self.table
         call("jp_pack_replay", dev, n, total)
         for e in live:
-            e.epoch = ep
+            e.epoch, e.ver = ep, e.param._version
 
 
 def _conv_call(name, w: Var, which: str, sig, nfloats: int, args_before_ws, args_after_ws):
@@ -246,11 +246,13 @@ def _conv_call(name, w: Var, which: str, sig, nfloats: int, args_before_ws, args
             n = int(L.fn["jp_pack_record_end"]())
         if n > len(buf):
             raise RuntimeError(f"{name}: {n} weight packs in one call (record buffer too small)")
-        e.jobs, e.epoch = buf[:n].copy(), _EPOCH[0]
+        e.jobs, e.epoch, e.ver = buf[:n].copy(), _EPOCH[0], w.p._version
         reg.table = None
-    elif e.epoch != _EPOCH[0]:    # weights changed and nobody refreshed the registry: re-pack this layer alone
+    elif e.epoch != _EPOCH[0] or e.ver != w.p._version:
+        # weights changed and nobody refreshed the registry (a sub-network used standalone -- inference.pose_between,
+        # a module's own forward -- after an in-place load_state_dict / .copy_ on its parameters): re-pack this layer alone
         call(name, *args_before_ws, e.ws, 0, *args_after_ws)
-        e.epoch = _EPOCH[0]
+        e.epoch, e.ver = _EPOCH[0], w.p._version
     else:
         call(name, *args_before_ws, e.ws, 1, *args_after_ws)
 

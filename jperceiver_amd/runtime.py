@@ -83,7 +83,7 @@ class FlatArena:
         self.exp_avg_sq = None
         self.normsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self._nblk = int(_jplib().fn["jp_sumsq_blocks"]())
-        self._partials = torch.zeros(64 * self._nblk, device=dev, dtype=torch.float64)   # up to 64 buckets per step
+        self._partials = torch.zeros(64 * self._nblk, device=dev, dtype=torch.float64)   # grown on demand (small buckets)
         self._n_partials = 0
         self.step_count = 0
 
@@ -95,8 +95,11 @@ class FlatArena:
     # ---- global norm, two-phase so that buckets can be folded in as their all-reduce lands
     def add_norm_partial(self, off: int, n: int):
         """Stage 1 over grads[off:off+n] (a reduced bucket): block partials into the next slot."""
-        if self._n_partials >= 64:
-            raise RuntimeError("more than 64 gradient buckets per step")
+        if (self._n_partials + 1) * self._nblk > self._partials.numel():
+            # any bucket_size_mb is legal (the reference accepts any): grow the partial-sum table, keeping what landed
+            grown = torch.zeros(2 * self._partials.numel(), device=self._partials.device, dtype=torch.float64)
+            grown[:self._partials.numel()].copy_(self._partials)
+            self._partials = grown
         slot = self._partials[self._n_partials * self._nblk:(self._n_partials + 1) * self._nblk]
         call("jp_grad_sumsq_partials", self.grads[off:off + n], slot, n)
         self._n_partials += 1

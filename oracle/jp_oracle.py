@@ -752,6 +752,13 @@ def forward(P, Bf, opt, inputs, training=True, drop_masks=None, automask_noise=N
     cx = Ctx(P, Bf, training)
     feats = resnet18_features(cx, "DepthEncoder.encoder.", inputs[("color_aug", 0, 0)])
     outputs = depth_decoder(cx, feats, drop_masks)
+    if not opt.get("layout_branch", True):
+        # NOT a reference option: the shape-agnostic sub-path only (depth + pose + CGT warp + photometric / smoothness /
+        # scale losses, net.py:139-211,630-642,690-702,758-786) for non-square inputs such as BASELINE.json's 1024x320,
+        # where the reference's CVP / CCT (square maps only) cannot run.  Pinned by tests/golden/subpath_320x1024_b2.npz.
+        assert training
+        outputs.update(predict_poses(cx, opt, inputs))
+        return outputs, compute_losses(opt, inputs, outputs, automask_noise, scale_label, force)
     o, enc = predict_layout(cx, inputs, feats, "", force=force)
     outputs.update(o)
     if training:
@@ -770,6 +777,8 @@ def compute_losses(opt, inputs, outputs, automask_noise=None, scale_label=None, 
     ty = opt["type"]
     do_S = ty in ("static_raw", "static", "Argo_static", "Argo_both", "static_eigen")
     do_B = ty in ("dynamic", "Argo_dynamic", "Argo_both")
+    if not opt.get("layout_branch", True):
+        do_S = do_B = False
     if scale_label is None:
         scale_label = make_scale_label(opt, inputs)
     if do_S:

@@ -73,3 +73,51 @@ def run_oracle_f64(meta, force, label):
     finally:
         torch.set_default_dtype(torch.float32)
     return {n: p.grad for n, p in P.items() if p.grad is not None}
+
+
+# ---- BASELINE.json's 1024(W) x 320(H): the shape-agnostic sub-path (tests/golden/subpath_320x1024_b2.npz)
+def subpath_opt(meta, **kw):
+    from oracle import jp_oracle as J
+    return J.default_opt(frame_ids=meta["FR"], imgs_per_gpu=meta["B"], height=meta["H"], width=meta["W"],
+                         occ_map_size=meta["occ"], type=meta["type"], split=meta["split"], loss_weightS=20, loss2_weightS=20,
+                         layout_branch=False, **kw)
+
+
+def subpath_inputs(meta):
+    B, H, W, FR = meta["B"], meta["H"], meta["W"], meta["FR"]
+    inp = syn.make_batch(B, H, W, FR, meta["occ"], tuple(meta["full_hw"]), meta["split"], seed=meta["seed"])
+    masks = syn.make_dropout_masks(B, H, W, seed=meta["seed"])
+    noise = syn.make_automask_noise(B, H, W, 4, len(FR) - 1, seed=meta["seed"])
+    return inp, masks, noise
+
+
+def run_subpath_oracle(meta, force=None, label=None, dtype=torch.float32):
+    """The oracle's sub-path (layout_branch=False) on the fixture's inputs; dtype=float64 -> the gradient referee."""
+    from oracle import jp_oracle as J
+    opt = subpath_opt(meta)
+    shapes = J.state_shapes(meta["occ"])
+    tmpl = {n: torch.empty(s, dtype=torch.long if n.endswith("num_batches_tracked") else torch.float32)
+            for n, s in shapes.items()}
+    state = syn.synth_state_dict(tmpl, seed=0)
+    inp, masks, noise = subpath_inputs(meta)
+    if dtype == torch.float32:
+        P, Bf = J.make_params(shapes, state)
+        out, L = J.forward(P, Bf, opt, inp, True, masks, noise, label, force)
+    else:
+        P, Bf = {}, {}
+        for n in shapes:
+            t = state[n].clone()
+            if J.is_buffer(n):
+                Bf[n] = t.double() if t.dtype == torch.float32 else t
+            else:
+                P[n] = t.double().requires_grad_(True)
+        inp64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in inp.items()}
+        torch.set_default_dtype(torch.float64)
+        try:
+            out, L = J.forward(P, Bf, opt, inp64, True, tuple(m.double() for m in masks),
+                               [[z.double() for z in per] for per in noise], None if label is None else label.double(), force)
+        finally:
+            torch.set_default_dtype(torch.float32)
+    total = J.total_loss(L)
+    total.backward()
+    return dict(P=P, Bf=Bf, out=out, L=L, total=total, opt=opt, inp=inp, masks=masks, noise=noise, state=state)

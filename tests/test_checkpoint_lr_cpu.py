@@ -91,3 +91,46 @@ def test_step_lr_policy_with_linear_warmup():
     assert StepLrUpdaterHook(step=15).get_lr(31, 1e-4) == pytest.approx(1e-6)       # int step: gamma ** (epoch // step)
     with pytest.raises(NotImplementedError):
         StepLrUpdaterHook(policy="cosine", step=[1])
+
+
+def test_epoch_numbering_train_save_resume_matches_mmcv(tmp_path):
+    """mmcv's CheckpointHook saves in after_train_epoch, BEFORE `_epoch += 1`: after the first epoch the file is
+    epoch_1.pth with meta.epoch == 1, and a resumed run continues with epoch index 1 (its LR and sampler epoch)."""
+    model = _model()
+    optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+    seen = []
+
+    class Sampler:
+        def set_epoch(self, e):
+            seen.append(("set_epoch", e))
+
+    class Loader:
+        sampler = Sampler()
+
+        def __iter__(self):
+            return iter([1, 2, 3])
+    lr_cfg = dict(policy="step", step=[1, 2], gamma=0.5)
+    runner = Runner(model, None, optim, None, lr_config=lr_cfg, work_dir=str(tmp_path), checkpoint_config=dict(interval=1))
+    runner.train_iter = lambda batch: (seen.append(("iter", runner.epoch, runner.current_lr()[0])), setattr(runner, "iter", runner.iter + 1))
+    runner.after_train_epoch_hooks.append(lambda r: seen.append(("after_epoch", r.epoch)))
+    runner.train_epoch(Loader())
+    assert runner.epoch == 1 and runner.iter == 3
+    assert sorted(os.listdir(tmp_path)) == ["epoch_1.pth"]
+    ck = torch.load(os.path.join(tmp_path, "epoch_1.pth"), weights_only=False)
+    assert ck["meta"]["epoch"] == 1 and ck["meta"]["iter"] == 3
+    assert seen[0] == ("set_epoch", 0) and seen[1] == ("iter", 0, 1e-4) and seen[-1] == ("after_epoch", 0)
+    runner.train_epoch(Loader())                             # second epoch: lr halves at epoch index 1
+    assert sorted(os.listdir(tmp_path)) == ["epoch_1.pth", "epoch_2.pth"]
+    assert ("iter", 1, 5e-5) in seen and ("set_epoch", 1) in seen
+    # resume from the first file in a fresh runner: continues with epoch index 1, i.e. lr 5e-5, then writes epoch_2
+    model2 = _model()
+    optim2 = build_optimizer(model2, dict(type="Adam", lr=1e-4, weight_decay=0))
+    r2 = Runner(model2, None, optim2, None, lr_config=lr_cfg, work_dir=str(tmp_path / "resumed"), checkpoint_config=dict(interval=1))
+    r2.resume(os.path.join(tmp_path, "epoch_1.pth"))
+    assert r2.epoch == 1 and r2.iter == 3
+    lrs = []
+    r2.train_iter = lambda batch: lrs.append(r2.current_lr()[0])
+    r2.train_epoch(Loader())
+    assert lrs == [5e-5] * 3 and r2.epoch == 2
+    assert os.listdir(tmp_path / "resumed") == ["epoch_2.pth"]
+    assert torch.load(tmp_path / "resumed" / "epoch_2.pth", weights_only=False)["meta"]["epoch"] == 2

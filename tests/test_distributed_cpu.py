@@ -152,3 +152,18 @@ def test_flat_arena_layout_segments_and_optimizer_state_roundtrip():
     optim2 = build_optimizer(model2, dict(type="Adam", lr=1e-4, weight_decay=0))
     with pytest.raises(ValueError):
         optim2.load_state_dict(sd)
+
+
+def test_bucket_sizes_any_value_is_legal():
+    """the reference accepts any bucket_size_mb.  Bucket lengths are multiples of 64 floats (every bucket start
+    stays 16-byte aligned for the norm kernel) for fractional values too, and a tiny bucket size yields > 64 buckets
+    without tripping a fixed-size partial table (runtime.FlatArena grows it)."""
+    from jperceiver_amd.core.dist_utils import _bucket_floats, _Exchange
+    for mb in (-1, 0, None, 64, 1, 0.3, 2.7, 1e-5, 0.001):
+        n = _bucket_floats(mb)
+        assert n >= 64 and n % 64 == 0, (mb, n)
+    assert _bucket_floats(-1) == 64 * 1024 * 1024 // 4 and _bucket_floats(1) == 262144
+    ar = _Arena(3 * 1024 * 1024 // 4 + 1234)
+    ex = _Exchange(ar, bucket_size_mb=0.01)
+    offs = [o for seg in ar.segments.values() for o in range(seg[0], seg[0] + seg[1], ex.bucket)]
+    assert len(offs) > 64 and all(o % 64 == 0 for o in offs)

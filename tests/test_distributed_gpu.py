@@ -143,3 +143,137 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert j["roofline"]["bound"] == "mfma" and 0 <= j["roofline"]["frac"] < 1 and j["roofline"]["launches"] >= 1
     assert any(k in j["roofline"]["kernel"] for k in ("jp_igemm", "jp_wgrad"))
     assert j["roofline"]["step_frac_fp32"] > 0 and j["families"]
+
+
+# ------------------------------------------------------------------------------------------- RCCL itself (1 rank)
+def _rccl_worker(port, q):
+    """One rank, backend "nccl" (= RCCL): a real step through `_Exchange.launch` / `finish` -- communicator creation,
+    async work handles launched from the tape's streams, `work.wait()` as a stream dependency, allocator stream
+    bookkeeping on the arena slices (gloo has none of these semantics)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        from jperceiver_amd import synthetic as syn
+        from jperceiver_amd.model import MONO
+        from jperceiver_amd.apis import batch_processor, build_optimizer, Runner, DataParallelShell, init_dist
+        from jperceiver_amd.core import DistOptimizerHook
+        from jperceiver_amd.core import dist_utils
+        from oracle import jp_oracle as J
+        init_dist("pytorch", backend="nccl")
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        HW, B, FR = 256, 2, [0, -1, 1]
+        opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type="static", split="odometry")
+        d = syn.make_batch(B, HW, HW, FR, HW // 4, (94, 311), "odometry", seed=41)
+        m = syn.make_dropout_masks(B, HW, HW, seed=41)
+        d[("dropout_mask", 0)], d[("dropout_mask", 1)] = m
+        for s, per in enumerate(syn.make_automask_noise(B, HW, HW, 4, 2, seed=41)):
+            for j, nz in enumerate(per):
+                d[("automask_noise", s, j)] = nz
+
+        def fresh(force):
+            model = MONO.module_dict["Baseline"](opt)
+            model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
+            model = model.cuda().train()
+            optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+            shell = DataParallelShell(model)             # wrap-time broadcast over RCCL
+            hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), bucket_size_mb=4, force_exchange=force)
+            return model, optim, Runner(shell, batch_processor, optim, hook)
+
+        def sha(t):
+            return hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()
+
+        # (a) two plain world-1 steps from identical weights: is the step itself bit-reproducible run to run?
+        digests = []
+        for _ in range(2):
+            model, optim, runner = fresh(False)
+            runner.train_iter({k: v.clone() for k, v in d.items()})
+            torch.cuda.synchronize()
+            digests.append((sha(optim.arena.grads), sha(optim.arena.params)))
+            p_plain, g_plain = optim.arena.params.detach().cpu().clone(), optim.arena.grads.detach().cpu().clone()
+        deterministic = digests[0] == digests[1]
+        # (b) the same step with every bucket pushed through RCCL.  Each bucket is snapshotted on the launching stream
+        # right before its all-reduce is enqueued: with one rank SUM is the identity, so after finish() the arena must
+        # equal the snapshots BIT FOR BIT (a collective that ran before the producing kernels finished, or a wait that did
+        # not order the norm / Adam kernels behind it, shows up here or in the parameter comparison below)
+        model, optim, runner = fresh(True)
+        snaps, launches = [], []
+        orig_launch = dist_utils._Exchange.launch
+
+        def spy(self, seg):
+            if seg not in self.done and seg in self.arena.segments:
+                off, n = self.arena.segments[seg]
+                snaps.append((off, n, self.arena.grads[off:off + n].clone()))
+                launches.append((seg, torch.cuda.current_stream().cuda_stream))
+            return orig_launch(self, seg)
+        dist_utils._Exchange.launch = spy
+        try:
+            runner.train_iter({k: v.clone() for k, v in d.items()})
+        finally:
+            dist_utils._Exchange.launch = orig_launch
+        torch.cuda.synchronize()
+        a = optim.arena
+        ident = all(torch.equal(a.grads[o:o + n], t) for o, n, t in snaps)
+        covered = sorted((o, n) for o, n, _ in snaps) == sorted(a.segments.values())
+        g_x, p_x = a.grads.detach().cpu(), a.params.detach().cpu()
+        same_as_plain = bool(torch.equal(g_x, g_plain) and torch.equal(p_x, p_plain))
+        close_to_plain = float((p_x - p_plain).abs().max())
+        # oracle clip+Adam on the exchanged arena (grad_scale = 1/1)
+        p0 = syn.synth_state_dict(model.state_dict(), seed=0)
+        P = {}
+        for n, p, o, k in a.entries[:a.n_live_entries]:
+            t = p0[n].clone().requires_grad_(True)
+            t.grad = g_x[o:o + k].view(t.shape).clone()
+            P[n] = t
+        J.adam_step(P, {}, lr=1e-4, max_norm=35.0)
+        worst = max(float((p.detach().cpu() - P[n].detach()).abs().max()) for n, p in model.named_parameters() if n in P)
+        q.put(dict(ident=ident, covered=covered, deterministic=deterministic, same_as_plain=same_as_plain,
+                   close_to_plain=close_to_plain, worst=worst, n_buckets=len(snaps), streams=len({s for _, s in launches}),
+                   segs=[s for s, _ in launches], err=None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put(dict(err=traceback.format_exc() + repr(e)))
+
+
+def test_rccl_single_rank_exchange():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    r = q.get(timeout=900)
+    p.join(60)
+    assert r["err"] is None, r["err"]
+    assert r["covered"] and r["n_buckets"] == 6, r          # every arena segment went through RCCL exactly once
+    assert r["segs"][0] == "DepthDecoder" and r["segs"][-1] == "DepthEncoder.lo", r["segs"]   # in backward-completion order
+    assert r["ident"], "a bucket changed under a 1-rank SUM all-reduce: the collective raced its producer kernels"
+    assert r["worst"] <= 1e-6, f"parameters after the RCCL step differ from clip+Adam on the exchanged arena by {r['worst']}"
+    if r["deterministic"]:
+        assert r["same_as_plain"], "the step through RCCL is not bit-identical to the plain world-1 step"
+    else:   # atomics in a backward kernel: the step is not bit-reproducible run to run, compare at rounding level
+        assert r["close_to_plain"] <= 2.5e-4, r             # lr-sized moves: |dp| <= ~2 lr for sign flips of ~0 gradients
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with NO rendezvous in the environment (the form of the driver's command): bench.py starts
+    its own ranks under torch.distributed.run and rank 0 still prints exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(JP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "2",
+           "--batch", "1", "--hw", "256", "--no-cpu-baseline", "--no-secondary", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["config_index"] == 2
+    assert "cfg_kitti_baseline_kitti_odom_4gpus" in j["config"]["workload"] and "loss_sum 1" in j["config"]["workload"]

@@ -132,3 +132,34 @@ def test_lazy_log_vars_reads_like_a_dict_of_floats():
     c = LazyLogVars(names, vals * 4)
     assert not a._pending and b._pending
     assert a["loss"] == pytest.approx(-2.5) and b["loss"] == pytest.approx(-3.75) and c["loss"] == pytest.approx(-5.0)
+
+
+def test_standalone_pose_nets_repack_after_in_place_weight_load():
+    """sub-networks used standalone (no `Baseline.forward`, hence no PackRegistry.refresh_all) keep persistent
+    packed conv weights; an in-place `load_state_dict` / `.copy_()` on their parameters bumps neither the optimizer epoch
+    nor the storage pointer.  The per-layer parameter version check must re-pack: forward -> load other weights -> forward
+    must equal a fresh net that only ever saw the second weights."""
+    def nets(seed):
+        _, model = _model()
+        sd = syn.synth_state_dict(model.state_dict(), seed=seed, bn_stats=True)
+        return {"state_dict": {k: v for k, v in sd.items()}}
+    ck_a, ck_b = nets(3), nets(4)
+    gen = torch.Generator().manual_seed(9)
+    f0, f1 = torch.rand(1, 3, 192, 640, generator=gen).to(DEV), torch.rand(1, 3, 192, 640, generator=gen).to(DEV)
+    enc, dec = PoseEncoder(18, None, 2).to(DEV).eval(), PoseDecoder(np.array([64, 64, 128, 256, 512])).to(DEV).eval()
+    pose_nets_from_checkpoint(ck_a, enc, dec)
+    T_a = pose_between(enc, dec, f0, f1).clone()
+    pose_nets_from_checkpoint(ck_b, enc, dec)                       # in place: same storage, same optimizer epoch
+    T_b = pose_between(enc, dec, f0, f1).clone()
+    enc2, dec2 = PoseEncoder(18, None, 2).to(DEV).eval(), PoseDecoder(np.array([64, 64, 128, 256, 512])).to(DEV).eval()
+    pose_nets_from_checkpoint(ck_b, enc2, dec2)
+    T_fresh = pose_between(enc2, dec2, f0, f1)
+    assert float((T_a - T_b).abs().max()) > 1e-4, "the two weight sets must give different poses for this test to mean anything"
+    assert torch.equal(T_b, T_fresh), f"stale packed weights: {float((T_b - T_fresh).abs().max())}"
+    # the reference's own pattern (scripts/draw_odometry.py:52-56): state_dict()[n].copy_(...)
+    with torch.no_grad():
+        for n, t in enc.state_dict().items():
+            t.copy_(ck_a["state_dict"]["PoseEncoder." + n])
+        for n, t in dec.state_dict().items():
+            t.copy_(ck_a["state_dict"]["PoseDecoder." + n])
+    assert torch.equal(pose_between(enc, dec, f0, f1), T_a)

@@ -210,3 +210,40 @@ def test_device_loader_feeds_train_steps_in_order():
         tags.append(int(batch.pop("tag")[0]))
         losses.append(runner.train_iter(batch)["log_vars"]["loss"])
     assert tags == [0, 1, 2, 3] and all(np.isfinite(losses))
+
+
+@pytest.mark.gpu
+def test_color_jitter_is_decided_per_item_and_drawn_per_frame():
+    """ADVICE r02 / mono_dataset.py:202,338-339,153-156: `do_color_aug` is one coin per ITEM; the `ColorJitter` object the
+    reference passes re-draws order + factors per call, i.e. per FRAME.  Un-augmented items keep color_aug == color;
+    every augmented (item, frame) equals the torchvision restatement applied with ITS parameters."""
+    from jperceiver_amd.datasets import DevicePreprocessor
+    from oracle import tv_restated as TV
+    H, W, FR, N = 32, 48, [0, -1, 1], 4
+    pre = DevicePreprocessor(H, W, "cuda")
+    raw = {("color", f, -1): (torch.from_numpy(syn.hash_uniform(60, ("rawj", f), (N, 40, 60, 3))) * 256).to(torch.uint8).cuda()
+           for f in FR}
+    out = pre(raw, FR, (36, 54), do_color_aug=[True, False, True, False], generator=torch.Generator().manual_seed(2))
+    P = pre.last_jitter
+    assert set(P) == {(i, f) for i in (0, 2) for f in FR}
+    assert len({(tuple(p.order), tuple(p.factors)) for p in P.values()}) == 6          # one draw per (item, frame)
+    for f in FR:
+        col, aug = out[("color", f, 0)].cpu(), out[("color_aug", f, 0)].cpu()
+        for i in range(N):
+            if (i, f) in P:
+                ref = TV.color_jitter(col[i:i + 1].clone(), P[(i, f)].order, P[(i, f)].factors)
+                assert float((aug[i:i + 1] - ref).abs().max()) < 2e-5, (i, f)
+                assert float((aug[i] - col[i]).abs().max()) > 1e-3
+            else:
+                assert torch.equal(aug[i], col[i]), (i, f)
+    # the coin itself: one per item from the generator; roughly half of many items are augmented
+    gen = torch.Generator().manual_seed(5)
+    raw1 = {k: v[:1].repeat(64, 1, 1, 1) for k, v in raw.items()}
+    pre(raw1, FR, (36, 54), generator=gen)
+    n_aug = len({i for i, _ in pre.last_jitter})
+    assert 16 <= n_aug <= 48
+    # jitter="per_item": the item's frames share one draw
+    pre(raw, FR, (36, 54), do_color_aug=True, generator=torch.Generator().manual_seed(3), jitter="per_item")
+    for i in range(N):
+        assert len({id(pre.last_jitter[(i, f)]) for f in FR}) == 1
+    assert len({id(p) for p in pre.last_jitter.values()}) == N

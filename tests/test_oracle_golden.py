@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.golden_util import load_case, run_oracle
+from tests.golden_util import load_case, run_oracle, run_subpath_oracle
 from oracle import jp_oracle as J
 
 
@@ -55,6 +55,45 @@ def test_full_step_matches_reference(case):
     for k in g.files:
         if k.startswith("nbt/"):
             assert int(Bf[k[4:]]) == int(g[k]), k
+        if k.startswith("buf/"):
+            np.testing.assert_allclose(Bf[k[4:]].numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+def test_subpath_320x1024_matches_reference():
+    """BASELINE.json's 1024(W) x 320(H) shape: the oracle's `layout_branch=False` sub-path against the fixture the
+    REFERENCE's own DepthEncoder / DepthDecoder / predict_poses / compute_losses produced at H=320, W=1024
+    (tools/make_golden.py::subpath_case)."""
+    g, meta = load_case("subpath_320x1024_b2")
+    r = run_subpath_oracle(meta)
+    L, out, P, Bf = r["L"], r["out"], r["P"], r["Bf"]
+    assert {repr(k) for k in L} == {k[len("loss/"):] for k in g.files if k.startswith("loss/(")}
+    for k, v in L.items():
+        assert float(v) == pytest.approx(float(g["loss/" + repr(k)]), rel=2e-5, abs=1e-7), k
+    assert float(r["total"]) == pytest.approx(float(g["loss/total"]), rel=2e-5)
+    for f in meta["FR"][1:]:
+        np.testing.assert_allclose(out[("cam_T_cam", 0, f)].detach().numpy(), g[f"cam_T_cam/{f}"], atol=1e-6)
+    for s in range(4):
+        d = out[("disp", 0, s)]
+        assert d.shape == (meta["B"], 1, meta["H"] >> (s + 1), meta["W"] >> (s + 1))     # depth_decoder.py: disp_s at 1/2^(s+1)
+        np.testing.assert_allclose(pool_to(d), g[f"disp{s}/pool"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(d.detach().numpy()[:, :, :8, :8], g[f"disp{s}/first"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(d.detach().numpy()[:, :, -8:, -8:], g[f"disp{s}/last"], rtol=1e-4, atol=1e-6)
+        hist = np.bincount(out[("min_index", s)].reshape(-1).numpy(), minlength=4)
+        assert np.abs(hist - g[f"min_index{s}/hist"]).sum() <= 4
+        for f in meta["FR"][1:]:
+            np.testing.assert_allclose(pool_to(out[("color", f, s)]), g[f"color{f}_{s}/pool"], rtol=1e-4, atol=1e-5)
+    none_ref = {k[len("gradnone/"):] for k in g.files if k.startswith("gradnone/")}
+    assert {n for n, p in P.items() if p.grad is None} == none_ref
+    assert all(n.split(".")[0] in ("DepthEncoder", "DepthDecoder", "PoseEncoder", "PoseDecoder") for n, p in P.items() if p.grad is not None)
+    for n, p in P.items():
+        if p.grad is None:
+            continue
+        gn = float(p.grad.double().pow(2).sum()) ** 0.5
+        floor = 1e-6 * float(g["gradnorm_module/" + n.split(".")[0]])
+        assert gn == pytest.approx(float(g["gradnorm/" + n]), rel=2e-3, abs=floor), n
+        np.testing.assert_allclose(p.grad.reshape(-1)[:4].numpy(), g["gradprobe/" + n], rtol=5e-3,
+                                   atol=floor + 1e-4 * float(g["gradnorm/" + n]))
+    for k in g.files:
         if k.startswith("buf/"):
             np.testing.assert_allclose(Bf[k[4:]].numpy(), g[k], rtol=1e-4, atol=1e-6)
 

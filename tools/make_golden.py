@@ -219,6 +219,92 @@ def run_case(net, name, HW, B, FR, ty, split, full_hw, seed=1):
     return model, inp, out, losses, cap
 
 
+def subpath_case(net, name="subpath_320x1024_b2", H=320, W=1024, B=2, FR=(0, -1, 1), seed=4, full_hw=(514, 616)):
+    """BASELINE.json's 1024(W) x 320(H): the reference's shape-agnostic sub-path run by the REFERENCE's own modules and its
+    own `compute_losses` (net.py:94-192) -- DepthEncoder, DepthDecoder, predict_poses (:630-642), generate_images_pred
+    (:690-702), compute_reprojection_loss (:84-92), automask + min (:159-175), get_scale_label_both (:400-476),
+    get_scale_loss (:194-211), get_smooth_loss (:758-786).  The BEV-layout branch cannot run on a non-square input
+    (CycledViewProjection / CrossViewTransformer flatten square maps), so `predict_layout*` is not
+    called; `compute_losses` still reads their outputs, which are fed as constants and whose loss entries are discarded."""
+    FR = list(FR)
+    occ = 256
+    opt = Opt(depth_num_layers=18, pose_num_layers=18, frame_ids=FR, imgs_per_gpu=B, height=H, width=W,
+              scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0, depth_pretrained_path=None,
+              pose_pretrained_path=None, automask=True, disp_norm=True, smoothness_weight=1e-3,
+              scale_weight=0.1, dynamic_weight=15., static_weight=5., occ_map_size=occ, num_class=2,
+              loss_type="iou", loss_weight=20, loss_weightS=20, loss2_type="boundary", loss2_weight=20,
+              loss2_weightS=20, type="Argo_both", loss_sum=3, split="argo")
+    torch.manual_seed(0)
+    model = net.Baseline(opt)
+    model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0), strict=True)
+    model.train()
+    inp = syn.make_batch(B, H, W, FR, occ, full_hw, "argo", seed=seed)
+    m4, m3 = syn.make_dropout_masks(B, H, W, seed=seed)
+    model.DepthDecoder.do = FixedDropout([m4, m3])
+    noise = syn.make_automask_noise(B, H, W, 4, len(FR) - 1, seed=seed)
+    it = iter([n.clone() for per_scale in noise for n in per_scale])
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    cap = {}
+    orig = model.get_scale_label_both
+
+    def grab(inputs, o):
+        cap["scale_label"] = orig(inputs, o)
+        return cap["scale_label"]
+    model.get_scale_label_both = grab
+    try:
+        d = {k: v.clone() for k, v in inp.items()}
+        out = model.DepthDecoder(model.DepthEncoder(d["color_aug", 0, 0]))
+        const = torch.zeros(B, 2, occ, occ)
+        feat = torch.zeros(B, 128, occ // 32, occ // 32)
+        for k in ("topview", "transform_topview", "topviewB", "transform_topviewB"):
+            out[k] = const
+        for k in ("features", "retransform_features", "featuresB", "retransform_featuresB"):
+            out[k] = feat
+        out.update(model.predict_poses(d))
+        losses = model.compute_losses(d, out)
+    finally:
+        torch.randn = real_randn
+    losses = {k: v for k, v in losses.items() if isinstance(k, tuple)}        # the 12 depth-path terms
+    total = sum(v.mean() for v in losses.values())
+    total.backward()
+    g = {}
+    for k, v in losses.items():
+        g["loss/" + repr(k)] = np.float64(v.detach().double().item())
+    g["loss/total"] = np.float64(total.detach().double().item())
+    for f in FR[1:]:
+        g[f"cam_T_cam/{f}"] = out[("cam_T_cam", 0, f)].detach().numpy()
+    for s in range(4):
+        dsp = out[("disp", 0, s)]
+        g[f"disp{s}/pool"] = pool_to(dsp)
+        g[f"disp{s}/first"] = dsp.detach().numpy()[:, :, :8, :8].copy()
+        g[f"disp{s}/last"] = dsp.detach().numpy()[:, :, -8:, -8:].copy()
+        g[f"min_index{s}/hist"] = np.bincount(out[("min_index", s)].reshape(-1).numpy(), minlength=4)
+        for f in FR[1:]:
+            g[f"color{f}_{s}/pool"] = pool_to(out[("color", f, s)])
+    g["scale_label/pool"] = pool_to(cap["scale_label"], 32)
+    g["scale_label/nnz"] = np.int64((cap["scale_label"] > 0).sum().item())
+    mods = {}
+    for n, p in model.named_parameters():
+        top = n.split(".")[0]
+        if p.grad is None:
+            g["gradnone/" + n] = np.int64(1)
+            continue
+        gn = float(p.grad.double().pow(2).sum())
+        mods[top] = mods.get(top, 0.0) + gn
+        g["gradnorm/" + n] = np.float64(np.sqrt(gn))
+        g["gradprobe/" + n] = p.grad.reshape(-1)[:4].detach().numpy().copy()
+    for top, v in mods.items():
+        g["gradnorm_module/" + top] = np.float64(np.sqrt(v))
+    for n in ("DepthEncoder.encoder.bn1.running_mean", "DepthEncoder.encoder.layer4.1.bn2.running_var",
+              "PoseEncoder.encoder.bn1.running_var"):
+        g["buf/" + n] = dict(model.named_buffers())[n].detach().numpy().copy()
+    meta = dict(H=H, W=W, B=B, FR=FR, type="Argo_both", split="argo", full_hw=list(full_hw), seed=seed, occ=occ)
+    g["meta"] = np.array(repr(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
+    print(name, "total loss", g["loss/total"], "keys", len(g), {k: float(v) for k, v in losses.items()})
+
+
 def unit_vectors(net):
     """Small op-level known-answer vectors straight from the reference's layers/losses."""
     layers = sys.modules["mono.model.mono_baseline.layers"]
@@ -473,7 +559,7 @@ CASES = {
 
 if __name__ == "__main__":
     net = import_reference()
-    want = sys.argv[1:] or (["unit", "scale_labels", "eval", "eval_metrics", "sampler", "preprocess"] + list(CASES))
+    want = sys.argv[1:] or (["unit", "scale_labels", "eval", "eval_metrics", "sampler", "preprocess", "subpath"] + list(CASES))
     for c in want:
         if c == "unit":
             unit_vectors(net)
@@ -487,5 +573,7 @@ if __name__ == "__main__":
             preprocess_vectors()
         elif c == "scale_labels":
             scale_label_cases(net)
+        elif c == "subpath":
+            subpath_case(net)
         else:
             run_case(net, c, *CASES[c][:6], seed=CASES[c][6])
