@@ -170,7 +170,13 @@ def test_iconv_at_bench_shape(N, H, W, Cr, Cx, Cout):
             tape.backward()
     finally:
         ops._WG_ON = was
-    _expect(kt.names, ["jp_igemm_p9_kernel<4, 2, false, true, DgradEpi, 9, 1>", "jp_wgrad_w9_kernel<2, 2, 1, true>"], "iconv backward")
+    # skip segment: P9 dgrad on the 128-row tiles of the 513-row bank's pack + reflection border pass; upsampled segment:
+    # parity-class dgrad at half resolution (+ its edge pass); wgrad per source (W9 on the skip segment, parity-class
+    # kernels on the upsampled one, table pass for the disparity channel)
+    _expect(kt.names, ["jp_igemm_p9_kernel<2, 2, false, true, DgradEpi, 9, 1>", "DgradBorderB<3>",
+                       "jp_wgrad_w9_kernel<2, 2, 1, true>", "WgradAP, WgradBP"], "iconv backward")
+    if H >= 128:      # at 64^2 the half-resolution (32^2) dgrad of the upsampled segment takes the tap-major path instead
+        _expect(kt.names, ["DgradUPB", "DgradUPBorderB"], "iconv backward, upsampled segment")
     yr.backward(gy.cpu())
     for got, ref, nm in zip((rv.g, xv.g, dv.g, wv.g, bv.g), leaves, ("d_reduce", "d_x_half", "d_disp", "dw", "db")):
         close(got, ref.grad, rtol=2e-4, msg=nm)

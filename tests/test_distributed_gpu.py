@@ -176,7 +176,7 @@ def _rccl_worker(port, q):
             model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
             model = model.cuda().train()
             optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
-            shell = DataParallelShell(model)             # wrap-time broadcast over RCCL
+            shell = DataParallelShell(model)
             hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), bucket_size_mb=4, force_exchange=force)
             return model, optim, Runner(shell, batch_processor, optim, hook)
 
@@ -250,7 +250,10 @@ def test_rccl_single_rank_exchange():
     p.join(60)
     assert r["err"] is None, r["err"]
     assert r["covered"] and r["n_buckets"] == 6, r          # every arena segment went through RCCL exactly once
-    assert r["segs"][0] == "DepthDecoder" and r["segs"][-1] == "DepthEncoder.lo", r["segs"]   # in backward-completion order
+    # launched from the tape as each segment's backward is ENQUEUED (the side stream's heads / layout encoder / pose nodes
+    # are enqueued before the depth decoder's); the depth encoder's remainder is the last thing the backward finishes
+    assert set(r["segs"]) == {"DepthDecoder", "heads", "LayoutEncoder", "Pose", "DepthEncoder.l4", "DepthEncoder.lo"}
+    assert r["segs"][-1] == "DepthEncoder.lo" and r["streams"] >= 2, r
     assert r["ident"], "a bucket changed under a 1-rank SUM all-reduce: the collective raced its producer kernels"
     assert r["worst"] <= 1e-6, f"parameters after the RCCL step differ from clip+Adam on the exchanged arena by {r['worst']}"
     if r["deterministic"]:

@@ -3,8 +3,9 @@
   * against the oracle (oracle/jp_oracle.py) run here on CPU on the same seeded inputs —
     every loss term, pose, disparity / layout maps, per-parameter gradient norms and probes, BN buffers,
     then one clip+Adam step.
-Tolerances follow BASELINE.json: depth/layout 1e-3 relative, pose 1e-4; gradients 1e-2 relative to the
-owning module's gradient norm (fp32 summation order; hard arg-max / arg-min are discrete)."""
+Tolerances follow BASELINE.json: depth / layout / features / warped images 1e-3 relative (vs the reference fixture AND the
+oracle), pose 1e-4; gradients 2 % of each parameter's gradient norm with a float64 referee (fp32 summation order; hard
+arg-max / arg-min are discrete)."""
 import numpy as np
 import pytest
 import torch
@@ -83,11 +84,13 @@ def test_train_step_matches_reference_and_oracle(case):
         hist = np.bincount(out[("min_index", s)].reshape(-1).cpu().numpy(), minlength=4)
         assert np.abs(hist - g[f"min_index{s}/hist"]).sum() <= 0.002 * hist.sum()
         for f in meta["FR"][1:]:
-            assert rel(pool_to(out[("color", f, s)]), g[f"color{f}_{s}/pool"]) < 2e-3
+            assert rel(pool_to(out[("color", f, s)]), g[f"color{f}_{s}/pool"]) < 1e-3
+    # layout maps / features vs the REFERENCE fixture at north_star's 1e-3 (pooled fingerprints + the first 8x8 crop)
     for k in ("topview", "transform_topview", "topviewB", "transform_topviewB"):
-        assert rel(pool_to(out[k]), g[k + "/pool"]) < 2e-3, k
+        assert rel(pool_to(out[k]), g[k + "/pool"]) < 1e-3, k
+        assert rel(out[k].cpu().numpy()[:, :, :8, :8], g[k + "/first"]) < 1e-3, k
     for k in ("features", "featuresB", "retransform_features", "cv_attn_road", "cm_attn_car", "origin_features"):
-        assert rel(out[k].cpu().numpy(), g["feat/" + k]) < 2e-3, k
+        assert rel(out[k].cpu().numpy(), g["feat/" + k]) < 1e-3, k
 
     # ---- gradients.  (a) vs the REFERENCE golden: which parameters get none, per-parameter norms within 5 %
     # (the per-pixel arg-min of the automask and the CCT arg-max are discrete: a handful of selections

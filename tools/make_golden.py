@@ -284,6 +284,10 @@ def subpath_case(net, name="subpath_320x1024_b2", H=320, W=1024, B=2, FR=(0, -1,
             g[f"color{f}_{s}/pool"] = pool_to(out[("color", f, s)])
     g["scale_label/pool"] = pool_to(cap["scale_label"], 32)
     g["scale_label/nnz"] = np.int64((cap["scale_label"] > 0).sum().item())
+    # the label itself (mostly zeros: compresses well).  It is an INPUT of the parity-checked step, and the abs-rel scale loss
+    # divides by it: the few near-zero label values at the edge of the warped layout are decided by the evaluating host's
+    # rounding (another x86 host's PyTorch moves scale_loss by ~1 %), so the GPU test feeds THIS label to both sides
+    g["scale_label/full"] = cap["scale_label"].detach().numpy().astype(np.float32)
     mods = {}
     for n, p in model.named_parameters():
         top = n.split(".")[0]
