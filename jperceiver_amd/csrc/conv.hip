@@ -23,6 +23,7 @@
 //   "S2" parity-class dgrad of the 3x3 stride-2 convs; "C" whole-tap K chunks for the 3/6-channel stems.
 //   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
 #include "igemm_p9.h"
+#include "igemm_p9s.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -44,7 +45,7 @@ __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 // The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
 // launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
 // tiny launches per step become one.
-enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6 };
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7 };
 struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
     const float* w;
     float* wp;
@@ -122,6 +123,37 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             if (m >= rows || c >= red) return 0.f;
             const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
             return w[((size_t)co * Cin + ci) * KHW + tap];
+        }
+        case PACK_SPLIT: {     // p = Cout, Cin, for_dgrad, BMT, KHW (9 or 1), KGS: bf16 three-way split weights in the fragment order
+                               // of the P9S kernel (igemm_p9s.h): wp[M tile][step = (stage, tap, 16-channel group) (+ slack)]
+                               // [split][k-half][row][4 words]; word w4 = the bf16 pair of reduction channels
+                               // stage*16*KGS + group*16 + khalf*8 + 2*w4 + {0, 1} (low half = the even channel)
+            const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4], KGS = p[5];
+            const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+            const long nsteps = (long)(red / (16 * KGS)) * KHW * KGS;
+            const long per_tile = (nsteps + P9S_AHEAD) * 24 * BMT;
+            const int mt = (int)(i / per_tile);
+            long t = i - (long)mt * per_tile;
+            const int w4 = (int)(t & 3); t >>= 2;
+            const int m = mt * BMT + (int)(t % BMT);
+            t /= BMT;
+            const int khalf = (int)(t & 1); t >>= 1;
+            const int sp = (int)(t % 3);
+            const long U = t / 3;
+            if (U >= nsteps || m >= rows) return 0.f;
+            const int stage = (int)(U / (KHW * KGS)), u = (int)(U % (KHW * KGS));
+            const int tap = u / KGS, kg = u % KGS;
+            const int c = stage * 16 * KGS + kg * 16 + khalf * 8 + 2 * w4;
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int cc = c + k;
+                const int co = for_dgrad ? cc : m, ci = for_dgrad ? m : cc;
+                v[k] = cc < red ? w[((size_t)co * Cin + ci) * KHW + tap] : 0.f;
+            }
+            unsigned s0, s1, s2;
+            jp_split3(v[0], v[1], s0, s1, s2);
+            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
         }
         case PACK_FRAGSEG: {   // p = Cout, Cin, c_off, C, KP, up: one channel segment of an iconv bank in the fragment order of
                                // the P9U kernel (igemm_p9u.h): [class (up only)][M tile of 128][quad][k parity][row][4],
@@ -1838,6 +1870,25 @@ inline long p9_ws_floats(int rows, int red, int khw = 9) {
     const int bmt = rows <= 64 ? 64 : 128;          // the 256-row tiling of the same bank never needs more
     return ((long)jp_cdiv(red, 32) * khw * 4 + P9_QAHEAD + 1) * 8 * bmt * jp_cdiv(rows, bmt);
 }
+// P9S (igemm_p9s.h): the same tiles with every fp32 product formed on the bf16 matrix pipe from three-way splits of both
+// operands (6 MFMAs of 32 cycles instead of 8 of 64; fp32-equivalent accuracy).  JP_P9S=0 keeps the exact-fp32 P9 kernel.
+inline bool p9s_enabled() {
+    static const int on = [] { const char* e = getenv("JP_P9S"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+inline int p9s_kgs(int khw) { return khw == 9 ? 1 : 2; }       // 16-channel groups per stage
+inline long p9s_ws_floats(int rows, int red, int khw = 9) {
+    const int bmt = rows <= 64 ? 64 : 128, kgs = p9s_kgs(khw);
+    return ((long)(red / (16 * kgs)) * khw * kgs + P9S_AHEAD) * 24 * bmt * jp_cdiv(rows, bmt);
+}
+// scratch that holds either pack of a bank
+inline long p9_alloc_floats(int rows, int red, int khw = 9) { return std::max(p9_ws_floats(rows, red, khw), p9s_ws_floats(rows, (red + 31) / 32 * 32, khw)); }
+// fragment-order pack of a bank for the patch kernels: fp32 (PACK_FRAG) or bf16 splits (PACK_SPLIT)
+inline void pack_p9(const float* w, float* wp, int Cout, int Cin, int for_dgrad, int bmt, int khw, hipStream_t st) {
+    const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+    if (p9s_enabled()) do_pack(PACK_SPLIT, w, wp, p9s_ws_floats(rows, red, khw), Cout, Cin, for_dgrad, bmt, khw, p9s_kgs(khw), st);
+    else do_pack(PACK_FRAG, w, wp, p9_ws_floats(rows, red, khw), Cout, Cin, for_dgrad, bmt, khw, 0, st);
+}
 // JP_P1: 1 = every eligible 1x1 layer, 0 = none, unset = only banks that get the 256-channel 8-wave tiles (there the
 // patch kernel wins: 256->256 @256x256 forward 101 -> 107 TF, dgrad 106 -> 113 TF; with 128-channel tiles it does not)
 inline int p1_mode() {
@@ -1852,11 +1903,34 @@ inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {
 }
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9_tag() { return __PRETTY_FUNCTION__; }       // profiler tag naming the instantiation
+template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
+const char* p9s_tag() { return __PRETTY_FUNCTION__; }
+template <bool REFLECT, bool REV, class E, int TAPS>
+void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
+    constexpr int KGS = TAPS == 9 ? 1 : 2;
+    const int NST = red / (16 * KGS);
+    const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
+    // executed FLOPs: 6 bf16 MFMA products per fp32 product
+    jp_prof_before(bmt == 64 ? p9s_tag<1, 4, REFLECT, REV, E, TAPS>() : (bmt == 256 ? p9s_tag<4, 2, REFLECT, REV, E, TAPS>() : p9s_tag<2, 2, REFLECT, REV, E, TAPS>()),
+                   6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+    if (bmt == 64) {
+        dim3 grid(N * (H / 8) * (W / 32), 1, 1);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<1, 4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+    } else if (bmt == 256) {
+        dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+    } else {
+        dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<2, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+    }
+    jp_prof_after(st);
+}
 template <bool REFLECT, bool REV, class E>
 void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off = 0,
                int bank_rows = -1) {
     const int NCH = jp_cdiv(red, 32);
     const int bmt = p9_bmt(bank_rows < 0 ? rows : bank_rows, 9, p9_ptiles(N, H, W));   // the M tile of the PACK (the bank's rows)
+    if (p9s_enabled()) { launch_p9s<REFLECT, REV, E, 9>(wp, x, e, rows, red, N, H, W, st, mt_off, bmt); return; }
     jp_prof_before(bmt == 64 ? p9_tag<1, 4, REFLECT, REV, E>() : (bmt == 256 ? p9_tag<4, 2, REFLECT, REV, E>() : p9_tag<2, 2, REFLECT, REV, E>()),
                    2.0 * rows * (double)N * H * W * 9.0 * red, st);
     if (bmt == 64) {
@@ -1876,6 +1950,7 @@ template <class E>
 void launch_p1(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st) {
     const int NST = jp_cdiv(red, 64);
     const int bmt = p9_bmt(rows, 1, p9_ptiles(N, H, W));
+    if (p9s_enabled()) { launch_p9s<false, false, E, 1>(wp, x, e, rows, red, N, H, W, st, 0, bmt); return; }
     jp_prof_before(bmt == 64 ? p9_tag<1, 4, false, false, E, 1>() : (bmt == 256 ? p9_tag<4, 2, false, false, E, 1>() : p9_tag<2, 2, false, false, E, 1>()),
                    2.0 * rows * (double)N * H * W * red, st);
     if (bmt == 64) {
@@ -2056,10 +2131,10 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
     if (which == 0 && Cin <= 8) return (long)(Cout + 256) * pad32(KH * KH * 8);   // row-major pack of the stem path
     if (which == 0) return Cin >= 16 ? std::max(((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96),
-                                                KH == 3 ? p9_ws_floats(Cout, pad32(Cin)) : (KH == 1 ? p9_ws_floats(Cout, pad32(Cin), 1) : 0L)) : 0;
+                                                KH == 3 ? p9_alloc_floats(Cout, pad32(Cin)) : (KH == 1 ? p9_alloc_floats(Cout, pad32(Cin), 1) : 0L)) : 0;
     // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled
     // segment, plus the fragment-order pack of the P9 main pass behind them
-    if (which == 1) return Cout >= 16 ? dgrad_tap_floats(Cin, Cout, KH) + (KH == 3 ? p9_ws_floats(Cin, pad32(Cout)) : (KH == 1 ? p9_ws_floats(Cin, pad32(Cout), 1) : 0L)) : 0;
+    if (which == 1) return Cout >= 16 ? dgrad_tap_floats(Cin, Cout, KH) + (KH == 3 ? p9_alloc_floats(Cin, pad32(Cout)) : (KH == 1 ? p9_alloc_floats(Cin, pad32(Cout), 1) : 0L)) : 0;
     return 0;
 }
 
@@ -2158,14 +2233,14 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         const bool use_p1 = KH == 1 && stride == 1 && pad == 0 && !((c0 && up0) || (c1 && up1) || (c2 && up2)) && c1 == 0 &&
                             c2 == 0 && p9_ok(Cout, Cin, N, H, W, 1);
         if (use_p1) {      // 1x1: weights stream in fragment order, two channel chunks of the pixel tile staged per barrier pair
-            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin, 1), Cout, Cin, 0, p9_bmt(Cout, 1, p9_ptiles(N, H, W)), 1, 0, st);
+            if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, p9_bmt(Cout, 1, p9_ptiles(N, H, W)), 1, st);
             launch_p1(ws, x0, e, Cout, Cin, N, H, W, st);
             JP_LAUNCH_CHECK();
         }
         if (use_p9) {
             // P9 patch kernel: the input patch of a 4x32 pixel tile is staged once per channel chunk for all 9 taps,
             // weights stream from L2 in MFMA fragment order (igemm_p9.h); its pack takes the place of the tap-major one
-            if (!ws_state) do_pack(PACK_FRAG, w, ws, p9_ws_floats(Cout, Cin), Cout, Cin, 0, p9_bmt(Cout, 9, p9_ptiles(N, H, W)), 9, 0, st);
+            if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, p9_bmt(Cout, 9, p9_ptiles(N, H, W)), 9, st);
             if (pad_mode == JP_PAD_REFLECT) launch_p9<true, false>(ws, x0, e, Cout, Cin, N, H, W, st);
             else launch_p9<false, false>(ws, x0, e, Cout, Cin, N, H, W, st);
             JP_LAUNCH_CHECK();
@@ -2331,7 +2406,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                     const int bn3 = Mm <= 64 ? 256 : 128;
                     if (KH == 1 && pad == 0 && tail == 0 && p9_ok(Cin, Cout, N, H, W, 1)) {
                         float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
-                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout, 1), Cout, Cin, 1, p9_bmt(Cin, 1, p9_ptiles(N, H, W)), 1, 0, st);
+                        if (!ws_state) pack_p9(w, wfr, Cout, Cin, 1, p9_bmt(Cin, 1, p9_ptiles(N, H, W)), 1, st);
                         launch_p1(wfr, dy, e, Cin, Cout, N, H, W, st);
                     } else
                     if (KH == 3 && pad == 1 && (tail == 0 || Mm > 64) && p9_ok(Mm, Cout, N, H, W)) {
@@ -2340,7 +2415,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                         // row tail (513 = 4*128 + 1) the kernel runs the full 128-row tiles of the same pack, the tail
                         // its own launch below.
                         float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
-                        if (!ws_state) do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin, 9, p9_ptiles(N, H, W)), 9, 0, st);
+                        if (!ws_state) pack_p9(w, wfr, Cout, Cin, 1, p9_bmt(Cin, 9, p9_ptiles(N, H, W)), 9, st);
                         launch_p9<false, true>(wfr, dy, e, Mm, Cout, N, H, W, st, 0, Cin);
                     } else
                     if (KH == 3 && pad == 1 && Cout >= 32 && W % bn3 == 0 && npix > 64) {
@@ -2454,7 +2529,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
                     // P9 patch kernel on this segment's 128-row tiles of the whole bank's fragment-order pack
                     float* wfr = ws + dgrad_tap_floats(Cin, Cout, 3);
                     if (!ws_state && !frag_packed) {
-                        do_pack(PACK_FRAG, w, wfr, p9_ws_floats(Cin, Cout), Cout, Cin, 1, p9_bmt(Cin, 9, p9_ptiles(N, H, W)), 9, 0, st);
+                        pack_p9(w, wfr, Cout, Cin, 1, p9_bmt(Cin, 9, p9_ptiles(N, H, W)), 9, st);
                         frag_packed = true;
                     }
                     launch_p9<false, true>(wfr, dy, e, C, Cout, N, H, W, st, coff / p9_bmt(Cin, 9, p9_ptiles(N, H, W)), Cin);

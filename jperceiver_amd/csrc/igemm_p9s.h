@@ -1,0 +1,216 @@
+// "P9S" patch kernel: the P9 convolution (3x3 stride-1 pad-1 forward / dgrad main pass, and 1x1) with every fp32 product
+// formed on the BF16 matrix pipe from exact three-way splits of both operands -- fp32 in, fp32 out, fp32 accumulate,
+// fp32-equivalent accuracy, at 6/16 of the fp32-MFMA issue cost.
+//
+// Why.  gfx950 has no TF32/xf32 path and its fp32 MFMA runs at the fp32 VECTOR rate (157 TF), 1/16 of the bf16 MFMA rate
+// (2.5 PF dense).  An fp32 value v is the sum of three bf16 values to within 2^-25 |v|:
+//     v0 = bf16(v)   r1 = v - v0 (exact)   v1 = bf16(r1)   r2 = r1 - v1 (exact)   v2 = bf16(r2)          (round to nearest)
+// and a product a*b = sum_{s,t} a_s * b_t.  Every a_s * b_t is exact in fp32 (8 x 8 significand bits) and the bf16 MFMA
+// accumulates in fp32, so issuing the six terms with s + t <= 2
+//     a0 b0   a0 b1   a1 b0   a0 b2   a1 b1   a2 b0
+// leaves out a1 b2 + a2 b1 + a2 b2 <= (2^-24 + 2^-24 + 2^-32) |a b|: the same size as the ONE rounding an fp32 FMA applies
+// to the running sum it adds the product to.  The sum over the 16 products of one MFMA is formed inside the matrix unit and
+// rounded once into the fp32 accumulator -- 6 roundings per 16 reduction elements instead of the FMA chain's 16.
+// tests/test_kernels_gpu.py::test_split_product_accuracy_vs_float64 holds the kernel to "no further from the float64
+// result than the exact-fp32 P9 kernel is".  6 MFMAs of 32 cycles replace 8 of 64: 2.67x less matrix-pipe time.
+//
+// Structure (same tiling ideas as igemm_p9.h): a workgroup owns TR = WN*NJ pixel rows x 32 columns and 64*WM output
+// channels.  Per stage of CS = 16*KGS reduction channels the (TR+2) x 34 input patch is staged ONCE: 8 channels of one
+// pixel are gathered by one thread (8 coalesced dword loads), split, and written as three 16-byte LDS words
+//     patch[split][k-half (8 channels)][patch row][column]  = 8 bf16
+// so that a lane's B operand of `v_mfma_f32_32x32x16_bf16` (pixel = lane & 31, 8 consecutive k = channels of k-half
+// lane >> 5) for ANY tap is one aligned ds_read_b128 at a compile-time offset.  The weights are split once per step by the
+// pack (PACK_SPLIT, conv.hip) into MFMA fragment order [M tile][step = (stage, tap, 16-channel group)][split][k-half][row]
+// x 16 bytes and stream from L2 with one buffer_load_dwordx4 per (row block, split) per step, one step ahead.
+// Per step a wave issues 6 weight loads + 3*NJ LDS reads for 12*NJ MFMAs; a workgroup meets 2 barriers per stage.
+#pragma once
+#include "igemm.h"
+
+typedef __bf16 jp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned jp_u32x4 __attribute__((ext_vector_type(4)));
+
+// three-way bf16 split of a pair of floats -> packed words {lo = x, hi = y} of split 0, 1, 2 (round to nearest even)
+__device__ __forceinline__ void jp_split3(float x, float y, unsigned& s0, unsigned& s1, unsigned& s2) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {x, y};
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    v[0] = x - __uint_as_float(h0 << 16);
+    v[1] = y - __uint_as_float(h0 & 0xffff0000u);
+    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    v[0] -= __uint_as_float(h1 << 16);
+    v[1] -= __uint_as_float(h1 & 0xffff0000u);
+    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    s0 = h0; s1 = h1; s2 = h2;
+}
+
+constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring of P9S_AHEAD + 1 slots)
+
+// WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
+// TAPS = 9 (3x3, one-pixel halo) or 1 (1x1).  KGS = 16-channel groups per stage.
+template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) void jp_igemm_p9s_kernel(
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
+    constexpr int NT = 64 * WM * WN;
+    static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
+    constexpr int HALO = TAPS == 9 ? 1 : 0;
+    constexpr int TR = WN * NJ, PR = TR + 2 * HALO, COLS = 32 + 2 * HALO;
+    constexpr int KH = 2 * KGS;                               // k-halves (8 channels each) per stage
+    constexpr int CS = 16 * KGS;
+    constexpr int PLANE = PR * COLS;                          // 16-byte words per (split, k-half)
+    constexpr int ITEMS = KH * PLANE, NQ = (ITEMS + NT - 1) / NT;
+    constexpr int STEPS = TAPS * KGS;                         // (tap, group) steps per stage
+    constexpr int BMT = 64 * WM;
+    __shared__ jp_u32x4 patch[3 * KH * PLANE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int mt, nt;
+    {   // XCD band order, see jp_igemm_kernel
+        const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
+        const int L = blockIdx.x + blockIdx.y * gx;
+        if (L < G * gy) {
+            const int j = L >> 3;
+            mt = j % gy;
+            nt = (L & 7) * (G >> 3) + j / gy;
+        } else {
+            const int i = L - G * gy;
+            mt = i % gy;
+            nt = G + i / gy;
+        }
+    }
+    const int tiles_x = W / 32, tiles_y = H / TR;
+    const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
+    const int y0 = (tr_ / tiles_x) * TR, x0 = (tr_ % tiles_x) * 32;
+    const int m0 = mt * BMT;
+    const long HW = (long)H * W;
+    const float* xin = x + (long)img * C * HW;
+
+    // ---- staging map: item e = t + NT*q -> (k-half, patch row, column); source offset relative to the stage's first
+    // channel (or -1: zero), LDS word index
+    int soff[NQ], loff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = t + NT * q;
+        const int col = e % COLS, rp = e / COLS, pr = rp % PR, kh = rp / PR;
+        int yy = y0 - HALO + pr, xx = x0 - HALO + col;
+        if (REFLECT) { yy = jp_reflect(yy, H); xx = jp_reflect(xx, W); }
+        const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        soff[q] = ok ? (int)(kh * 8 * HW + (long)yy * W + xx) : -1;
+        loff[q] = e < ITEMS ? (kh * PR + pr) * COLS + col : -1;
+    }
+    float rv[NQ][8];
+    auto gload = [&](int stage) {
+        const float* xs = xin + (long)stage * CS * HW;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = soff[q] >= 0;
+            const float* p = xs + (ok ? soff[q] : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[q][k] = ok ? p[(long)k * HW] : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (loff[q] < 0) continue;
+            jp_u32x4 w0, w1, w2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned a, b, c;
+                jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
+                w0[k] = a; w1[k] = b; w2[k] = c;
+            }
+            patch[loff[q]] = w0;
+            patch[KH * PLANE + loff[q]] = w1;
+            patch[2 * KH * PLANE + loff[q]] = w2;
+        }
+    };
+
+    jp_f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- weight stream of this M tile: step u (global over stages) = [split][k-half][row] x 16 B; lane (l31, lhi) of row
+    // block i reads [s][lhi][wm*64 + i*32 + l31].  SGPR buffer resource + constant per-lane offset + scalar step offset.
+    constexpr int SBYTES = 3 * 2 * BMT * 16;                  // bytes per step
+    constexpr int RING = P9S_AHEAD + 1;
+    const long tile_bytes = ((long)NST * STEPS + P9S_AHEAD) * SBYTES;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)(mt + mt_off) * tile_bytes, 0, (int)tile_bytes, 0x00020000);
+    const int avo = (lhi * BMT + wm * 64 + l31) * 16;
+    jp_u32x4 ra[RING][2][3];
+    auto aload = [&](int slot, int step_bytes) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < P9S_AHEAD; ++d) aload(d, d * SBYTES);
+    const jp_u32x4* bp = patch + (lhi * PR + wn * NJ) * COLS + l31;
+
+    // B fragments of step u: [j][split], compile-time LDS offsets (the step loop is fully unrolled)
+    jp_u32x4 rb[2][NJ][3];
+    auto bload = [&](int slot, int u) {
+        const int tap = u / KGS, kg = u % KGS;
+        const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) rb[slot][j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+    };
+#define JP_P9S_MFMA(SA_, SB_)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[u % RING][i][SA_]),          \
+                                                            __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
+
+    gload(0);
+    for (int stage = 0; stage < NST; ++stage) {
+        lstore();
+        __syncthreads();
+        if (stage + 1 < NST) gload(stage + 1);              // next stage's patch: in flight during the MFMAs below
+        const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
+        bload(0, 0);
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            // operands of step u + 1 are requested before the MFMAs of step u issue: weights of step u + AHEAD (the stream
+            // continues into the next stage; the pack carries AHEAD steps of slack), B fragments of step u + 1
+            aload((u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+            if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
+            JP_P9S_MFMA(2, 0);
+            JP_P9S_MFMA(1, 1);
+            JP_P9S_MFMA(0, 2);
+            JP_P9S_MFMA(1, 0);
+            JP_P9S_MFMA(0, 1);
+            JP_P9S_MFMA(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#undef JP_P9S_MFMA
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = img * (int)HW + (y0 + wn * NJ + j) * W + x0 + l31;
+        const typename Epi::St se = epi.col(p);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < M) epi.put(se, m, acc[i][j][r]);
+            }
+        }
+    }
+}
