@@ -169,11 +169,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
     };
 #define JP_P9S_MFMA(SA_, SB_)                                                                                            \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[u % RING][i][SA_]),          \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
                                                             __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
 
-    gload(0);
-    for (int stage = 0; stage < NST; ++stage) {
+    // one stage; PAR = stage parity (compile-time): the weight ring slot of step u is (global step) % RING and STEPS may be odd
+    auto run_stage = [&](auto par_tag, int stage) {
+        constexpr int PAR = decltype(par_tag)::value;
         lstore();
         __syncthreads();
         if (stage + 1 < NST) gload(stage + 1);              // next stage's patch: in flight during the MFMAs below
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
         for (int u = 0; u < STEPS; ++u) {
             // operands of step u + 1 are requested before the MFMAs of step u issue: weights of step u + AHEAD (the stream
             // continues into the next stage; the pack carries AHEAD steps of slack), B fragments of step u + 1
-            aload((u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+            aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
             if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
             __builtin_amdgcn_sched_barrier(0);
             // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
@@ -196,6 +197,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    static_assert(RING == 2, "two stage parities <-> two ring phases");
+    gload(0);
+    for (int stage = 0; stage < NST; stage += 2) {
+        run_stage(std::integral_constant<int, 0>{}, stage);
+        if (stage + 1 < NST) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
     }
 #undef JP_P9S_MFMA
 

@@ -1,39 +1,129 @@
-"""GPU-box aid: TFLOP/s of conv fwd / dgrad / wgrad on the step's main layer shapes (weights pre-packed: ws_state 1).
-   JP_P9=0 python tools/conv_bench.py   vs   JP_P9=1 python tools/conv_bench.py"""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from jperceiver_amd._lib import call, lib
+#!/usr/bin/env python
+"""Per-layer timing of ops.conv2d forward + backward at the step's shapes, per kernel instantiation (the library's own
+HIP-event profile, jp_profile_*), and the error of every result against a float64 CPU reference on a small shape.
 
-SHAPES = [  # N, Cin, H, W, Cout, K, stride, pad, pad_mode
-    (8, 256, 256, 256, 256, 3, 1, 1, 1),
-    (8, 256, 128, 128, 256, 3, 1, 1, 1),
-    (8, 256, 64, 64, 256, 3, 1, 1, 1),
-    (8, 512, 32, 32, 256, 3, 1, 1, 1),
-    (8, 128, 128, 128, 128, 3, 1, 1, 0),
-    (8, 256, 64, 64, 256, 3, 1, 1, 0),
-    (8, 512, 32, 32, 512, 3, 1, 1, 0),
-    (8, 64, 256, 256, 64, 3, 1, 1, 0),
-    (8, 256, 256, 256, 256, 1, 1, 0, 0),
+  python tools/conv_bench.py [--iters 5] [--acc]          (A/B: JP_P9S=0 python tools/conv_bench.py ...)
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from jperceiver_amd import ops, _lib  # noqa: E402
+from jperceiver_amd.ops import Var, Tape, recording  # noqa: E402
+import bench  # noqa: E402
+
+CASES = [
+    # label, N, Cin, H, W, Cout, K, stride, pad, pad_mode
+    ("merge 256->256 3x3 refl @256^2", 8, 256, 256, 256, 256, 3, 1, 1, 1),
+    ("merge 256->256 3x3 refl @128^2", 8, 256, 128, 128, 256, 3, 1, 1, 1),
+    ("merge 256->256 3x3 refl @64^2", 8, 256, 64, 64, 256, 3, 1, 1, 1),
+    ("CRP 256->256 1x1 @256^2", 8, 256, 256, 256, 256, 1, 1, 0, 0),
+    ("CRP 256->256 1x1 @128^2", 8, 256, 128, 128, 256, 1, 1, 0, 0),
+    ("layer1 64->64 3x3 @256^2", 8, 64, 256, 256, 64, 3, 1, 1, 0),
+    ("layer2 128->128 3x3 @128^2", 8, 128, 128, 128, 128, 3, 1, 1, 0),
+    ("layer3 256->256 3x3 @64^2", 8, 256, 64, 64, 256, 3, 1, 1, 0),
+    ("layer4 512->512 3x3 @32^2", 8, 512, 32, 32, 512, 3, 1, 1, 0),
 ]
-L = lib()
-for (N, Cin, H, W, Cout, K, s, p, pm) in SHAPES:
-    OH, OW = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
-    x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, K, K, device="cuda") * 0.05
-    y = torch.empty(N, Cout, OH, OW, device="cuda"); dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.zeros_like(w)
-    wsf = torch.empty(int(L.fn["jp_conv2d_ws_floats"](Cin, Cout, K, 0)), device="cuda")
-    wsd = torch.empty(int(L.fn["jp_conv2d_ws_floats"](Cin, Cout, K, 1)), device="cuda")
-    nws = int(L.fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, K, s, p))
-    wsw = torch.empty(max(nws, 1), device="cuda")
-    flops = 2.0 * N * OH * OW * Cout * Cin * K * K
-    def t(fn, n=5):
-        fn(0); fn(1); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n): fn(1)
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
-    tf = t(lambda st: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, s, p, pm, 2, wsf, st, None))
-    td = t(lambda st: call("jp_conv2d_dgrad", dy, w, dx, N, Cin, H, W, Cout, K, s, p, pm, 0, wsd, st, None))
-    tw = t(lambda st: call("jp_conv2d_wgrad", x, dy, dw, N, Cin, H, W, Cout, K, s, p, pm, 0, wsw if nws else None, nws))
-    print(f"{Cin:4d}->{Cout:4d} k{K} s{s} pm{pm} @{H}x{W}: fwd {tf:7.3f} ms {flops/tf/1e9:6.1f} TF | dgrad {td:7.3f} ms {flops/td/1e9:6.1f} TF | wgrad {tw:7.3f} ms {flops/tw/1e9:6.1f} TF", flush=True)
+
+
+def profiled(fn):
+    L = _lib.lib()
+    assert L.fn["jp_profile_begin"](512) == 0
+    fn()
+    torch.cuda.synchronize()
+    n = L.fn["jp_profile_end"]()
+    buf, fl, ms = ctypes.create_string_buffer(512), ctypes.c_double(), ctypes.c_float()
+    out = []
+    for i in range(n):
+        L.fn["jp_profile_get"](i, ctypes.cast(buf, ctypes.c_void_p), 512, ctypes.cast(ctypes.pointer(fl), ctypes.c_void_p),
+                               ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p))
+        out.append((bench._kernel_name(buf.value.decode()), fl.value, ms.value))
+    return out
+
+
+def run_case(c, iters):
+    label, N, Cin, H, W, Cout, K, s, p, pm = c
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * (Cin * K * K) ** -0.5).cuda()
+    gy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    wv = Var(w, True, torch.zeros_like(w))
+    wv.p = torch.nn.Parameter(w)          # persistent pack, as in the model
+    wv.t = wv.p.data
+    agg = {}
+    for it in range(iters + 2):
+        xv = Var(x, True)
+        tape = Tape()
+
+        def step():
+            with recording(tape):
+                y = ops.conv2d(xv, wv, None, s, p, pm, 0)
+            y.g = gy
+            tape.backward()
+        recs = profiled(step)
+        if it < 2:
+            continue
+        for name, fl, ms in recs:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += fl
+    alg = 2.0 * N * H * W * Cout * Cin * K * K
+    print(f"== {label}: algorithmic {alg / 1e9:.1f} GFLOP per pass")
+    for name, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        per = ms / iters
+        print(f"   {per:8.3f} ms/step  {alg / per / 1e9 if per > 0 else 0:7.1f} alg-TF (if one pass)  exec {fl / iters / per / 1e9:7.1f} TF  x{n // iters}  {name[:110]}")
+
+
+def accuracy():
+    """error vs float64 of fwd / dgrad / wgrad on 8x128x64x64 -> 128 (3x3 zero pad and 1x1): a shape the patch kernels take"""
+    for K, p in ((3, 1), (1, 0)):
+        g = torch.Generator().manual_seed(3)
+        N, Cin, H, W, Cout = 8, 128, 64, 64, 128
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, K, K, generator=g) * (Cin * K * K) ** -0.5
+        gy = torch.randn(N, Cout, H, W, generator=g)
+        xv, wv = Var(x.cuda(), True), Var(w.cuda(), True, torch.zeros_like(w).cuda())
+        tape = Tape()
+
+        def step():
+            with recording(tape):
+                step.y = ops.conv2d(xv, wv, None, 1, p, 0, 0)
+            step.y.g = gy.cuda()
+            tape.backward()
+        print("   kernels:", sorted({r[0] for r in profiled(step)}))
+        y = step.y
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        yd = F.conv2d(xd, wd, None, 1, p)
+        yd.backward(gy.double())
+        xf, wf = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yf = F.conv2d(xf, wf, None, 1, p)
+        yf.backward(gy)
+        for nm, got, ref, cpu in (("fwd", y.t, yd, yf), ("dgrad", xv.g, xd.grad, xf.grad), ("wgrad", wv.g, wd.grad, wf.grad)):
+            e = float((got.cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+            ec = float((cpu.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+            er = float((got.cpu().double() - ref.detach()).pow(2).mean().sqrt() / ref.detach().pow(2).mean().sqrt())
+            ecr = float((cpu.detach().double() - ref.detach()).pow(2).mean().sqrt() / ref.detach().pow(2).mean().sqrt())
+            print(f"   K={K} {nm:5s}: max err / max |ref| = {e:.3e} (CPU ATen fp32: {ec:.3e});  rms rel {er:.3e} (CPU {ecr:.3e})")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--acc", action="store_true")
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    print("JP_P9S =", os.environ.get("JP_P9S", "(default)"))
+    if a.acc:
+        accuracy()
+    for c in CASES:
+        if a.only and a.only not in c[0]:
+            continue
+        run_case(c, a.iters)
