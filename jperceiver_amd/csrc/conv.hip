@@ -24,6 +24,7 @@
 //   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
 #include "igemm_p9.h"
 #include "igemm_p9s.h"
+#include "igemm_w9s.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -1972,13 +1973,21 @@ static bool w9_enabled() {
     static const bool on = [] { const char* e = getenv("JP_W9"); return !(e && e[0] == '0'); }();
     return on;
 }
-struct W9Plan { int splits, tps, ntiles, slices, narrow; long need; };
+// W9S (igemm_w9s.h): the wide variant (> 64 output channels) with split-bf16 products on the bf16 matrix pipe; JP_W9S=0
+// keeps the exact-fp32 W9 kernel.  Its pixel tiles are W9S_TR rows high.
+constexpr int W9S_TR = 2;
+static bool w9s_enabled() {
+    static const bool on = [] { const char* e = getenv("JP_W9S"); return !(e && e[0] == '0'); }();
+    return on;
+}
+struct W9Plan { int splits, tps, ntiles, slices, narrow, split_mfma; long need; };
 static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W9Plan* p) {
     if (!w9_enabled() || KH != 3 || stride != 1 || pad != 1 || W % 32 || H % W9_TR || Cm < 64 || Cm % 64 || Cout < 48 ||
         (long)N * Cout * H * W * 4 >= (1L << 31))
         return false;
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
-    const int ntiles = N * (H / W9_TR) * (W / 32), kg = narrow ? 2 : 1;
+    p->split_mfma = !narrow && w9s_enabled();
+    const int ntiles = N * (H / (p->split_mfma ? W9S_TR : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
     const long out_tiles = (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128), per = (long)Cout * 9 * Cm;
     static const long wgs = [] { const char* e = getenv("JP_W9_WGS"); return e ? atol(e) : 256L; }();
     long sp = std::max<long>(1, std::min<long>(wgs / std::max<long>(1, out_tiles), ntiles / 2));
@@ -1995,9 +2004,20 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
 }
 template <int MW, int KG, bool REFLECT>
 const char* w9_tag() { return __PRETTY_FUNCTION__; }
+template <int TR, bool REFLECT>
+const char* w9s_tag() { return __PRETTY_FUNCTION__; }
 template <bool REFLECT>
 static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
                       const W9Plan& p, hipStream_t st) {
+    if (p.split_mfma) {
+        // executed FLOPs: 6 bf16 MFMA products per fp32 product
+        jp_prof_before(w9s_tag<W9S_TR, REFLECT>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+        dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
+        hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W, p.ntiles,
+                           p.tps, (int)((long)N * Cout * H * W * 4));
+        jp_prof_after(st);
+        return;
+    }
     jp_prof_before(p.narrow ? w9_tag<1, 2, REFLECT>() : w9_tag<2, 1, REFLECT>(), 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
     const int dyb = (int)((long)N * Cout * H * W * 4);          // < 2^31 (w9_plan): dY is addressed through a buffer resource
     if (p.narrow) {

@@ -1,0 +1,215 @@
+// "W9S" patch kernel: WEIGHT GRADIENT of a 3x3 stride-1 pad-1 convolution with every fp32 product formed on the BF16 matrix
+// pipe from three-way splits of both operands (igemm_p9s.h has the arithmetic argument: fp32 in / out / accumulate,
+// fp32-equivalent accuracy, 6 MFMAs of 32 cycles instead of 8 of 64).
+//     dW[co][ci][ty][tx] = sum over pixels p of  dY[co][p] * Xpad[ci][p + (ty-1, tx-1)]
+// Per tap a GEMM with M = Cout, N = Cin and K = pixels; one `v_mfma_f32_32x32x16_bf16` takes 16 consecutive pixels of one
+// image row as its K group, a lane holding the 8 pixels 8*(lane>>5) .. +7 of its row (A: output channel) / column (B: input
+// channel).
+//   A (dY) comes STRAIGHT FROM GLOBAL MEMORY: a lane's 8 pixels are two aligned 16-byte buffer loads of its channel row
+//     (one K group ahead); they are split in registers (~44 VALU operations per 54 MFMAs, hidden behind the other wave of
+//     the SIMD).
+//   B (X) is staged once per pixel tile -- padding resolved, each value split ONCE -- as bf16 [split][32-channel block]
+//     [patch pixel][32 channels] (64 bytes per pixel), and read with the LDS TRANSPOSE read `ds_read_b64_tr_b16`: 16 lanes
+//     fetch a [4 pixels][16 channels] block and each receives the 4 pixels of ITS channel, so a tap shift is just another
+//     patch pixel (an immediate offset) and no element is ever re-laid out per tap.  The 8-byte channel quads of a pixel
+//     row are XOR-swizzled with (patch column & 7): conflict-free transpose reads, 2-way conflicts on the (rare) writes.
+// Workgroup: 8 waves = 4 blocks of 32 output channels x 2 blocks of 32 input channels; a wave owns ALL 9 taps of its
+// (32 x 32) block pair: nine 32x32 accumulators, 54 MFMAs per K group for 2 dY loads and 54 transpose reads.
+// Output: split-K partial sums ws[split][m][tap*Cm + ci] (wgrad_reduce kernels fold them into dW), as igemm_w9.h.
+// Preconditions (host-checked): W % 32 == 0, H % TR == 0, Cm % 64 == 0.
+#pragma once
+#include "igemm_p9s.h"
+
+typedef short jp_s16x4 __attribute__((ext_vector_type(4)));
+typedef short jp_s16x8 __attribute__((ext_vector_type(8)));
+
+template <int TR, bool REFLECT>
+__global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
+                                                             int ntiles, int tiles_per_split, int dy_bytes) {
+    constexpr int NT = 512, PR = TR + 2, PC = 34;
+    constexpr int SLOTS = PR * PC;                 // patch pixels
+    constexpr int CBP = SLOTS * 64;                // bytes per (split, channel block) plane
+    constexpr int SPL = 2 * CBP;                   // bytes per split
+    constexpr int ITEMS = SLOTS * 16, NQ = (ITEMS + NT - 1) / NT;      // (pixel, channel quad) items, rounds per thread
+    constexpr int KGR = TR * 2;                    // K groups (16 pixels) per tile
+    static_assert(2 * SPL + ((TR + 1) * PC + 18) * 64 + 256 < 65536, "transpose-read immediates must fit 16 bits");
+    __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ab = wave & 3, cb = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int mt, nt, zs;
+    {   // every XCD owns whole K slices, see jp_wgrad_w9_kernel
+        const int gx = gridDim.x, gy = gridDim.y, T = gx * gy, SG = gridDim.z & ~7;
+        const int L3 = blockIdx.x + blockIdx.y * gx + blockIdx.z * T;
+        int tile;
+        if (L3 < SG * T) {
+            const int idx = L3 >> 3;
+            zs = (idx / T) * 8 + (L3 & 7);
+            tile = idx % T;
+        } else {
+            const int r = L3 - SG * T;
+            zs = SG + r / T;
+            tile = r % T;
+        }
+        mt = tile % gy;
+        nt = tile / gy;
+    }
+    const int m0 = mt * 128, c0 = nt * 64;
+    const int T0 = zs * tiles_per_split, T1 = min(ntiles, T0 + tiles_per_split);
+    const int tiles_x = W / 32, tiles_img = tiles_x * (H / TR);
+    const long HW = (long)H * W;
+    auto tile_org = [&](int T, int& img, int& y0, int& x0) {
+        const int Tc = min(T, ntiles - 1);
+        img = Tc / tiles_img;
+        const int r = Tc - img * tiles_img;
+        y0 = (r / tiles_x) * TR;
+        x0 = (r % tiles_x) * 32;
+    };
+
+    // ---- A: dY rows of this lane (channel clamped; rows >= Cout are dropped in the epilogue), 8 pixels per K group
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    const int arow = (min(m0 + ab * 32 + l31, Cout - 1) * (int)HW + 8 * lhi) * 4;
+    jp_u32x4 araw[2][2];
+    auto aload = [&](int slot, int tbase, int g) {          // K group g of the tile whose dY element offset (channel 0) is tbase
+        const int so = __builtin_amdgcn_readfirstlane((tbase + (g / 2) * W + 16 * (g % 2)) * 4);
+        araw[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(drs, arow, so, 0);
+        araw[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(drs, arow + 16, so, 0);
+    };
+
+    // ---- B: per-lane byte bases of the transpose reads.  Lane (g16 = lane>>4, r = (lane&15)>>2, q = lane&3) addresses pixel row
+    // r of the [4 pixels][16 channels] block of channel half g16 & 1; its channel quad Q = 4*(g16&1) + q sits at position
+    // Q ^ (patch column & 7), patch column = 16*(K-group half) + tx + 4*rd + 8*lhi + r  ->  mask (tx + 4*rd + r) & 7
+    const int rr = (lane & 15) >> 2, Qq = 4 * ((lane >> 4) & 1) + (lane & 3);
+    int bbase[3][2];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+            bbase[tx][rd] = cb * CBP + (8 * lhi + rr) * 64 + ((Qq ^ ((tx + 4 * rd + rr) & 7)) * 8);
+    auto bread = [&](int ty, int tx, int g, int s) -> jp_bf16x8 {
+        const int imm = s * SPL + ((g / 2 + ty) * PC + 16 * (g % 2) + tx) * 64;
+        const jp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx][0] + imm));
+        const jp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx][1] + imm + 256));
+        const jp_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(jp_bf16x8, v);
+    };
+
+    // ---- staging: item e = t + NT*q -> (patch column, patch row, channel quad Qd of the 64 channels); lanes run along
+    // the patch columns (coalesced loads), each item = 4 channels of one pixel -> three 8-byte LDS words
+    float rv[NQ][4];
+    auto gload = [&](int T) {
+        int img, y0, x0;
+        tile_org(T, img, y0, x0);
+        const float* xc = x + ((long)img * Cx + c0) * HW;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = t + NT * q;
+            const int pcol = e % PC, rest = e / PC, prow = rest % PR, Qd = rest / PR;
+            int yy = y0 - 1 + prow, xx = x0 - 1 + pcol;
+            if (REFLECT) { yy = jp_reflect(yy, H); xx = jp_reflect(xx, W); }
+            const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* p = xc + (long)(4 * Qd) * HW + (ok ? (long)yy * W + xx : 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[q][k] = ok ? p[(long)k * HW] : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = t + NT * q;
+            if (e >= ITEMS) continue;
+            const int pcol = e % PC, rest = e / PC, prow = rest % PR, Qd = rest / PR;
+            const int off = (Qd >> 3) * CBP + (prow * PC + pcol) * 64 + (((Qd & 7) ^ (pcol & 7)) * 8);
+            unsigned a0, a1, a2, b0, b1, b2;
+            jp_split3(rv[q][0], rv[q][1], a0, a1, a2);
+            jp_split3(rv[q][2], rv[q][3], b0, b1, b2);
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u2*>(patch + off) = u2{a0, b0};
+            *reinterpret_cast<u2*>(patch + SPL + off) = u2{a1, b1};
+            *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a2, b2};
+        }
+    };
+
+    jp_f32x16 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    if (T0 < T1) {
+        int img, y0, x0;
+        tile_org(T0, img, y0, x0);
+        int tb = (img * Cout) * (int)HW + y0 * W + x0;
+        aload(0, tb, 0);
+        gload(T0);
+        for (int T = T0; T < T1; ++T) {
+            lstore();
+            __syncthreads();
+            gload(T + 1);                                           // next tile's patch: in flight during the MFMAs below
+            tile_org(T + 1, img, y0, x0);
+            const int tbn = (img * Cout) * (int)HW + y0 * W + x0;
+#pragma unroll
+            for (int g = 0; g < KGR; ++g) {
+                // dY of the NEXT K group (of this or the next tile) is requested now; this group's raw values are split
+                if (g + 1 < KGR) aload((g + 1) & 1, tb, g + 1);
+                else aload((g + 1) & 1, tbn, 0);
+                jp_u32x4 sa[3];
+                {
+                    const jp_u32x4 lo = araw[g & 1][0], hi = araw[g & 1][1];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        unsigned s0, s1, s2;
+                        jp_split3(__uint_as_float(lo[2 * k]), __uint_as_float(lo[2 * k + 1]), s0, s1, s2);
+                        sa[0][k] = s0; sa[1][k] = s1; sa[2][k] = s2;
+                        jp_split3(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), s0, s1, s2);
+                        sa[0][2 + k] = s0; sa[1][2 + k] = s1; sa[2][2 + k] = s2;
+                    }
+                }
+                // B fragments are read one tap ahead of the MFMAs that use them (compile-time offsets: everything is unrolled);
+                // the scheduling barriers keep the compiler from hoisting a whole K group's reads (register pressure)
+                jp_bf16x8 bq[2][3];
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) bq[0][s_] = bread(0, 0, g, s_);
+                const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[1]),
+                                a2 = __builtin_bit_cast(jp_bf16x8, sa[2]);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (tap + 1 < 9) {
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) bq[(tap + 1) & 1][s_] = bread((tap + 1) / 3, (tap + 1) % 3, g, s_);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const jp_bf16x8 b0 = bq[tap & 1][0], b1 = bq[tap & 1][1], b2 = bq[tap & 1][2];
+                    // the six products with split index sum <= 2, smallest terms first
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tap], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            tb = tbn;
+            __syncthreads();
+        }
+    }
+
+    // ---- partial tile -> ws[zs][m][tap*Cm + ci]; C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const long Np = 9L * Cm;
+    float* wz = ws + (long)zs * Cout * Np;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const long n = (long)tap * Cm + c0 + cb * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < Cout) wz[(long)m * Np + n] = acc[tap][r];
+        }
+    }
+}
