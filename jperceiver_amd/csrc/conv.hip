@@ -25,6 +25,7 @@
 #include "igemm_p9.h"
 #include "igemm_p9s.h"
 #include "igemm_w9s.h"
+#include "igemm_p9us.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -46,7 +47,7 @@ __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 // The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
 // launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
 // tiny launches per step become one.
-enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7 };
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7, PACK_SPLITSEG = 8 };
 struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
     const float* w;
     float* wp;
@@ -151,6 +152,33 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                 const int cc = c + k;
                 const int co = for_dgrad ? cc : m, ci = for_dgrad ? m : cc;
                 v[k] = cc < red ? w[((size_t)co * Cin + ci) * KHW + tap] : 0.f;
+            }
+            unsigned s0, s1, s2;
+            jp_split3(v[0], v[1], s0, s1, s2);
+            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+        }
+        case PACK_SPLITSEG: {  // p = Cout, Cin, c_off, C, up: one channel segment of an iconv bank as bf16 three-way splits in the
+                               // fragment order of the P9US kernel (igemm_p9us.h): [class (up only)][M tile of 128][step = (16-channel
+                               // stage, tap | slot)][split][k-half][row 128][4 words]; word w4 = channels stage*16 + khalf*8 + 2*w4 + {0,1}
+            const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], up = p[4];
+            const int T = up ? 4 : 9, MT = Cout / 128;
+            const long tile = (long)((C + 15) / 16) * T * 3072;
+            const int cm = (int)(i / tile);
+            if (cm >= (up ? 4 : 1) * MT) return 0.f;            // slack words behind the last stream
+            long t = i - (long)cm * tile;
+            const int cls = cm / MT, mt = cm - cls * MT;
+            const int w4 = (int)(t & 3); t >>= 2;
+            const int row = (int)(t & 127); t >>= 7;
+            const int khalf = (int)(t & 1); t >>= 1;
+            const int sp = (int)(t % 3);
+            const int U = (int)(t / 3);
+            const int stage = U / T, tap = U - stage * T;
+            const int c = stage * 16 + khalf * 8 + 2 * w4, co = mt * 128 + row;
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float* wc = w + ((size_t)co * Cin + c_off + c + k) * 9;
+                v[k] = (c + k < C && co < Cout) ? (up ? pack_slot_sum(wc, cls * 4 + tap) : wc[tap]) : 0.f;
             }
             unsigned s0, s1, s2;
             jp_split3(v[0], v[1], s0, s1, s2);
@@ -1852,6 +1880,12 @@ inline bool p9u_enabled() {
 }
 template <class E>
 const char* p9u_tag() { return __PRETTY_FUNCTION__; }
+inline bool p9us_enabled() {
+    static const int on = [] { const char* e = getenv("JP_P9US"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+template <class E>
+const char* p9us_tag() { return __PRETTY_FUNCTION__; }
 // channels per M tile of a bank with `rows` rows: 64 x (8x32 px), 128 x (4x32 px), or -- 3x3 banks whose row count is a
 // multiple of 256 -- 256 x (4x32 px) on 8 waves (JP_P9_M256=0 turns that variant off)
 inline bool p9_m256() {
@@ -2150,7 +2184,9 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
     if (which == 0 && Cin <= 8) return (long)(Cout + 256) * pad32(KH * KH * 8);   // row-major pack of the stem path
-    if (which == 0) return Cin >= 16 ? std::max(((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96),
+    if (which == 0) return Cin >= 16 ? std::max(std::max(((long)std::max(KH * KH, 16) * Cout + 256) * (pad32(Cin) + 96),
+                                                         // P9US pack: <= 16 steps per 16 channels (4 classes x 4 slots) + D + slack
+                                                         KH == 3 ? (long)jp_cdiv(Cout, 128) * ((long)jp_cdiv(Cin, 16) * 16 + 10) * 3072 : 0L),
                                                 KH == 3 ? p9_alloc_floats(Cout, pad32(Cin)) : (KH == 1 ? p9_alloc_floats(Cout, pad32(Cin), 1) : 0L)) : 0;
     // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled
     // segment, plus the fragment-order pack of the P9 main pass behind them
@@ -2206,6 +2242,22 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         !up0 && c1 >= 32 && c1 % 32 == 0 && up1 && c2 <= 8 && !(c2 && up2) && Cout % 128 == 0 && H % 4 == 0 && W % 64 == 0 &&
         (long)(Cout / 128) * N * (H / 4) * (W / 64) >= 128 && p9u_enabled()) {
         const int MT = Cout / 128;
+        if (p9us_enabled()) {
+            // P9US: the same tiles on the bf16 matrix pipe (three-way split products, igemm_p9us.h)
+            const long fS = (long)MT * (c0 / 16) * 9 * 3072, fU = 4L * MT * (c1 / 16) * 4 * 3072, fD = c2 ? (long)MT * 9 * 3072 : 0;
+            if (!ws_state) {
+                do_pack(PACK_SPLITSEG, w, ws, fS, Cout, Cin, 0, c0, 0, 0, st);
+                do_pack(PACK_SPLITSEG, w, ws + fS, fU, Cout, Cin, c0, c1, 1, 0, st);
+                if (c2) do_pack(PACK_SPLITSEG, w, ws + fS + fU, fD, Cout, Cin, c0 + c1, c2, 0, 0, st);
+                // (the kernel's last weight prefetch reads one step past the streams: inside the scratch, never used)
+            }
+            jp_prof_before(p9us_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
+            dim3 grid(N * (H / 4) * (W / 64), MT, 1);
+            hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi>), grid, dim3(512), 0, st, reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e,
+                               Cout, c0, c1, c2, H, W);
+            jp_prof_after(st);
+            JP_LAUNCH_CHECK();
+        }
         const long fS = (long)MT * (c0 / 32) * 36 * 1024, fU = 4L * MT * (c1 / 32) * 16 * 1024, fD = (long)MT * 9 * 1024;
         if (!ws_state) {
             do_pack(PACK_FRAGSEG, w, ws, fS, Cout, Cin, 0, c0, 16, 0, st);

@@ -44,6 +44,12 @@ __device__ __forceinline__ void jp_split3(float x, float y, unsigned& s0, unsign
     s0 = h0; s1 = h1; s2 = h2;
 }
 
+// gather load: SGPR buffer resource + per-lane byte offset (a loop-invariant 32-bit VGPR) + wave-uniform byte offset (SGPR):
+// no 64-bit per-lane address arithmetic for the compiler to hoist out of the stage loop (it spilled dozens of pointer pairs)
+__device__ __forceinline__ float jp_gather(const __amdgpu_buffer_rsrc_t& r, unsigned lane_bytes, int uniform_bytes) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_bytes, 0));
+}
+
 constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring of P9S_AHEAD + 1 slots)
 
 // WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
@@ -90,7 +96,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
 
     // ---- staging map: item e = t + NT*q -> (k-half, patch row, column); source offset relative to the stage's first
     // channel (or -1: zero), LDS word index
-    int soff[NQ], loff[NQ];
+    unsigned soff[NQ];                                       // byte offset inside the image, bit 0 set = zero (padding / no item)
+    int loff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = t + NT * q;
@@ -98,18 +105,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
         int yy = y0 - HALO + pr, xx = x0 - HALO + col;
         if (REFLECT) { yy = jp_reflect(yy, H); xx = jp_reflect(xx, W); }
         const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        soff[q] = ok ? (int)(kh * 8 * HW + (long)yy * W + xx) : -1;
+        soff[q] = ok ? (unsigned)(kh * 8 * HW + (long)yy * W + xx) * 4u : 1u;
         loff[q] = e < ITEMS ? (kh * PR + pr) * COLS + col : -1;
     }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)((long)C * HW * 4), 0x00020000);
     float rv[NQ][8];
     auto gload = [&](int stage) {
-        const float* xs = xin + (long)stage * CS * HW;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const bool ok = soff[q] >= 0;
-            const float* p = xs + (ok ? soff[q] : 0);
+        for (int k = 0; k < 8; ++k) {
+            const int ub = __builtin_amdgcn_readfirstlane((int)(((long)stage * CS + k) * HW * 4));
 #pragma unroll
-            for (int k = 0; k < 8; ++k) rv[q][k] = ok ? p[(long)k * HW] : 0.f;
+            for (int q = 0; q < NQ; ++q) {
+                const float v = jp_gather(xrs, soff[q] & ~1u, ub);
+                rv[q][k] = (soff[q] & 1u) ? 0.f : v;
+            }
         }
     };
     auto lstore = [&]() {

@@ -54,10 +54,16 @@ class kernel_tags:
 
 
 def _split_name(w):
-    """jp_igemm_p9_kernel<WM, WN, REFLECT, REV, Epi, TAPS, CPB> -> its split-bf16 twin (igemm_p9s.h), which the library
-    launches for the same tiles unless JP_P9S=0: jp_igemm_p9s_kernel<WM, WN, 2, REFLECT, REV, Epi, TAPS, KGS>."""
+    """Names of the split-bf16 twins the library launches for the same tiles unless JP_P9S / JP_W9S / JP_P9US = 0:
+    jp_igemm_p9_kernel<WM, WN, REFLECT, REV, Epi, TAPS, CPB> -> jp_igemm_p9s_kernel<WM, WN, 2, REFLECT, REV, Epi, TAPS, KGS>
+    (igemm_p9s.h), the wide W9 -> jp_wgrad_w9s_kernel<TR, REFLECT> (igemm_w9s.h), P9U -> P9US (igemm_p9us.h)."""
     import os
     import re
+    mw = re.fullmatch(r"jp_wgrad_w9_kernel<2, 2, 1, (\w+)>", w)
+    if mw is not None and os.environ.get("JP_W9S", "1") != "0":
+        return f"jp_wgrad_w9s_kernel<2, {mw.group(1)}>"
+    if w == "jp_igemm_p9u_kernel<FwdEpi>" and os.environ.get("JP_P9US", "1") != "0":
+        return "jp_igemm_p9us_kernel<FwdEpi>"
     m = re.fullmatch(r"jp_igemm_p9_kernel<(\d), (\d), (\w+), (\w+), (\w+), (\d), \d>", w)
     if m is None or os.environ.get("JP_P9S", "1") == "0":
         return w
