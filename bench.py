@@ -15,11 +15,11 @@ frames [0,-1,1], type static, loss_sum 3, occ 256, fp32, 8 images per GPU.
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     — the BY-TIME DOMINANT kernel of one instrumented step: every implicit-GEMM dispatch is bracketed by HIP
                  events inside the library, on the stream it is launched on (jp_profile_*); dominant = the kernel
-                 instantiation with the largest summed duration.  achieved = ALGORITHMIC FLOPs of the conv layers it
-                 computed (2*N*OH*OW*Cout*Cin*k^2 per launch) / its measured time; peak 157.3 TFLOP/s (dense fp32 MFMA).
-                 Step-level figures ride along: step_frac_fp32 = 1.63 TFLOP*B / t_step / 157.3 TF and achieved_hbm =
-                 (9.7 GB*B + 2.3 GB) / t_step, plus the conv FLOPs actually counted in the step and
-                 the aggregate rate of all igemm kernels.
+                 instantiation with the largest summed duration.
+                 A kernel is priced on the pipe it runs on: EXECUTED MFMA FLOPs / time against 2.5 PFLOP/s (dense bf16) for the
+                 split-product patch kernels (P9S / W9S / P9US: 6 bf16 products per fp32 product), against 157.3 TFLOP/s for
+                 the exact-fp32 MFMA kernels.  Step-level figures ride along: step_fp32_equiv_tflops = 1.63 TFLOP*B / t_step,
+                 achieved_hbm = (9.7 GB*B + 2.3 GB) / t_step, and per-pipe aggregates of all igemm kernels.
   families     — per-kernel-family time / rate table of that step (also written to $JP_BENCH_TABLE or
                  gpurun_out/bench_families.json).
   cpu_baseline — the oracle (PyTorch-CPU port of the reference step) timed on this host's cores at B=1, SAME flags as
@@ -42,7 +42,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_FP32_TF, PEAK_HBM_TBS = 157.3, 8.0
+PEAK_FP32_TF, PEAK_BF16_TF, PEAK_HBM_TBS = 157.3, 2500.0, 8.0     # dense fp32-MFMA / dense bf16-MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
+SPLIT_TAGS = ("p9s_tag", "w9s_tag", "p9us_tag")     # kernels on the bf16 pipe: 6 bf16 MFMA products per fp32 product (igemm_p9s.h)
 
 # BASELINE.json `configs`, in order.  Per-GPU batch = BASELINE.json's figure (the reference's files carry IMGS_PER_GPU = 1/3/3/3/1
 # for a 24 GB card; /root/reference/config/<name>.py:3-6 give frames / size, :19 the type, :47-55 loss_sum / split).  The
@@ -259,6 +260,9 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 6 bf16-MFMA "
+                          "products of exact 3-way bf16 operand splits (igemm_p9s.h): error vs float64 <= the fp32 FMA chain's "
+                          "(tests/test_split_accuracy_gpu.py); JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
             "config": {"workload": f"{cfg['name']}: {HW}x{HW}, frames {frames}, {B} images/GPU, type {cfg['type']}, "
                                    f"loss_sum {cfg['loss_sum']}, occ {HW // 4}, full-res frame {cfg['full_hw'][0]}x{cfg['full_hw'][1]}",
                        "config_index": args.config, "global_batch": B * world,
@@ -361,7 +365,7 @@ def _kernel_name(tag):
     if "p9u_tag" in tag:
         return f"jp_igemm_p9u_kernel<{kv['E']}>"
     if "w9s_tag" in tag:
-        return f"jp_wgrad_w9s_kernel<{kv['TR']}, {kv['REFLECT']}>"
+        return f"jp_wgrad_w9s_kernel<{kv['TR']}, {kv['REFLECT']}, {kv.get('KG', '1')}>"
     if "w9_tag" in tag:
         return f"jp_wgrad_w9_kernel<{kv['MW']}, 2, {kv['KG']}, {kv['REFLECT']}>"
     if "launch_r3" in tag:
@@ -413,7 +417,10 @@ def measure_roofline(runner, batch, B, t_step, rank):
                                     ctypes.cast(ctypes.pointer(msv), ctypes.c_void_p))
         if rc != 0:
             raise RuntimeError(L.last_error())
-        recs.append([buf.value.decode(), fl.value, msv.value, 0.0, 0.0])       # + algorithmic FLOPs / bytes
+        tag = buf.value.decode()
+        split = any(k in tag for k in SPLIT_TAGS)
+        # [tag, executed MFMA FLOPs, ms, algorithmic FLOPs, algorithmic bytes, fp32-equivalent executed FLOPs]
+        recs.append([tag, fl.value, msv.value, 0.0, 0.0, fl.value / 6.0 if split else fl.value])
     fam = collections.OrderedDict()
     by_name = {}
     conv_alg = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
@@ -431,28 +438,29 @@ def measure_roofline(runner, batch, B, t_step, rank):
                 # The layer's algorithmic work goes to its main kernel(s); border / fold passes get none.  Plain GEMM
                 # kernels are credited what they execute (2*M*N*K, never more than the layer's nominal FLOPs); only the
                 # parity-class kernels (pre-summed weight slots: fewer executed than nominal FLOPs) get the remainder.
-                big = max(r[1] for r in sub)
-                main = [r for r in sub if r[1] >= 0.1 * big]
-                par = [r for r in main if re.search(r"FwdBP|WgradBP|DgradUPB|DgradS2B|p9u_tag", r[0]) and "p9_tag" not in r[0]]
+                # (r[5] = executed FLOPs in fp32 products: a split-bf16 kernel issues 6 bf16 MFMA FLOPs per fp32 FLOP)
+                big = max(r[5] for r in sub)
+                main = [r for r in sub if r[5] >= 0.1 * big]
+                par = [r for r in main if re.search(r"FwdBP|WgradBP|DgradUPB|DgradS2B|p9u_tag|p9us_tag", r[0]) and "p9_tag" not in r[0]]
                 plain = [r for r in main if r not in par]
                 left = shp[1]
-                tot_plain = sum(r[1] for r in plain)
+                tot_plain = sum(r[5] for r in plain)
                 for r in plain:
-                    a = r[1] if (par or tot_plain <= shp[1]) else shp[1] * r[1] / tot_plain
+                    a = r[5] if (par or tot_plain <= shp[1]) else shp[1] * r[5] / tot_plain
                     a = min(a, left)
                     r[3] += a
                     left -= a
-                tot_par = sum(r[1] for r in par)
+                tot_par = sum(r[5] for r in par)
                 for r in par:
-                    r[3] += max(left, 0.0) * r[1] / tot_par
-                tot = sum(r[1] for r in main)
+                    r[3] += max(left, 0.0) * r[5] / tot_par
+                tot = sum(r[5] for r in main)
                 for r in main:
-                    r[4] += shp[2] * r[1] / tot
+                    r[4] += shp[2] * r[5] / tot
         d = fam.setdefault(f, {"calls": 0, "ms": 0.0})
         d["calls"] += 1
         d["ms"] += t
     kern = {}
-    for tag, flx, msx, alg, byt in recs:
+    for tag, flx, msx, alg, byt, _f32 in recs:
         k = kern.setdefault(tag, {"launches": 0, "ms": 0.0, "executed_flop": 0.0, "algorithmic_flop": 0.0, "alg_bytes": 0.0})
         k["launches"] += 1
         k["ms"] += msx
@@ -465,8 +473,17 @@ def measure_roofline(runner, batch, B, t_step, rank):
     dom_tag, dom = max(cand.items(), key=lambda kv: kv[1]["ms"])
     ig_ms = sum(k["ms"] for k in kern.values())
     ig_alg = sum(k["algorithmic_flop"] for k in kern.values())
-    ach = dom["algorithmic_flop"] / (dom["ms"] * 1e-3) / 1e12
+    # the dominant kernel is priced on the pipe it runs on: EXECUTED MFMA FLOPs / time against that pipe's dense peak -- bf16
+    # (2.5 PF) for the split-product kernels, fp32 (157.3 TF) for the exact-fp32 ones; parity-class kernels execute fewer
+    # FLOPs than the layer's nominal count and are priced on what they execute, so nothing can exceed its peak
+    dom_split = any(k in dom_tag for k in SPLIT_TAGS)
+    peak = PEAK_BF16_TF if dom_split else PEAK_FP32_TF
+    ach = dom["executed_flop"] / (dom["ms"] * 1e-3) / 1e12
     name = _kernel_name(dom_tag)
+    ms_split = sum(k["ms"] for t, k in kern.items() if any(x in t for x in SPLIT_TAGS))
+    ex_split = sum(k["executed_flop"] for t, k in kern.items() if any(x in t for x in SPLIT_TAGS))
+    ms_f32 = sum(k["ms"] for t, k in kern.items() if not any(x in t for x in SPLIT_TAGS))
+    ex_f32 = sum(k["executed_flop"] for t, k in kern.items() if not any(x in t for x in SPLIT_TAGS))
     traffic = None
     try:    # HBM/fabric bytes per launch of this kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
         import glob
@@ -478,24 +495,32 @@ def measure_roofline(runner, batch, B, t_step, rank):
     except Exception:
         pass
     conv_total = sum(conv_alg.values())
-    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TF, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_TF, 4), "traffic": traffic,
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic,
             "kernel": name + " — by-time dominant igemm instantiation of the step",
+            "pipe": ("bf16 MFMA, fp32 products as 6 bf16 products of 3-way operand splits (fp32 in/out/accumulate)" if dom_split
+                     else "fp32 MFMA (exact)"),
             "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
             "total_ms_per_step": round(dom["ms"], 3),
             "avg_launch_gflop": round(dom["algorithmic_flop"] / dom["launches"] / 1e9, 2),
-            "executed_tflops": round(dom["executed_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+            "executed_tflops": round(ach, 2),
+            # the same kernel in fp32 FLOPs of the layer it computes (what an fp32-MFMA kernel would be priced on)
+            "algorithmic_fp32_tflops": round(dom["algorithmic_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
             "algorithmic_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
-            # step level: the step is fp32-MFMA-bound, HBM fraction is given so it is not misread
-            "step_frac_fp32": round(1.63e12 * B / t_step / (PEAK_FP32_TF * 1e12), 4),
+            # step level (1.63 TFLOP / image-step of fp32 convolution work).  Since the patch kernels moved to
+            # the bf16 pipe the fp32-MFMA peak is no longer the step's bound: the ratio is given as a speed-up over it
+            "step_fp32_equiv_tflops": round(1.63e12 * B / t_step / 1e12, 2),
+            "step_vs_fp32_mfma_peak": round(1.63e12 * B / t_step / (PEAK_FP32_TF * 1e12), 4),
             "step_conv_tflop_counted": round(conv_total / 1e12, 3),
-            "step_achieved_fp32_tflops": round(conv_total / t_step / 1e12, 2),
-            "step_frac_fp32_counted": round(conv_total / t_step / (PEAK_FP32_TF * 1e12), 4),
             "achieved_hbm_tbs": round((9.7e9 * B + 2.3e9) / t_step / 1e12, 3),
             "achieved_hbm_frac": round((9.7e9 * B + 2.3e9) / t_step / (PEAK_HBM_TBS * 1e12), 4),
-            # all implicit-GEMM kernels of the step together (flat keys: the driver's parser keeps scalars only)
-            "igemm_ms_per_step": round(ig_ms, 2), "igemm_tflops": round(ig_alg / (ig_ms * 1e-3) / 1e12, 2),
-            "igemm_frac": round(ig_alg / (ig_ms * 1e-3) / 1e12 / PEAK_FP32_TF, 4),
+            # all implicit-GEMM kernels of the step (flat keys: the driver's parser keeps scalars only), per pipe: executed MFMA
+            # TFLOP/s against that pipe's dense peak
+            "igemm_ms_per_step": round(ig_ms, 2), "igemm_fp32_equiv_tflops": round(ig_alg / (ig_ms * 1e-3) / 1e12, 2),
+            "bf16_pipe_ms": round(ms_split, 2), "bf16_pipe_executed_tflops": round(ex_split / max(ms_split, 1e-9) / 1e9, 1),
+            "bf16_pipe_frac": round(ex_split / max(ms_split, 1e-9) / 1e9 / PEAK_BF16_TF, 4),
+            "fp32_pipe_ms": round(ms_f32, 2), "fp32_pipe_executed_tflops": round(ex_f32 / max(ms_f32, 1e-9) / 1e9, 1),
+            "fp32_pipe_frac": round(ex_f32 / max(ms_f32, 1e-9) / 1e9 / PEAK_FP32_TF, 4),
             # HBM-bound kernel families of the same (single-stream) instrumented step
             "hbm_kernels_ms": round(sum(v["ms"] for k, v in fam.items() if not k.startswith("conv ")), 2)}
     table = {"step_ms_timed": round(t_step * 1e3, 2),

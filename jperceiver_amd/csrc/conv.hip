@@ -2010,6 +2010,7 @@ static bool w9_enabled() {
 // W9S (igemm_w9s.h): the wide variant (> 64 output channels) with split-bf16 products on the bf16 matrix pipe; JP_W9S=0
 // keeps the exact-fp32 W9 kernel.  Its pixel tiles are W9S_TR rows high.
 constexpr int W9S_TR = 2;
+constexpr int W9S_TRN = 4;     // narrow variant (<= 64 output channels): two K groups of 2 rows each
 static bool w9s_enabled() {
     static const bool on = [] { const char* e = getenv("JP_W9S"); return !(e && e[0] == '0'); }();
     return on;
@@ -2020,8 +2021,8 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
         (long)N * Cout * H * W * 4 >= (1L << 31))
         return false;
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
-    p->split_mfma = !narrow && w9s_enabled();
-    const int ntiles = N * (H / (p->split_mfma ? W9S_TR : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
+    p->split_mfma = w9s_enabled();
+    const int ntiles = N * (H / (p->split_mfma ? (narrow ? W9S_TRN : W9S_TR) : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
     const long out_tiles = (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128), per = (long)Cout * 9 * Cm;
     static const long wgs = [] { const char* e = getenv("JP_W9_WGS"); return e ? atol(e) : 256L; }();
     long sp = std::max<long>(1, std::min<long>(wgs / std::max<long>(1, out_tiles), ntiles / 2));
@@ -2038,17 +2039,25 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
 }
 template <int MW, int KG, bool REFLECT>
 const char* w9_tag() { return __PRETTY_FUNCTION__; }
-template <int TR, bool REFLECT>
+template <int TR, bool REFLECT, int KG>
 const char* w9s_tag() { return __PRETTY_FUNCTION__; }
 template <bool REFLECT>
 static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
                       const W9Plan& p, hipStream_t st) {
     if (p.split_mfma) {
         // executed FLOPs: 6 bf16 MFMA products per fp32 product
-        jp_prof_before(w9s_tag<W9S_TR, REFLECT>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
-        dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
-        hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W, p.ntiles,
-                           p.tps, (int)((long)N * Cout * H * W * 4));
+        const int dyb = (int)((long)N * Cout * H * W * 4);
+        if (p.narrow) {
+            jp_prof_before(w9s_tag<W9S_TRN, REFLECT, 2>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+            dim3 grid(Cm / 64, jp_cdiv(Cout, 64), p.splits);
+            hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TRN, REFLECT, 2>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                               p.ntiles, p.tps, dyb);
+        } else {
+            jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+            dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
+            hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                               p.ntiles, p.tps, dyb);
+        }
         jp_prof_after(st);
         return;
     }

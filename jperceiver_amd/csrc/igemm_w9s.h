@@ -23,7 +23,9 @@
 typedef short jp_s16x4 __attribute__((ext_vector_type(4)));
 typedef short jp_s16x8 __attribute__((ext_vector_type(8)));
 
-template <int TR, bool REFLECT>
+// KG = 1: M tile = 128 output channels (4 blocks).  KG = 2 (layers with <= 64 output channels): M tile = 64 channels and the
+// two wave groups take different pixel rows of the tile (K groups), writing their own partial slice 2*split + kg.
+template <int TR, bool REFLECT, int KG = 1>
 __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
                                                              int ntiles, int tiles_per_split, int dy_bytes) {
@@ -33,12 +35,15 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     constexpr int SPL = 2 * CBP;                   // bytes per split
     constexpr int ITEMS = SLOTS * 16, NQ = (ITEMS + NT - 1) / NT;      // (pixel, channel quad) items, rounds per thread
     constexpr int KGR = TR * 2;                    // K groups (16 pixels) per tile
+    constexpr int MB = 4 / KG, KGW = KGR / KG;     // 32-channel output blocks per M tile; K groups per wave and tile
+    static_assert(KG == 1 || KG == 2, "one or two K groups");
     static_assert(2 * SPL + ((TR + 1) * PC + 18) * 64 + 256 < 65536, "transpose-read immediates must fit 16 bits");
+    static_assert(KGW % 2 == 0 || KG == 1, "a wave group's K groups must be whole pixel rows");
     __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int ab = wave & 3, cb = wave >> 2;
+    const int ab = wave % MB, cb = (wave / MB) & 1, kg = wave / (2 * MB);
     const int l31 = lane & 31, lhi = lane >> 5;
     int mt, nt, zs;
     {   // every XCD owns whole K slices, see jp_wgrad_w9_kernel
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         mt = tile % gy;
         nt = tile / gy;
     }
-    const int m0 = mt * 128, c0 = nt * 64;
+    const int m0 = mt * 32 * MB, c0 = nt * 64;
     const int T0 = zs * tiles_per_split, T1 = min(ntiles, T0 + tiles_per_split);
     const int tiles_x = W / 32, tiles_img = tiles_x * (H / TR);
     const long HW = (long)H * W;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
-            bbase[tx][rd] = cb * CBP + (8 * lhi + rr) * 64 + ((Qq ^ ((tx + 4 * rd + rr) & 7)) * 8);
+            bbase[tx][rd] = cb * CBP + (kg * (KGW / 2) * PC + 8 * lhi + rr) * 64 + ((Qq ^ ((tx + 4 * rd + rr) & 7)) * 8);
     auto bread = [&](int ty, int tx, int g, int s) -> jp_bf16x8 {
         const int imm = s * SPL + ((g / 2 + ty) * PC + 16 * (g % 2) + tx) * 64;
         const jp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         int img, y0, x0;
         tile_org(T0, img, y0, x0);
         int tb = (img * Cout) * (int)HW + y0 * W + x0;
-        aload(0, tb, 0);
+        aload(0, tb, kg * KGW);
         gload(T0);
         for (int T = T0; T < T1; ++T) {
             lstore();
@@ -154,13 +159,16 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
             tile_org(T + 1, img, y0, x0);
             const int tbn = (img * Cout) * (int)HW + y0 * W + x0;
 #pragma unroll
-            for (int g = 0; g < KGR; ++g) {
+            for (int gi = 0; gi < KGW; ++gi) {
+                // (KG = 2: the wave's K groups are gi + kg*KGW; `g` below is only used in compile-time LDS offsets, the kg
+                // part of which is added through a wave-uniform byte offset folded into the read bases)
+                const int g = gi;
                 // dY of the NEXT K group (of this or the next tile) is requested now; this group's raw values are split
-                if (g + 1 < KGR) aload((g + 1) & 1, tb, g + 1);
-                else aload((g + 1) & 1, tbn, 0);
+                if (gi + 1 < KGW) aload((gi + 1) & 1, tb, kg * KGW + gi + 1);
+                else aload((gi + 1) & 1, tbn, kg * KGW);
                 jp_u32x4 sa[3];
                 {
-                    const jp_u32x4 lo = araw[g & 1][0], hi = araw[g & 1][1];
+                    const jp_u32x4 lo = araw[gi & 1][0], hi = araw[gi & 1][1];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         unsigned s0, s1, s2;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
 
     // ---- partial tile -> ws[zs][m][tap*Cm + ci]; C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long Np = 9L * Cm;
-    float* wz = ws + (long)zs * Cout * Np;
+    float* wz = ws + (long)(zs * KG + kg) * Cout * Np;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const long n = (long)tap * Cm + c0 + cb * 32 + l31;

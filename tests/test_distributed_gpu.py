@@ -142,7 +142,7 @@ def test_bench_two_rank_code_path_on_one_gpu():
     # the other rank, so the fraction may round to 0.0 -- only its range is checked on this smoke configuration)
     assert j["roofline"]["bound"] == "mfma" and 0 <= j["roofline"]["frac"] < 1 and j["roofline"]["launches"] >= 1
     assert any(k in j["roofline"]["kernel"] for k in ("jp_igemm", "jp_wgrad"))
-    assert j["roofline"]["step_frac_fp32"] > 0 and j["families"]
+    assert j["roofline"]["step_fp32_equiv_tflops"] > 0 and j["families"]
 
 
 # ------------------------------------------------------------------------------------------- RCCL itself (1 rank)

@@ -1,0 +1,116 @@
+"""Accuracy of the split-product kernels (igemm_p9s.h / igemm_w9s.h / igemm_p9us.h) against FLOAT64.
+
+The patch convolutions form every fp32 product on the bf16 matrix pipe as 6 bf16 products of exact three-way bf16 splits
+of both operands, accumulated in fp32.  The claim that makes this "fp32 arithmetic" rather than reduced precision is
+checked here, per kernel family, on well-scaled AND on wide-dynamic-range operands:
+
+  (a) against the float64 result, the split kernel's error is no larger than the EXACT-fp32 MFMA kernel's (the same library
+      with JP_P9S=0 JP_W9S=0 JP_P9US=0: `v_mfma_f32_32x32x2_f32`, bit-identical to an fmaf chain) -- rms within 1.25x, max
+      within 2x (the max of ~10^6 samples fluctuates);
+  (b) absolutely: |error| <= 2^-19 * sum_k |a_k| |b_k| for every output element (an fp32 FMA chain of K terms is bounded by
+      ~K * 2^-24 of that sum; the layers here have K = 256 ... 4617; measured worst cases on the wide-range operands: split
+      1.3e-6, exact-fp32 FMA chain 1.7e-6).
+
+Each variant runs in its own process (the library reads the JP_* switches once)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _emit():
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.nn.functional as F
+    from jperceiver_amd import ops
+    from jperceiver_amd.ops import Var, Tape, recording
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    res = {}
+
+    def data(shape, g, wide):
+        t = torch.randn(shape, generator=g)
+        if wide:        # per-element random power-of-two scale: 2^-6 .. 2^6
+            t = t * torch.pow(2.0, torch.randint(-6, 7, shape, generator=g).float())
+        return t
+
+    def metrics(got, ref64, bound64):
+        e = (got.double() - ref64).abs()
+        return dict(rms=float(e.pow(2).mean().sqrt() / ref64.pow(2).mean().sqrt()), max=float(e.max() / ref64.abs().max()),
+                    rel_bound=float((e / bound64.clamp_min(1e-300)).max()))
+
+    def conv_case(name, N, Cin, H, W, Cout, K, pad, pm, wide):
+        g = torch.Generator().manual_seed(11)
+        x, w = data((N, Cin, H, W), g, wide), data((Cout, Cin, K, K), g, wide) * (Cin * K * K) ** -0.5
+        gy = data((N, Cout, H, W), g, wide)
+        xv, wv = Var(x.cuda(), True), Var(w.cuda(), True, torch.zeros_like(w).cuda())
+        tape = Tape()
+        with recording(tape):
+            y = ops.conv2d(xv, wv, None, 1, pad, pm, 0)
+        y.g = gy.cuda()
+        tape.backward()
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        pad_ = (lambda t: F.pad(t, (pad,) * 4, mode="reflect")) if (pm == 1 and pad) else (lambda t: t)
+        yd = F.conv2d(pad_(xd), wd, None, 1, 0 if pm == 1 else pad)
+        yd.backward(gy.double())
+        # sum |a||b| bounds of the three GEMMs
+        xa, wa, ga = x.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True), gy.double().abs()
+        ya = F.conv2d(pad_(xa), wa, None, 1, 0 if pm == 1 else pad)
+        ya.backward(ga)
+        res[name + "/fwd"] = metrics(y.t.cpu(), yd.detach(), ya.detach())
+        res[name + "/dgrad"] = metrics(xv.g.cpu(), xd.grad, xa.grad)
+        res[name + "/wgrad"] = metrics(wv.g.cpu(), wd.grad, wa.grad)
+
+    for wide in (False, True):
+        tag = "wide" if wide else "unit"
+        conv_case(f"3x3_zero_128_{tag}", 8, 128, 64, 64, 128, 3, 1, 0, wide)
+        conv_case(f"3x3_reflect_256_{tag}", 8, 256, 64, 64, 256, 3, 1, 1, wide)
+        conv_case(f"1x1_256_{tag}", 8, 256, 64, 64, 256, 1, 0, 0, wide)
+        # iconv (P9US): cat(skip 64, up2x(x 96), disp 1) -> 256, reflect
+        g = torch.Generator().manual_seed(12)
+        N, H, W, Cr, Cx, Cout = 2, 64, 128, 64, 96, 256
+        r, xh, d = data((N, Cr, H, W), g, wide), data((N, Cx, H // 2, W // 2), g, wide), data((N, 1, H, W), g, wide)
+        w = data((Cout, Cr + Cx + 1, 3, 3), g, wide) * (9 * (Cr + Cx + 1)) ** -0.5
+        with recording(Tape()):
+            y = ops.conv2d(None, Var(w.cuda()), None, 1, 1, 1, 0, srcs=[(Var(r.cuda()), 0), (Var(xh.cuda()), 1), (Var(d.cuda()), 0)])
+        cat = torch.cat((r.double(), F.interpolate(xh.double(), scale_factor=2, mode="nearest"), d.double()), 1)
+        yd = F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), w.double())
+        ya = F.conv2d(F.pad(cat.abs(), (1, 1, 1, 1), mode="reflect"), w.double().abs())
+        res[f"iconv_{tag}/fwd"] = metrics(y.t.cpu(), yd, ya)
+    print("JSON" + json.dumps(res))
+
+
+def _run(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--emit"], capture_output=True, text=True, timeout=1800, env=env,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("JSON")][-1]
+    return json.loads(line[4:])
+
+
+def test_split_product_accuracy_vs_float64():
+    split = _run(dict(JP_P9S="1", JP_W9S="1", JP_P9US="1"))
+    exact = _run(dict(JP_P9S="0", JP_W9S="0", JP_P9US="0"))
+    assert set(split) == set(exact)
+    report = []
+    for k in sorted(split):
+        s, e = split[k], exact[k]
+        report.append(f"{k}: rms {s['rms']:.2e} (exact fp32 {e['rms']:.2e})  max {s['max']:.2e} ({e['max']:.2e})  "
+                      f"max err/sum|a||b| {s['rel_bound']:.2e} ({e['rel_bound']:.2e})")
+    print("\n".join(report))
+    for k in sorted(split):
+        s, e = split[k], exact[k]
+        assert s["rms"] <= 1.25 * e["rms"] + 1e-9, (k, s, e)
+        assert s["max"] <= 2.0 * e["max"] + 1e-9, (k, s, e)
+        assert s["rel_bound"] <= 2.0 ** -19, (k, s)
+        assert e["rel_bound"] <= 2.0 ** -19, (k, e)
+
+
+if __name__ == "__main__":
+    if "--emit" in sys.argv:
+        _emit()
