@@ -2125,6 +2125,7 @@ static inline bool w1_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
     return true;
 }
 static const char* w1_tag() { return "const char *w1_tag() [K = 1]"; }
+static const char* w1s_tag() { return "const char *w1s_tag() [K = 1]"; }
 
 Src3 make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
               int up2, int H, int W) {
@@ -2724,9 +2725,15 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     JP_CHECK_ARG(whole || single, "conv2d_wgrad: internal sub-range call must be single-source");
     W1Plan w1;
     if (single && ws && w1_plan(N, Cin, H, W, Cout, KH, stride, pad, ws_floats, &w1)) {
-        jp_prof_before(w1_tag(), 2.0 * Cout * (double)Cin * N * H * W, st);
-        hipLaunchKernelGGL(jp_wgrad_w1_kernel, dim3(Cin / 128, jp_cdiv(Cout, 256), w1.splits), dim3(512), 0, st, dy, x0, ws, Cout, Cin,
-                           Cin, H, W, w1.ntiles, w1.tps, (int)((long)N * Cout * H * W * 4));
+        if (w9s_enabled()) {    // W1S: the same tile and split-K plan on the bf16 pipe (igemm_w9s.h)
+            jp_prof_before(w1s_tag(), 6.0 * 2.0 * Cout * (double)Cin * N * H * W, st);
+            hipLaunchKernelGGL(jp_wgrad_w1s_kernel, dim3(Cin / 128, jp_cdiv(Cout, 256), w1.splits), dim3(512), 0, st, dy, x0, ws, Cout,
+                               Cin, Cin, H, W, w1.ntiles, w1.tps, (int)((long)N * Cout * H * W * 4));
+        } else {
+            jp_prof_before(w1_tag(), 2.0 * Cout * (double)Cin * N * H * W, st);
+            hipLaunchKernelGGL(jp_wgrad_w1_kernel, dim3(Cin / 128, jp_cdiv(Cout, 256), w1.splits), dim3(512), 0, st, dy, x0, ws, Cout,
+                               Cin, Cin, H, W, w1.ntiles, w1.tps, (int)((long)N * Cout * H * W * 4));
+        }
         jp_prof_after(st);
         const long total = (long)Cout * Cin;
         const int nblk = (int)((total / 4 + 63) / 64);

@@ -221,3 +221,171 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "W1S": the 1x1 stride-1 weight gradient (dW[co][ci] = sum_p dY[co][p] * X[ci][p]; the CRP / reduce layers) on the bf16
+// pipe.  No tap shifts, so BOTH operands are pixel-contiguous with aligned 8-pixel groups: X is staged in its natural
+// [channel][pixel] layout as three bf16 planes (a thread converts 8 consecutive pixels of one channel: two 16-byte loads,
+// three 16-byte LDS writes; row pitch 272 B -> conflict-free b128 fragment reads), dY comes straight from global memory and
+// is split in registers like in W9S.  Workgroup = 8 waves x (32 output channels) = 256 output channels x 128 input channels
+// (the W1 tile and split-K plan); a wave reads its four 32-channel B blocks for every K group: 12 ds_read_b128 + 2 dY
+// loads per 24 MFMAs.  Output: ws[split][m][ci] (wgrad_reduce4_kernel with one "tap").
+// Preconditions: Cm % 128 == 0, W % 32 == 0, H % 4 == 0 (rows >= Cout are clamped / masked).
+__global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
+                                                             int ntiles, int tiles_per_split, int dy_bytes) {
+    constexpr int NT = 512, TR = 4, NC = 128, P = TR * 32;
+    constexpr int PITCH = P * 2 + 16;                 // bytes per channel row of one split plane
+    constexpr int SPL = NC * PITCH;                   // bytes per split plane
+    constexpr int NQ = NC * (P / 8) / NT;             // (channel, pixel octet) items per thread: 4
+    constexpr int KGR = TR * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
+    const int t = threadIdx.x, lane = t & 63;
+    const int ab = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int mt, nt, zs;
+    {   // every XCD owns whole K slices, see jp_wgrad_w9_kernel
+        const int gx = gridDim.x, gy = gridDim.y, T = gx * gy, SG = gridDim.z & ~7;
+        const int L3 = blockIdx.x + blockIdx.y * gx + blockIdx.z * T;
+        int tile;
+        if (L3 < SG * T) {
+            const int idx = L3 >> 3;
+            zs = (idx / T) * 8 + (L3 & 7);
+            tile = idx % T;
+        } else {
+            const int r = L3 - SG * T;
+            zs = SG + r / T;
+            tile = r % T;
+        }
+        mt = tile % gy;
+        nt = tile / gy;
+    }
+    const int m0 = mt * 256, c0 = nt * NC;
+    const int T0 = zs * tiles_per_split, T1 = min(ntiles, T0 + tiles_per_split);
+    const int tiles_x = W / 32, tiles_img = tiles_x * (H / TR);
+    const long HW = (long)H * W;
+    auto tile_org = [&](int T, int& img, int& y0, int& x0) {
+        const int Tc = min(T, ntiles - 1);
+        img = Tc / tiles_img;
+        const int r = Tc - img * tiles_img;
+        y0 = (r / tiles_x) * TR;
+        x0 = (r % tiles_x) * 32;
+    };
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    const int arow = (min(m0 + ab * 32 + l31, Cout - 1) * (int)HW + 8 * lhi) * 4;
+    jp_u32x4 araw[2][2];
+    auto aload = [&](int slot, int tbase, int g) {
+        const int so = __builtin_amdgcn_readfirstlane((tbase + (g / 2) * W + 16 * (g % 2)) * 4);
+        araw[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(drs, arow, so, 0);
+        araw[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(drs, arow + 16, so, 0);
+    };
+    // staging: item e = t + NT*q -> (octet o = e & 15 of the tile's 128 pixels: tile row o >> 2, columns 8*(o & 3) .. +7; channel
+    // e >> 4): lanes run along the octets of a channel row -> 16-byte global loads, contiguous 16-byte LDS writes
+    jp_u32x4 rx[NQ][2];
+    auto gload = [&](int T) {
+        int img, y0, x0;
+        tile_org(T, img, y0, x0);
+        const float* xc = x + ((long)img * Cx + c0) * HW + (long)y0 * W + x0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = t + NT * q, o = e & 15, c = e >> 4;
+            const jp_u32x4* p = reinterpret_cast<const jp_u32x4*>(xc + (long)c * HW + (o >> 2) * W + 8 * (o & 3));
+            rx[q][0] = p[0];
+            rx[q][1] = p[1];
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = t + NT * q, o = e & 15, c = e >> 4;
+            jp_u32x4 w0, w1, w2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned a, b, cc;
+                jp_split3(__uint_as_float(rx[q][0][2 * k]), __uint_as_float(rx[q][0][2 * k + 1]), a, b, cc);
+                w0[k] = a; w1[k] = b; w2[k] = cc;
+                jp_split3(__uint_as_float(rx[q][1][2 * k]), __uint_as_float(rx[q][1][2 * k + 1]), a, b, cc);
+                w0[2 + k] = a; w1[2 + k] = b; w2[2 + k] = cc;
+            }
+            unsigned char* d = patch + c * PITCH + o * 16;
+            *reinterpret_cast<jp_u32x4*>(d) = w0;
+            *reinterpret_cast<jp_u32x4*>(d + SPL) = w1;
+            *reinterpret_cast<jp_u32x4*>(d + 2 * SPL) = w2;
+        }
+    };
+    jp_f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // B fragment of K group g (tile row g/2, columns 16*(g%2) + 8*lhi .. +7 = octet 4*(g/2) + 2*(g%2) + lhi), block j, split s
+    const unsigned char* bp = patch + l31 * PITCH + lhi * 16;
+    auto bread = [&](int g, int j, int s) -> jp_bf16x8 {
+        return __builtin_bit_cast(jp_bf16x8, *reinterpret_cast<const jp_u32x4*>(bp + s * SPL + j * 32 * PITCH + (4 * (g / 2) + 2 * (g % 2)) * 16));
+    };
+    if (T0 < T1) {
+        int img, y0, x0;
+        tile_org(T0, img, y0, x0);
+        int tb = (img * Cout) * (int)HW + y0 * W + x0;
+        aload(0, tb, 0);
+        gload(T0);
+        for (int T = T0; T < T1; ++T) {
+            lstore();
+            __syncthreads();
+            gload(T + 1);
+            tile_org(T + 1, img, y0, x0);
+            const int tbn = (img * Cout) * (int)HW + y0 * W + x0;
+#pragma unroll
+            for (int g = 0; g < KGR; ++g) {
+                if (g + 1 < KGR) aload((g + 1) & 1, tb, g + 1);
+                else aload((g + 1) & 1, tbn, 0);
+                jp_u32x4 sa[3];
+                {
+                    const jp_u32x4 lo = araw[g & 1][0], hi = araw[g & 1][1];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        unsigned s0, s1, s2;
+                        jp_split3(__uint_as_float(lo[2 * k]), __uint_as_float(lo[2 * k + 1]), s0, s1, s2);
+                        sa[0][k] = s0; sa[1][k] = s1; sa[2][k] = s2;
+                        jp_split3(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), s0, s1, s2);
+                        sa[0][2 + k] = s0; sa[1][2 + k] = s1; sa[2][2 + k] = s2;
+                    }
+                }
+                const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[1]),
+                                a2 = __builtin_bit_cast(jp_bf16x8, sa[2]);
+                jp_bf16x8 bq[2][3];
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) bq[0][s_] = bread(g, 0, s_);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j + 1 < 4) {
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) bq[(j + 1) & 1][s_] = bread(g, j + 1, s_);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const jp_bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][1], b2 = bq[j & 1][2];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            tb = tbn;
+            __syncthreads();
+        }
+    }
+    float* wz = ws + (long)zs * Cout * Cm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long n = c0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (m < Cout) wz[(long)m * Cm + n] = acc[j][r];
+        }
+    }
+}
