@@ -54,8 +54,11 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 
 // WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
 // TAPS = 9 (3x3, one-pixel halo) or 1 (1x1).  KGS = 16-channel groups per stage.
+#ifndef P9S_OCC
+#define P9S_OCC 2          // waves per SIMD the 4-wave variants are compiled for (3: <= 168 VGPRs, B fragments re-read per row)
+#endif
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) void jp_igemm_p9s_kernel(
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     constexpr int NT = 64 * WM * WN;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
@@ -166,6 +169,45 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
     for (int d = 0; d < P9S_AHEAD; ++d) aload(d, d * SBYTES);
     const jp_u32x4* bp = patch + (lhi * PR + wn * NJ) * COLS + l31;
 
+#if P9S_OCC >= 3
+    // B fragments of pixel row j, [split]: each row is re-read just in time -- row j of the next use is requested while the
+    // MFMAs of the other rows run (12*NJ registers instead of a double buffer of 24*NJ)
+    jp_u32x4 rb[NJ][3];
+    auto bload = [&](int j, int u) {
+        const int tap = u / KGS, kg = u % KGS;
+        const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) rb[j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+    };
+#define JP_P9S_MFMA(J_, SA_, SB_)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
+        acc[i][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
+                                                             __builtin_bit_cast(jp_bf16x8, rb[J_][SB_]), acc[i][J_], 0, 0, 0)
+    auto run_stage = [&](auto par_tag, int stage) {
+        constexpr int PAR = decltype(par_tag)::value;
+        lstore();
+        __syncthreads();
+        if (stage + 1 < NST) gload(stage + 1);
+        const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
+        bload(0, 0);
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) bload(j + 1, u);
+                else if (u + 1 < STEPS) { /* row 0 of the next step: requested after this row's MFMAs were issued (below) */ }
+                __builtin_amdgcn_sched_barrier(0);
+                JP_P9S_MFMA(j, 2, 0); JP_P9S_MFMA(j, 1, 1); JP_P9S_MFMA(j, 0, 2);
+                JP_P9S_MFMA(j, 1, 0); JP_P9S_MFMA(j, 0, 1); JP_P9S_MFMA(j, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0 && NJ > 1) { /* rb[0] is free again */ }
+                if (j + 1 == NJ && u + 1 < STEPS) bload(0, u + 1);
+            }
+        }
+        __syncthreads();
+    };
+#else
     // B fragments of step u: [j][split], compile-time LDS offsets (the step loop is fully unrolled)
     jp_u32x4 rb[2][NJ][3];
     auto bload = [&](int slot, int u) {
@@ -207,6 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? 2 : 1) vo
         }
         __syncthreads();
     };
+#endif
     static_assert(RING == 2, "two stage parities <-> two ring phases");
     gload(0);
     for (int stage = 0; stage < NST; stage += 2) {
