@@ -55,6 +55,7 @@ struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (stru
     int mode, p[6];
 };
 static_assert(sizeof(JpPackJob) == 64, "JpPackJob layout");
+__host__ __device__ inline int jp_cdiv_d(int a, int b) { return (a + b - 1) / b; }
 
 // taps a (class, slot) pair of the parity-class form stands for: dy in [y0, y1], dx in [x0, x1]
 __device__ __forceinline__ float pack_slot_sum(const float* wc, int pl) {
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void pack_replay_kernel(const JpPackJob* __res
         const JpPackJob& j = jobs[lo];
         const long i = g - j.begin;
         if (i >= j.total) continue;                         // alignment padding between two jobs
+        if (j.mode == PACK_SPLIT || j.mode == PACK_SPLITSEG) continue;      // pack_split_replay_kernel's
         if (j.mode == PACK_FRAG && i + 4 <= j.total) {
             const int* p = j.p;
             const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4];
@@ -261,6 +263,120 @@ __global__ __launch_bounds__(256) void pack_replay_kernel(const JpPackJob* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (i + k < j.total) j.wp[i + k] = pack_elem(j.mode, j.w, i + k, j.p);
+        }
+    }
+}
+
+// The split packs (PACK_SPLIT / PACK_SPLITSEG, most of the replayed bytes since round 3) through LDS: a work item = (job, M tile,
+// 16*KGS-channel stage, chunk of 64 rows).  Its weights -- 64 rows x CS channels x KHW taps, contiguous runs of the weight tensor in
+// either orientation -- are read COALESCED into LDS, then every (step, k-half, row) triple is split once and written as three
+// 16-byte words; the 64 rows of a (step, split, k-half) are one contiguous 1 KB run of the pack.  (The generic replay decoded
+// every 4-byte word on its own and read its two weights with a KHW-float stride: 1.3 ms per step at the head of the step.)
+__device__ __forceinline__ int split_job_items(const JpPackJob& j) {
+    const int* p = j.p;
+    if (j.mode == PACK_SPLIT) {
+        const int rows = p[2] ? p[1] : p[0], red = p[2] ? p[0] : p[1];
+        return jp_cdiv_d(rows, p[3]) * (red / (16 * p[5])) * (p[3] / 64);
+    }
+    if (j.mode == PACK_SPLITSEG) return (p[0] / 128) * ((p[3] + 15) / 16) * 2;
+    return 0;
+}
+__global__ __launch_bounds__(256) void pack_split_replay_kernel(const JpPackJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64 * 16 * 9 + 64];           // [row][channel][tap] (PACK_SPLIT fwd / SEG) or [channel][row][tap] (dgrad)
+    constexpr int MAXJ = 2048;
+    __shared__ int pre[MAXJ + 1];                       // exclusive prefix of the jobs' work-item counts
+    const int t = threadIdx.x;
+    for (int q = t; q < njobs && q < MAXJ; q += 256) pre[q + 1] = split_job_items(jobs[q]);
+    if (t == 0) pre[0] = 0;
+    __syncthreads();
+    if (t == 0)
+        for (int q = 1; q <= njobs && q <= MAXJ; ++q) pre[q] += pre[q - 1];
+    __syncthreads();
+    const int nj = min(njobs, MAXJ), total_items = pre[nj];
+    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+        __syncthreads();                                // the tile of the previous item is no longer read
+        int lo = 0, hi = nj - 1;                        // last job whose prefix <= item
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= item) lo = mid; else hi = mid - 1;
+        }
+        const int jj = lo, loc = item - pre[lo];
+        const JpPackJob& j = jobs[jj];
+        const int* p = j.p;
+        unsigned* out = reinterpret_cast<unsigned*>(j.wp);
+        if (j.mode == PACK_SPLIT) {
+            const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4], KGS = p[5];
+            const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
+            const int CS = 16 * KGS, nst = red / CS, rch = BMT / 64;
+            const int rc = loc % rch, stage = (loc / rch) % nst, mt = loc / (rch * nst);
+            const int m0 = mt * BMT + rc * 64, c0 = stage * CS;
+            const int RUN = CS * KHW;                   // floats of one row (fwd) -- or 64*KHW of one channel (dgrad)
+            if (!for_dgrad) {
+                for (int e = t; e < 64 * RUN; e += 256) {
+                    const int r = e / RUN, o = e - r * RUN;
+                    tile[e] = (m0 + r < rows) ? j.w[((size_t)(m0 + r) * Cin + c0) * KHW + o] : 0.f;
+                }
+            } else {
+                const int RUNd = 64 * KHW;
+                for (int e = t; e < CS * RUNd; e += 256) {
+                    const int c = e / RUNd, o = e - c * RUNd;            // o = r*KHW + tap
+                    tile[e] = (m0 + o / KHW < rows) ? j.w[((size_t)(c0 + c) * Cin + m0) * KHW + o] : 0.f;
+                }
+            }
+            __syncthreads();
+            const long nsteps = (long)nst * KHW * KGS;
+            const long per_tile = (nsteps + P9S_AHEAD) * 24 * BMT;
+            const int trip = KHW * KGS * 2 * 64;        // (tap, group, k-half, row) triples of this item
+            for (int e = t; e < trip; e += 256) {
+                const int r = e & 63, kh = (e >> 6) & 1, u = e >> 7;      // u = tap*KGS + kg
+                const int tap = u / KGS, kg = u - tap * KGS;
+                jp_u32x4 w0, w1, w2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = kg * 16 + kh * 8 + 2 * k;
+                    const float a = for_dgrad ? tile[(c * 64 + r) * KHW + tap] : tile[(r * CS + c) * KHW + tap];
+                    const float b = for_dgrad ? tile[((c + 1) * 64 + r) * KHW + tap] : tile[(r * CS + c + 1) * KHW + tap];
+                    unsigned s0, s1, s2;
+                    jp_split3(a, b, s0, s1, s2);
+                    w0[k] = s0; w1[k] = s1; w2[k] = s2;
+                }
+                const long U = (long)stage * KHW * KGS + u;
+                unsigned* q = out + (long)mt * per_tile + ((U * 3) * 2 + kh) * (long)BMT * 4 + (long)(rc * 64 + r) * 4;
+                *reinterpret_cast<jp_u32x4*>(q) = w0;
+                *reinterpret_cast<jp_u32x4*>(q + 2L * BMT * 4) = w1;
+                *reinterpret_cast<jp_u32x4*>(q + 4L * BMT * 4) = w2;
+            }
+        } else {            // PACK_SPLITSEG: p = Cout, Cin, c_off, C, up
+            const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], up = p[4];
+            const int T = up ? 4 : 9, MT = Cout / 128, nst = (C + 15) / 16;
+            const int rc = loc & 1, stage = (loc >> 1) % nst, mt = (loc >> 1) / nst;
+            const int m0 = mt * 128 + rc * 64, c0 = stage * 16;
+            for (int e = t; e < 64 * 144; e += 256) {
+                const int r = e / 144, o = e - r * 144, c = o / 9;
+                tile[e] = (c0 + c < C && m0 + r < Cout) ? j.w[((size_t)(m0 + r) * Cin + c_off + c0) * 9 + o] : 0.f;
+            }
+            __syncthreads();
+            const long tl = (long)nst * T * 3072;
+            const int ncls = up ? 4 : 1, trip = ncls * T * 2 * 64;
+            for (int e = t; e < trip; e += 256) {
+                const int r = e & 63, kh = (e >> 6) & 1, ct = e >> 7, tap = ct % T, cls = ct / T;
+                jp_u32x4 w0, w1, w2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = kh * 8 + 2 * k;
+                    const float* wa = tile + (r * 16 + c) * 9;
+                    const float a = up ? pack_slot_sum(wa, cls * 4 + tap) : wa[tap];
+                    const float b = up ? pack_slot_sum(wa + 9, cls * 4 + tap) : wa[9 + tap];
+                    unsigned s0, s1, s2;
+                    jp_split3(a, b, s0, s1, s2);
+                    w0[k] = s0; w1[k] = s1; w2[k] = s2;
+                }
+                const long U = (long)stage * T + tap;
+                unsigned* q = out + (long)(cls * MT + mt) * tl + ((U * 3) * 2 + kh) * 512L + (long)(rc * 64 + r) * 4;
+                *reinterpret_cast<jp_u32x4*>(q) = w0;
+                *reinterpret_cast<jp_u32x4*>(q + 1024) = w1;
+                *reinterpret_cast<jp_u32x4*>(q + 2048) = w2;
+            }
         }
     }
 }
@@ -2986,5 +3102,7 @@ extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, voi
     JP_CHECK_ARG(jobs && njobs > 0 && total_elems > 0, "pack_replay: bad args");
     hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 4095) / 4096, 16384)), dim3(256), 0,
                        (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
+    // the split-bf16 packs of the table: LDS-staged, grid-stride over their work items (a block without an item returns)
+    hipLaunchKernelGGL(pack_split_replay_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
     JP_LAUNCH_CHECK();
 }

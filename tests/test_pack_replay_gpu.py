@@ -1,0 +1,68 @@
+"""Weight packs refreshed by ONE `jp_pack_replay` launch (every step after the first) must equal the packs a layer builds on
+first use.  Model A takes a training step (its packs are recorded, Adam rewrites the weights) and then runs a second step,
+whose convolutions read REPLAYED packs (generic replay kernel + the LDS-staged split-pack replay kernel); model B is a
+fresh model loaded with A's updated weights, whose first step packs every layer directly.  Same inputs: the forward pass is
+deterministic, so losses and disparities must agree bit for bit; gradients to fp32 rounding (split-K atomics)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from jperceiver_amd import synthetic as syn                                    # noqa: E402
+from jperceiver_amd.model import MONO                                          # noqa: E402
+from jperceiver_amd.apis import build_optimizer                                # noqa: E402
+from oracle import jp_oracle as J                                              # noqa: E402  (option dict only)
+
+
+@pytest.mark.parametrize("ty,HW,B", [("static", 256, 2), ("Argo_both", 512, 1)])
+def test_replayed_packs_equal_first_use_packs(ty, HW, B):
+    FR = [0, -1, 1]
+    opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type=ty,
+                        split="argo" if ty == "Argo_both" else "odometry", loss_weightS=20, loss2_weightS=20)
+    inp = syn.make_batch(B, HW, HW, FR, HW // 4, (94, 311), opt.split, seed=51)
+    masks = syn.make_dropout_masks(B, HW, HW, seed=51)
+    noise = syn.make_automask_noise(B, HW, HW, 4, 2, seed=51)
+
+    def feed():
+        d = {k: v.cuda() for k, v in inp.items()}
+        d[("dropout_mask", 0)], d[("dropout_mask", 1)] = masks[0].cuda(), masks[1].cuda()
+        for s, per in enumerate(noise):
+            for j, nz in enumerate(per):
+                d[("automask_noise", s, j)] = nz.cuda()
+        return d
+
+    def step(model, optim, update):
+        optim.zero_grad()
+        out, losses = model(feed())
+        losses.total().backward()
+        torch.cuda.synchronize()
+        res = dict(losses={k: float(v) for k, v in losses.items()}, disp=[out[("disp", 0, s)].clone() for s in range(4)],
+                   top=out["topview"].clone(), grads=optim.arena.grads.clone())
+        if update:
+            optim.max_norm, optim.grad_scale = 35.0, 1.0
+            optim.step()
+            torch.cuda.synchronize()
+        return res
+
+    A = MONO.module_dict["Baseline"](opt)
+    A.load_state_dict(syn.synth_state_dict(A.state_dict(), seed=0))
+    A = A.cuda().train()
+    oa = build_optimizer(A, dict(type="Adam", lr=1e-3, weight_decay=0))      # a large step: every weight really changes
+    step(A, oa, True)
+    state = {k: v.detach().clone() for k, v in A.state_dict().items()}
+    ra = step(A, oa, False)                     # reads packs refreshed by jp_pack_replay
+
+    Bm = MONO.module_dict["Baseline"](opt)
+    Bm.load_state_dict(state)
+    Bm = Bm.cuda().train()
+    ob = build_optimizer(Bm, dict(type="Adam", lr=1e-3, weight_decay=0))
+    rb = step(Bm, ob, False)                    # packs built on first use
+
+    assert ra["losses"].keys() == rb["losses"].keys()
+    for k in ra["losses"]:
+        assert ra["losses"][k] == rb["losses"][k], (k, ra["losses"][k], rb["losses"][k])
+    for s in range(4):
+        assert torch.equal(ra["disp"][s], rb["disp"][s]), f"disp scale {s} differs between replayed and first-use packs"
+    assert torch.equal(ra["top"], rb["top"])
+    ga, gb = ra["grads"], rb["grads"]
+    assert float((ga - gb).norm() / gb.norm()) < 1e-5
