@@ -26,6 +26,7 @@
 #include "igemm_p9s.h"
 #include "igemm_w9s.h"
 #include "igemm_p9us.h"
+#include "igemm_p9sd.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -47,7 +48,7 @@ __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 // The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
 // launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
 // tiny launches per step become one.
-enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7, PACK_SPLITSEG = 8 };
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7, PACK_SPLITSEG = 8, PACK_SPLITUPD = 9 };
 struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
     const float* w;
     float* wp;
@@ -154,6 +155,30 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                 const int co = for_dgrad ? cc : m, ci = for_dgrad ? m : cc;
                 v[k] = cc < red ? w[((size_t)co * Cin + ci) * KHW + tap] : 0.f;
             }
+            unsigned s0, s1, s2;
+            jp_split3(v[0], v[1], s0, s1, s2);
+            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+        }
+        case PACK_SPLITUPD: {  // p = Cout, Cin, c_off, Cx: dgrad weights of the upsampled iconv segment as bf16 three-way splits in the
+                               // fragment order of the P9SD kernel (igemm_p9sd.h): [M tile of 128 rows c][step = (16-channel stage
+                               // of co, (class, slot) q)][split][k-half][row][4 words]; value = the pre-summed slot weight W'_q[co][c]
+            const int Cout = p[0], Cin = p[1], c_off = p[2], Cx = p[3];
+            const long nsteps = (long)((Cout + 31) / 32 * 2) * 16;
+            const long per_tile = (nsteps + P9S_AHEAD) * 3072;
+            const int mt = (int)(i / per_tile);
+            long t = i - (long)mt * per_tile;
+            const int w4 = (int)(t & 3); t >>= 2;
+            const int c = mt * 128 + (int)(t & 127); t >>= 7;
+            const int khalf = (int)(t & 1); t >>= 1;
+            const int sp = (int)(t % 3);
+            const long U = t / 3;
+            if (U >= nsteps || c >= Cx) return 0.f;
+            const int stage = (int)(U >> 4), q = (int)(U & 15);
+            const int co = stage * 16 + khalf * 8 + 2 * w4;
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                v[k] = co + k < Cout ? pack_slot_sum(w + ((size_t)(co + k) * Cin + c_off + c) * 9, q) : 0.f;
             unsigned s0, s1, s2;
             jp_split3(v[0], v[1], s0, s1, s2);
             return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
@@ -2002,6 +2027,14 @@ inline bool p9us_enabled() {
 }
 template <class E>
 const char* p9us_tag() { return __PRETTY_FUNCTION__; }
+// P9SD (igemm_p9sd.h): dgrad of the upsampled iconv segment at half resolution on the bf16 pipe; JP_P9SD=0 keeps DgradUPB
+inline bool p9sd_enabled() {
+    static const int on = [] { const char* e = getenv("JP_P9SD"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+inline long p9sd_floats(int rows, int Cout) { return (long)jp_cdiv(rows, 128) * ((long)((Cout + 31) / 32 * 2) * 16 + P9S_AHEAD) * 3072; }
+template <class E>
+const char* p9sd_tag() { return __PRETTY_FUNCTION__; }
 // channels per M tile of a bank with `rows` rows: 64 x (8x32 px), 128 x (4x32 px), or -- 3x3 banks whose row count is a
 // multiple of 256 -- 256 x (4x32 px) on 8 waves (JP_P9_M256=0 turns that variant off)
 inline bool p9_m256() {
@@ -2316,7 +2349,7 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
                                                 KH == 3 ? p9_alloc_floats(Cout, pad32(Cin)) : (KH == 1 ? p9_alloc_floats(Cout, pad32(Cin), 1) : 0L)) : 0;
     // dgrad: [tap][ci][Cp] + slack, plus 16 planes [class,slot][c][Cp] + slack for jp_conv2d_dgrad_src3's upsampled
     // segment, plus the fragment-order pack of the P9 main pass behind them
-    if (which == 1) return Cout >= 16 ? dgrad_tap_floats(Cin, Cout, KH) + (KH == 3 ? p9_alloc_floats(Cin, pad32(Cout)) : (KH == 1 ? p9_alloc_floats(Cin, pad32(Cout), 1) : 0L)) : 0;
+    if (which == 1) return Cout >= 16 ? dgrad_tap_floats(Cin, Cout, KH) + (KH == 3 ? p9_alloc_floats(Cin, pad32(Cout)) + p9sd_floats(Cin, Cout) : (KH == 1 ? p9_alloc_floats(Cin, pad32(Cout), 1) : 0L)) : 0;
     return 0;
 }
 
@@ -2755,6 +2788,17 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             PackA a{wsT, C, KpU, Cp, 16};
             DgradUPB bu{dy, (int)np2, h2, w2, Cout};
             DgradEpi e{dx, C, h2 * w2, accs[sidx]};
+            if (p9sd_enabled() && h2 % 4 == 0 && w2 % 32 == 0 && Cout % 16 == 0 && (long)N * Cout * H * W * 4 < (1L << 31) &&
+                (long)jp_cdiv(C, 128) * N * (h2 / 4) * (w2 / 32) >= 192) {
+                // split-product patch kernel over the full-resolution dY (igemm_p9sd.h); its pack sits behind the P9 one
+                float* wsd = ws + dgrad_tap_floats(Cin, Cout, 3) + p9_alloc_floats(Cin, Cp);
+                if (!ws_state) do_pack(PACK_SPLITUPD, w, wsd, p9sd_floats(C, Cout), Cout, Cin, coff, C, 0, 0, st);
+                jp_prof_before(p9sd_tag<DgradEpi>(), 6.0 * 2.0 * C * (double)np2 * 16.0 * Cp, st);
+                dim3 grid(N * (h2 / 4) * (w2 / 32), jp_cdiv(C, 128), 1);
+                hipLaunchKernelGGL((jp_igemm_p9sd_kernel<DgradEpi>), grid, dim3(256), 0, st, reinterpret_cast<const unsigned*>(wsd), dy, e,
+                                   C, Cout, Cp / 16, h2, w2);
+                jp_prof_after(st);
+            } else
             launch_auto(a, bu, e, C, (int)np2, KpU, 1, KpU, st);
             const int Nb = N * (2 * w2 + 2 * h2);
             DgradUPBorderB bb{dy, Nb, h2, w2, Cout};
