@@ -27,6 +27,7 @@
 #include "igemm_w9s.h"
 #include "igemm_p9us.h"
 #include "igemm_p9sd.h"
+#include "igemm_w4s.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -3014,6 +3015,26 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
 }
 
 
+// ---- W4S (igemm_w4s.h): split-bf16 parity-class wgrad of the upsampled iconv segment; JP_W9S=0 keeps the generic
+// WgradAP/WgradBP instantiation.  Same partial-sum layout ws[split][co][16*Cx], folded by wgrad_fold_parity_kernel.
+constexpr int W4S_TR = 2;
+struct W4SPlan { int splits, tps, ntiles; long need; };
+static inline bool w4s_plan(int N, int Cx, int h2, int w2, int Cout, long ws_floats, W4SPlan* p) {
+    if (!w9s_enabled() || Cx % 64 || w2 % 32 || h2 % W4S_TR || (long)N * Cout * h2 * w2 * 16 >= (1L << 31)) return false;
+    const int ntiles = N * (h2 / W4S_TR) * (w2 / 32);
+    const long out_tiles = 2L * (Cx / 64) * jp_cdiv(Cout, 128), per = (long)Cout * 16 * Cx;
+    long sp = std::max<long>(1, std::min<long>(jp_cdiv(256, out_tiles), ntiles / 2));
+    sp = std::min<long>(sp, ws_floats / per);
+    if (sp < 1 || ntiles < 8) return false;
+    p->tps = (int)jp_cdiv(ntiles, sp);
+    p->splits = jp_cdiv(ntiles, p->tps);
+    p->ntiles = ntiles;
+    p->need = (long)p->splits * per;
+    return true;
+}
+template <int TR>
+const char* w4s_tag() { return __PRETTY_FUNCTION__; }
+
 // one channel segment is eligible for the per-segment wgrad (no materialised concat): full-resolution segments run the
 // single-source paths on their own tensor, the upsampled one the parity-class kernels
 static bool wgrad_segments_ok(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W, int Cout, int KH,
@@ -3054,6 +3075,19 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
             } else {
                 const int h2 = H / 2, w2 = W / 2, Cx = cs[i], Np = 16 * Cx;
                 const long Ncl = (long)N * h2 * w2;
+                W4SPlan q;
+                if (w4s_plan(N, Cx, h2, w2, Cout, ws_floats, &q)) {
+                    // executed FLOPs: 6 bf16 MFMA products per fp32 product, 16 (class, slot) GEMMs over the half-res pixels
+                    jp_prof_before(w4s_tag<W4S_TR>(), 6.0 * 2.0 * Cout * 16.0 * Cx * (double)Ncl, st);
+                    hipLaunchKernelGGL((jp_wgrad_w4s_kernel<W4S_TR>), dim3(Cx / 64, jp_cdiv(Cout, 128), 2 * q.splits), dim3(512), 0,
+                                       st, dy, xs[i], ws, Cout, Cx, h2, w2, q.ntiles, q.tps, (int)((long)N * Cout * H * W * 4));
+                    jp_prof_after(st);
+                    const long total = (long)Cout * Cx * 9;
+                    hipLaunchKernelGGL(wgrad_fold_parity_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                                       st, ws, dw, Cout, Cx, q.splits, coff, Cin);
+                    coff += cs[i];
+                    continue;
+                }
                 WgradPlan p = wgrad_plan(Cout, Np, Ncl, 128, 128, 3, ws_floats);
                 if (!p.use_ws) {    // this path always reduces through scratch: take the largest split that fits
                     long sp = std::max<long>(1, std::min<long>(ws_floats / ((long)Cout * Np), jp_cdiv(Ncl, KC) / 4));
@@ -3090,6 +3124,8 @@ extern "C" long jp_conv2d_wgrad_src3_ws_floats(int c0, int up0, int c1, int up1,
         if (us[i]) {
             const WgradPlan p = wgrad_plan(Cout, 16 * cs[i], (long)N * (H / 2) * (W / 2), 128, 128, 3, cap);
             need = std::max(need, p.use_ws ? p.ws_need : (long)Cout * 16 * cs[i]);
+            W4SPlan q;
+            if (w4s_plan(N, cs[i], H / 2, W / 2, Cout, cap, &q)) need = std::max(need, q.need);
         } else if (cs[i] >= 16) {
             const int Np = KH * KH * (cs[i] >= 64 ? cs[i] / 64 * 64 : cs[i]);
             const WgradPlan p = wgrad_plan(Cout, Np, (long)N * H * W, 128, 128, 3, cap);
