@@ -94,12 +94,14 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     auto gloadS = [&](const __amdgpu_buffer_rsrc_t& rs, int ch0, int nch) {     // ch0: first channel of the stage; nch valid channels
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int ub = __builtin_amdgcn_readfirstlane((int)((long)(ch0 + k) * HW * 4));
+            // the scalar offset must stay wave-uniform (a lane-dependent one makes the compiler wrap every load in a
+            // waterfall loop): channel k of the k-half 0 exists iff k < nch, lanes of k-half 1 only when nch == 16
+            const int ub = __builtin_amdgcn_readfirstlane(k < nch ? (int)((long)(ch0 + k) * HW * 4) : 0);
 #pragma unroll
             for (int q = 0; q < NQS; ++q) {
                 const int kh8 = (t + NT * q) / (COLS_S * PRS) * 8;
                 const bool ok = lS[q] >= 0 && kh8 + k < nch;
-                const float v = jp_gather(rs, ok ? sS[q] * 4u : 0u, ok ? ub : 0);
+                const float v = jp_gather(rs, ok ? sS[q] * 4u : 0u, ub);
                 rv[q][k] = ok ? v : 0.f;
             }
         }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     // ---- stage sequence: S x NS0 (NS0 even: the ring parity is 0 again after every pair), U x NS1, D x (C2 ? 1 : 0)
     aload(0, NS0 ? offS : offU);
     if (NS0) gloadS(rsS, 0, 16); else gloadU(0);
-    for (int st = 0; st < NS0; ++st) {
+    auto s_stage = [&](auto par_tag, int st) {
         lstoreS();
         __syncthreads();
         if (st + 1 < NS0) gloadS(rsS, (st + 1) * 16, 16);
@@ -215,8 +217,12 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         else if (C2) gloadS(rsD, 0, C2);
         const int cur = offS + st * 9 * SBYTES;
         const int nxt = st + 1 < NS0 ? cur + 9 * SBYTES : (NS1 ? offU : offD);
-        if (st & 1) run_stage(P1{}, UPF{}, cur, nxt); else run_stage(P0{}, UPF{}, cur, nxt);
+        run_stage(par_tag, UPF{}, cur, nxt);
         __syncthreads();
+    };
+    for (int st = 0; st < NS0; st += 2) {         // 9 steps per stage: the ring parity alternates, a stage pair restores it
+        s_stage(P0{}, st);
+        s_stage(P1{}, st + 1);
     }
     for (int st = 0; st < NS1; ++st) {
         lstoreU();
