@@ -324,6 +324,52 @@ def _conv_shape(name, a):
     return kind, fl, by
 
 
+def _hbm_bytes(name, a):
+    """Algorithmic HBM bytes of one call of an HBM-bound entry point (every tensor the op must read or write, once per
+    pass the algorithm needs; ABI argument order, include/jperceiver_hip.h) -- None for entry points not modelled."""
+    try:
+        if name == "jp_bn_train_fwd":            # pass 1 reads x (statistics), pass 2 reads x (+ residual), writes y
+            E = a[10] * a[11] * a[12]
+            return 4.0 * E * (3 + (a[3] is not None))
+        if name == "jp_bn_train_bwd":            # reduce: dy, x (+ y for the ReLU mask); apply: the same + dx (+ dres)
+            E = a[12] * a[13] * a[14]
+            r = 1 if a[15] else 0
+            return 4.0 * E * (2 * (2 + r) + 1 + (a[8] is not None))
+        if name == "jp_maxpool_fwd":
+            NC, H, W, k, s_, p_ = a[3:9]
+            OH, OW = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+            return NC * (4.0 * H * W + 5.0 * OH * OW)
+        if name == "jp_maxpool_bwd":
+            NC, H, W, k, s_, p_ = a[4:10]
+            OH, OW = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+            return NC * (5.0 * OH * OW + 4.0 * H * W * (1 + (a[3] is not None)))
+        if name == "jp_cgt_warp_fwd":            # disparity (source scale), colour gather, pred
+            B, H, W = a[7:10]
+            return 4.0 * B * (a[1] * a[2] + 6 * H * W)
+        if name == "jp_cgt_warp_bwd":            # dpred, disparity, colour gather, ddisp_up
+            B, H, W = a[9:12]
+            return 4.0 * B * (a[2] * a[3] + 7 * H * W)
+        if name == "jp_ssim_l1_fwd":
+            return 4.0 * a[3] * a[4] * a[5] * 7
+        if name == "jp_ssim_l1_bwd":             # pred, target, min index (int64), gout, dpred
+            return a[7] * a[8] * a[9] * (12.0 + 12 + 8 + 4 + 12)
+        if name == "jp_adam_clip_step":
+            return 28.0 * a[4]
+        if name == "jp_sum_n":
+            return 4.0 * a[6] * (1 + sum(x is not None for x in a[:5]))
+        if name == "jp_axpby":
+            return 4.0 * a[3] * (2 + (a[1] is not None))
+        if name == "jp_act_bwd":
+            return 12.0 * a[3]
+        if name == "jp_upsample2x_fwd":
+            return 4.0 * a[2] * a[3] * a[4] * a[5] * 5
+        if name == "jp_upsample2x_bwd":
+            return 4.0 * a[2] * a[3] * a[4] * a[5] * 5
+    except (TypeError, IndexError):
+        return None
+    return None
+
+
 _FAMILY = [("jp_bn_", "batchnorm"), ("jp_maxpool", "pool"), ("jp_cgt_warp", "photometric"), ("jp_ssim", "photometric"),
            ("jp_minreproj", "photometric"), ("jp_pose", "photometric"), ("jp_smooth", "losses"), ("jp_scale_loss", "losses"),
            ("jp_layout", "losses"), ("jp_sdf", "losses"), ("jp_l1", "losses"), ("jp_adam", "optimizer"),
@@ -386,6 +432,7 @@ def measure_roofline(runner, batch, B, t_step, rank):
     L = _lib.lib()
     orig = _lib.call
     calls = []          # (name, e0, e1, rec_lo, rec_hi, conv-shape or None)
+    call_args = []
 
     def timed_call(name, *a):
         st = torch.cuda.current_stream()
@@ -395,6 +442,7 @@ def measure_roofline(runner, batch, B, t_step, rank):
         orig(name, *a)
         e1.record(st)
         calls.append((name, e0, e1, lo, L.fn["jp_profile_count"](), _conv_shape(name, a)))
+        call_args.append(a)
 
     patched = [m for m in (_lib, ops, ops_loss, runtime, netmod, mods, lossmod, dist_utils) if getattr(m, "call", None) is orig]
     if L.fn["jp_profile_begin"](8192) != 0:
@@ -537,6 +585,33 @@ def measure_roofline(runner, batch, B, t_step, rank):
                                 "algorithmic_tflops": round(k["algorithmic_flop"] / max(k["ms"], 1e-9) / 1e9, 1),
                                 "executed_tflops": round(k["executed_flop"] / max(k["ms"], 1e-9) / 1e9, 1)}
                                for t, k in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:24]]}
+    # every conv entry-point call of the step: integer arguments (ABI order), event ms, the kernels it launched
+    layers = collections.OrderedDict()
+    for (name, e0, e1, lo, hi, shp), args in zip(calls, call_args):
+        if shp is None:
+            continue
+        key = (name, tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool) and abs(x) < (1 << 20)),
+               tuple(_kernel_name(r[0]) for r in recs[lo:hi]))
+        d = layers.setdefault(key, {"calls": 0, "ms": 0.0, "kernel_ms": [0.0] * (hi - lo)})
+        d["calls"] += 1
+        d["ms"] += e0.elapsed_time(e1)
+        d["kernel_ms"] = [x + r[2] for x, r in zip(d["kernel_ms"], recs[lo:hi])]
+    table["conv_calls"] = [{"entry": k[0], "ints": list(k[1]), "calls": v["calls"], "ms": round(v["ms"], 3),
+                            "kernels": [f"{n} {m:.3f}" for n, m in zip(k[2], v["kernel_ms"])]}
+                           for k, v in sorted(layers.items(), key=lambda kv: -kv[1]["ms"])]
+    # HBM-bound entry points: algorithmic bytes against the event time of the same (single-stream) step
+    hb = {}
+    for (name, e0, e1, lo, hi, shp), args in zip(calls, call_args):
+        by = _hbm_bytes(name, args)
+        if by is None:
+            continue
+        d = hb.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += by
+    table["hbm_entry_points"] = [{"entry": k, "calls": v[0], "ms": round(v[1], 3), "algorithmic_GB": round(v[2] / 1e9, 3),
+                                  "algorithmic_TBps": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
+                                 for k, v in sorted(hb.items(), key=lambda kv: -kv[1][1])]
     for k, v in table["families"].items():
         if k.startswith("conv ") and v["ms"] > 0:
             v["algorithmic_tflops"] = round(conv_alg[k[5:]] / (v["ms"] * 1e-3) / 1e12, 1)

@@ -53,6 +53,28 @@ def main(fetch_db, write_db, out_json):
     res["traffic_bytes_per_launch"] = (res["fetch_KB_raw_avg"] * kf + res["write_KB_raw_avg"] * kw) * 1024.0
     json.dump(res, open(out_json, "w"), indent=1)
     print(json.dumps(res, indent=1))
+    # per-kernel table of the whole profiled run (steps = argv[5], default 3 = 2 timed + 1 warm-up): calibrated FETCH + WRITE
+    # bytes per step, to be read next to bench_families.json -> hbm_entry_points (algorithmic bytes of the same step)
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    short = lambda k: re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", k).split("(")[0])[:110]
+    rows = []
+    for k in F:
+        if "axpby_kernel" in k and k == copy:
+            fb = (sum(v for v, _ in F[k]) - sum(v for v, _ in cf)) * 1024.0 * kf
+            wb = (sum(v for v, _ in W.get(k, [])) - sum(v for v, _ in cw)) * 1024.0 * kw
+        else:
+            fb = sum(v for v, _ in F[k]) * 1024.0 * kf
+            wb = sum(v for v, _ in W.get(k, [])) * 1024.0 * kw
+        rows.append((short(k), len(F[k]) / steps, fb / steps, wb / steps))
+    rows.sort(key=lambda r: -(r[2] + r[3]))
+    md = out_json.replace(".json", "_kernels.md")
+    with open(md, "w") as f:
+        f.write("# HBM traffic per kernel and step: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on a 1 GiB copy\n")
+        f.write(f"# fetch factor {kf:.4f}, write factor {kw:.4f}; {steps} profiled steps; total "
+                f"{sum(r[2] + r[3] for r in rows) / 1e9:.2f} GB per step\n")
+        f.write("| kernel | launches/step | fetch GB/step | write GB/step | total GB/step |\n|---|---|---|---|---|\n")
+        for n, l, fb, wb in rows[:60]:
+            f.write(f"| `{n}` | {l:.1f} | {fb / 1e9:.3f} | {wb / 1e9:.3f} | {(fb + wb) / 1e9:.3f} |\n")
 
 
 if __name__ == "__main__":
