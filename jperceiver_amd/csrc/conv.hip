@@ -28,6 +28,7 @@
 #include "igemm_p9us.h"
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
+#include "igemm_p9s2d.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -2036,6 +2037,13 @@ inline bool p9sd_enabled() {
 inline long p9sd_floats(int rows, int Cout) { return (long)jp_cdiv(rows, 128) * ((long)((Cout + 31) / 32 * 2) * 16 + P9S_AHEAD) * 3072; }
 template <class E>
 const char* p9sd_tag() { return __PRETTY_FUNCTION__; }
+// P9S2D (igemm_p9s2d.h): class-uniform split-bf16 dgrad of the 3x3 stride-2 layers; JP_P9S2=0 keeps the generic DgradS2B form
+inline bool p9s2_enabled() {
+    static const bool on = [] { const char* e = getenv("JP_P9S2"); return !(e && e[0] == '0'); }();
+    return on;
+}
+template <int WM, int WN, class E>
+const char* p9s2d_tag() { return __PRETTY_FUNCTION__; }
 // channels per M tile of a bank with `rows` rows: 64 x (8x32 px), 128 x (4x32 px), or -- 3x3 banks whose row count is a
 // multiple of 256 -- 256 x (4x32 px) on 8 waves (JP_P9_M256=0 turns that variant off)
 inline bool p9_m256() {
@@ -2599,9 +2607,31 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         // never read the tap-major pack: it is neither built nor replayed for them
         const bool p9_only = KH == 3 && stride == 1 && pad == 1 && pad_mode != JP_PAD_REFLECT && sp <= 1 &&
                              !(Cin > 128 && Cin % 128 <= 16 && Cin % 128 != 0) && p9_ok(Cin, Cout, N, H, W);
+        const long Nc = (long)N * (H / 2) * (W / 2);
+        // 3x3 stride-2 layers: class-uniform split-bf16 kernel on the half-resolution grid (its own fragment-order pack only)
+        const bool s2_form = KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 &&
+                             2 * OH == H && 2 * OW == W;
+        if (s2_form && p9s_enabled() && p9s2_enabled() && Cin >= 32 && Cout % 16 == 0 && OW % 32 == 0 &&
+            OH % (Cin <= 64 ? 8 : 4) == 0 && (long)N * Cout * OH * OW * 4 < (1L << 31) &&
+            (long)jp_cdiv(Cin, Cin <= 64 ? 64 : 128) * N * (OH / (Cin <= 64 ? 8 : 4)) * (OW / 32) * 4 >= 192) {
+            float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
+            const int bmt = Cin <= 64 ? 64 : 128;
+            if (!ws_state) pack_p9(w, wfr, Cout, Cin, 1, bmt, 9, st);
+            const unsigned* wq = reinterpret_cast<const unsigned*>(wfr);
+            const int NST = Cout / 16;
+            jp_prof_before(bmt == 64 ? p9s2d_tag<1, 4, DgradEpi>() : p9s2d_tag<2, 2, DgradEpi>(),
+                           6.0 * 2.0 * Cin * (double)N * OH * OW * 9.0 * Cout, st);
+            if (bmt == 64)
+                hipLaunchKernelGGL((jp_igemm_p9s2d_kernel<1, 4, 2, DgradEpi>), dim3(4 * N * (OH / 8) * (OW / 32), 1, 1), dim3(256), 0, st,
+                                   wq, dy, e, Cin, Cout, NST, OH, OW);
+            else
+                hipLaunchKernelGGL((jp_igemm_p9s2d_kernel<2, 2, 2, DgradEpi>), dim3(4 * N * (OH / 4) * (OW / 32), jp_cdiv(Cin, 128), 1),
+                                   dim3(256), 0, st, wq, dy, e, Cin, Cout, NST, OH, OW);
+            jp_prof_after(st);
+            JP_LAUNCH_CHECK();
+        }
         if (!ws_state && !p9_only) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);
         PackA a{ws, Cin, Kp, Cp, KH * KH};
-        const long Nc = (long)N * (H / 2) * (W / 2);
         if (KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 && Nc % 256 == 0 &&
             2 * OH == H && 2 * OW == W) {
             // parity-class form: 4 tap slots instead of 9 taps per input pixel

@@ -67,6 +67,8 @@ def _split_name(w):
         return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2>"            # narrow twin: two K groups per workgroup
     if w == "jp_wgrad_w1_kernel" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w1s_kernel"
+    if w == "DgradS2B" and os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0":
+        return "jp_igemm_p9s2d_kernel"                                # class-uniform stride-2 dgrad (igemm_p9s2d.h)
     if w == "WgradAP, WgradBP" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w4s_kernel<2>"                               # parity-class wgrad of the upsampled segment (igemm_w4s.h)
     if w == "jp_igemm_p9u_kernel<FwdEpi>" and os.environ.get("JP_P9US", "1") != "0":

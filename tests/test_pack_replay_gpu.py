@@ -37,7 +37,9 @@ def test_replayed_packs_equal_first_use_packs(ty, HW, B):
         losses.total().backward()
         torch.cuda.synchronize()
         res = dict(losses={k: float(v) for k, v in losses.items()}, disp=[out[("disp", 0, s)].clone() for s in range(4)],
-                   top=out["topview"].clone(), grads=optim.arena.grads.clone())
+                   top=out["topview"].clone(), grads=optim.arena.grads.clone(),
+                   extra={str(k): v.detach().clone() for k, v in out.items()
+                          if torch.is_tensor(v) and (k == "origin_features" or (isinstance(k, tuple) and k[0] in ("axisangle", "translation")))})
         if update:
             optim.max_norm, optim.grad_scale = 35.0, 1.0
             optim.step()
@@ -59,8 +61,13 @@ def test_replayed_packs_equal_first_use_packs(ty, HW, B):
     rb = step(Bm, ob, False)                    # packs built on first use
 
     assert ra["losses"].keys() == rb["losses"].keys()
+    # where a difference starts (diagnostic for the assertions below)
+    where = {k: float((ra["extra"][k] - rb["extra"][k]).abs().max()) for k in ra["extra"]}
+    where.update({f"disp{s}": float((ra["disp"][s] - rb["disp"][s]).abs().max()) for s in range(4)})
+    where["top"] = float((ra["top"] - rb["top"]).abs().max())
+    where = {k: v for k, v in where.items() if v != 0.0}
     for k in ra["losses"]:
-        assert ra["losses"][k] == rb["losses"][k], (k, ra["losses"][k], rb["losses"][k])
+        assert ra["losses"][k] == rb["losses"][k], (k, ra["losses"][k], rb["losses"][k], where)
     for s in range(4):
         assert torch.equal(ra["disp"][s], rb["disp"][s]), f"disp scale {s} differs between replayed and first-use packs"
     assert torch.equal(ra["top"], rb["top"])
