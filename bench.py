@@ -408,6 +408,8 @@ def _kernel_name(tag):
         return "jp_wgrad_w1_kernel"
     if "w7_tag" in tag:
         return f"jp_wgrad_w7_kernel<{kv['CIN']}>"
+    if "p9s2f_tag" in tag:
+        return f"jp_igemm_p9s2f_kernel<{kv['E']}>"
     if "p9s2d_tag" in tag:
         return f"jp_igemm_p9s2d_kernel<{kv['WM']}, {kv['WN']}, 2, {kv['E']}>"
     if "w4s_tag" in tag:

@@ -29,6 +29,7 @@
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
 #include "igemm_p9s2d.h"
+#include "igemm_p9s2f.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -2044,6 +2045,8 @@ inline bool p9s2_enabled() {
 }
 template <int WM, int WN, class E>
 const char* p9s2d_tag() { return __PRETTY_FUNCTION__; }
+template <class E>
+const char* p9s2f_tag() { return __PRETTY_FUNCTION__; }
 // channels per M tile of a bank with `rows` rows: 64 x (8x32 px), 128 x (4x32 px), or -- 3x3 banks whose row count is a
 // multiple of 256 -- 256 x (4x32 px) on 8 waves (JP_P9_M256=0 turns that variant off)
 inline bool p9_m256() {
@@ -2475,6 +2478,17 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         if (use_p1) {      // 1x1: weights stream in fragment order, two channel chunks of the pixel tile staged per barrier pair
             if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, p9_bmt(Cout, 1, p9_ptiles(N, H, W)), 1, st);
             launch_p1(ws, x0, e, Cout, Cin, N, H, W, st);
+            JP_LAUNCH_CHECK();
+        }
+        if (KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && c1 == 0 && c2 == 0 && !up0 && p9s_enabled() &&
+            p9s2_enabled() && H == 2 * OH && W == 2 * OW && OH % 4 == 0 && OW % 32 == 0 && Cin % 16 == 0 && Cin >= 32 && Cout > 64 &&
+            (long)N * Cin * H * W * 4 < (1L << 31) && (long)jp_cdiv(Cout, 128) * N * (OH / 4) * (OW / 32) >= 192) {
+            // 3x3 stride 2: P9S2F patch kernel (igemm_p9s2f.h) on the P9S forward pack (instead of the tap-major one)
+            if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, 128, 9, st);
+            jp_prof_before(p9s2f_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * 9.0 * Cin, st);
+            hipLaunchKernelGGL((jp_igemm_p9s2f_kernel<FwdEpi>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(Cout, 128), 1), dim3(256), 0, st,
+                               reinterpret_cast<const unsigned*>(ws), x0, e, Cout, Cin, Cin / 16, OH, OW);
+            jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }
         if (use_p9) {
@@ -3213,6 +3227,9 @@ extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, voi
     hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 4095) / 4096, 16384)), dim3(256), 0,
                        (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
     // the split-bf16 packs of the table: LDS-staged, grid-stride over their work items (a block without an item returns)
-    hipLaunchKernelGGL(pack_split_replay_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
+    // (its job-prefix table lives in LDS: 2048 jobs per launch -- a model has a few hundred; longer tables go in slices)
+    for (int off = 0; off < njobs; off += 2048)
+        hipLaunchKernelGGL(pack_split_replay_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs + off,
+                           std::min(2048, njobs - off));
     JP_LAUNCH_CHECK();
 }

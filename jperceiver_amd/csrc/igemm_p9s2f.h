@@ -1,0 +1,172 @@
+// "P9S2F" patch kernel: FORWARD of a 3x3 STRIDE-2 pad-1 (zero) convolution on the bf16 matrix pipe (split products,
+// igemm_p9s.h):  y[co][oy][ox] = act(b[co] + sum W[co][c][ky][kx] * x[c][2oy+ky-1][2ox+kx-1]).
+// GEMM M = co, N = output pixels, K = (16-channel stage of c, 9 taps).  Tiling as P9S: workgroup = 2x2 waves, 128 rows x
+// (4 output rows x 32 columns).  Per stage the (2*4+1) x 65 full-resolution patch is staged once, split into bf16 triples, its
+// columns DE-INTERLEAVED by parity ([33 odd | 32 even]: tap kx = 0 / 2 reads odd position q / q+1, kx = 1 even position q), so
+// the 32 stride-2 pixels of a tap are 32 consecutive 16-byte LDS words at a compile-time offset.  Weights: the P9S forward
+// pack (PACK_SPLIT, 9 steps per stage), streamed from L2 one step ahead.
+// Preconditions (host-checked): OH % 4 == 0, OW % 32 == 0, H == 2*OH, W == 2*OW, Cin % 16 == 0; rows in tiles of 128.
+#pragma once
+#include "igemm_p9s.h"
+
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void jp_igemm_p9s2f_kernel(const unsigned* __restrict__ wp, const float* __restrict__ x,
+                                                                Epi epi, int M, int C, int NST, int OH, int OW) {
+    constexpr int NT = 256, WN = 2, NJ = 2, TR = WN * NJ;
+    constexpr int PR = 2 * TR + 1, COLS = 65, PODD = 34, PITS = PODD + 32;
+    constexpr int PLS = PR * PITS;                           // 16-byte words per (split, k-half) plane
+    constexpr int ITEMS = 2 * PR * COLS, NQ = (ITEMS + NT - 1) / NT;
+    constexpr int STEPS = 9, BMT = 128;
+    constexpr int SBYTES = 3 * 2 * BMT * 16;
+    __shared__ jp_u32x4 patch[3 * 2 * PLS];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int mt, nt;
+    {   // XCD band order, see jp_igemm_kernel
+        const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
+        const int L = blockIdx.x + blockIdx.y * gx;
+        if (L < G * gy) {
+            const int j = L >> 3;
+            mt = j % gy;
+            nt = (L & 7) * (G >> 3) + j / gy;
+        } else {
+            const int i = L - G * gy;
+            mt = i % gy;
+            nt = G + i / gy;
+        }
+    }
+    const int H = 2 * OH, W = 2 * OW;
+    const int tiles_x = OW / 32, tiles_y = OH / TR;
+    const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
+    const int i0 = (tr_ / tiles_x) * TR, j0 = (tr_ % tiles_x) * 32;
+    const int m0 = mt * BMT;
+    const long HW = (long)H * W;
+    const float* xin = x + (long)img * C * HW;
+
+    // ---- staging map: item e = t + NT*q -> (patch column 0..64 <-> input column 2*j0 - 1 + col, patch row, k-half)
+    unsigned soff[NQ];                                       // byte offset inside the image, bit 0 set = zero
+    int loff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = t + NT * q;
+        const int col = e % COLS, rp = e / COLS, pr = rp % PR, kh = rp / PR;
+        const int yy = 2 * i0 - 1 + pr, xx = 2 * j0 - 1 + col;
+        const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        soff[q] = ok ? (unsigned)(kh * 8 * HW + (long)yy * W + xx) * 4u : 1u;
+        // patch column col: even col <-> odd input column (index col/2 of the odd plane), odd col <-> even input column
+        loff[q] = e < ITEMS ? (kh * PR + pr) * PITS + ((col & 1) ? PODD : 0) + (col >> 1) : -1;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)((long)C * HW * 4), 0x00020000);
+    float rv[NQ][8];
+    auto gload = [&](int stage) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ub = __builtin_amdgcn_readfirstlane((int)(((long)stage * 16 + k) * HW * 4));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float v = jp_gather(xrs, soff[q] & ~1u, ub);
+                rv[q][k] = (soff[q] & 1u) ? 0.f : v;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (loff[q] < 0) continue;
+            jp_u32x4 w0, w1, w2_;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned a, b, c;
+                jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
+                w0[k] = a; w1[k] = b; w2_[k] = c;
+            }
+            patch[loff[q]] = w0;
+            patch[2 * PLS + loff[q]] = w1;
+            patch[4 * PLS + loff[q]] = w2_;
+        }
+    };
+
+    jp_f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const long tile_bytes = ((long)NST * STEPS + P9S_AHEAD) * SBYTES;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)mt * tile_bytes, 0, (int)tile_bytes, 0x00020000);
+    const int avo = (lhi * BMT + wm * 64 + l31) * 16;
+    jp_u32x4 ra[2][2][3];
+    auto aload = [&](int slot, int step_bytes) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
+    };
+    aload(0, 0);
+    // B fragment of tap (ky, kx), output row j of the wave: patch row 2*(wn*NJ + j) + ky, position (kx == 1 ? PODD : 0) + l31 + (kx == 2)
+    const jp_u32x4* bp = patch + (lhi * PR + 2 * wn * NJ) * PITS + l31;
+    jp_u32x4 rb[2][NJ][3];
+    auto bload = [&](int slot, int u) {
+        const int ky = u / 3, kx = u % 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+                rb[slot][j][sp] = bp[sp * 2 * PLS + (2 * j + ky) * PITS + (kx == 1 ? PODD : 0) + (kx == 2 ? 1 : 0)];
+    };
+#define JP_P9S2F_MFMA(SA_, SB_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR + u) & 1][i][SA_]),    \
+                                                            __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
+    // PAR = stage parity: 9 steps per stage, the weight ring slot of a step is (global step) & 1
+    auto run_stage = [&](auto par_tag, int stage) {
+        constexpr int PAR = decltype(par_tag)::value;
+        lstore();
+        __syncthreads();
+        if (stage + 1 < NST) gload(stage + 1);
+        const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
+        bload(0, 0);
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            aload((PAR + u + 1) & 1, ab + (u + 1) * SBYTES);
+            if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            JP_P9S2F_MFMA(2, 0);
+            JP_P9S2F_MFMA(1, 1);
+            JP_P9S2F_MFMA(0, 2);
+            JP_P9S2F_MFMA(1, 0);
+            JP_P9S2F_MFMA(0, 1);
+            JP_P9S2F_MFMA(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    gload(0);
+    for (int stage = 0; stage < NST; stage += 2) {
+        run_stage(std::integral_constant<int, 0>{}, stage);
+        if (stage + 1 < NST) run_stage(std::integral_constant<int, 1>{}, stage + 1);
+    }
+#undef JP_P9S2F_MFMA
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = img * (OH * OW) + (i0 + wn * NJ + j) * OW + j0 + l31;
+        const typename Epi::St se = epi.col(p);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < M) epi.put(se, m, acc[i][j][r]);
+            }
+        }
+    }
+}

@@ -148,6 +148,8 @@ def param(p: torch.nn.Parameter) -> Var:
 # afterwards `PackRegistry.refresh_all()` (called by Baseline.forward) re-packs every layer of the model with ONE
 # kernel launch whenever the weights changed (FlatAdam.step / load_state_dict / .to() bump the epoch, in-place edits of
 # a parameter are caught through its version counter), and the conv entry points run with ws_state=1.
+import weakref
+
 import numpy as np
 
 _JOB_DT = np.dtype([("w", "u8"), ("wp", "u8"), ("total", "i8"), ("begin", "i8"), ("mode", "i4"), ("p", "i4", (6,)),
@@ -161,7 +163,13 @@ def weights_changed():
 
 
 class _PackEntry:
-    __slots__ = ("ws", "jobs", "ptr", "epoch", "param", "ver")
+    """One layer's packed-weight scratch.  The parameter is held WEAKLY: when its model is dropped the entry (scratch and pack
+    jobs) goes with it instead of being replayed for ever."""
+    __slots__ = ("ws", "jobs", "ptr", "epoch", "_param", "ver")
+
+    @property
+    def param(self):
+        return self._param()
 
 
 class PackRegistry:
@@ -186,20 +194,33 @@ class PackRegistry:
         key = (id(w.p), which, sig)
         e = self.entries.get(key)
         ptr = w.t.data_ptr()
-        if e is None or e.ptr != ptr or e.ws.numel() != nfloats:
+        if e is None or e.ptr != ptr or e.ws.numel() != nfloats or e.param is not w.p:
             e = _PackEntry()
-            e.ws, e.jobs, e.ptr, e.epoch, e.param, e.ver = _new((nfloats,), w.t), None, ptr, -1, w.p, -1
+            e.ws, e.jobs, e.ptr, e.epoch, e.ver = _new((nfloats,), w.t), None, ptr, -1, -1
+            e._param = weakref.ref(w.p, lambda _r, key=key, reg=weakref.ref(self): PackRegistry._drop(reg, key, _r))
             self.entries[key] = e
             self.table = None
         return e
+
+    @staticmethod
+    def _drop(reg, key, ref):
+        self = reg()
+        if self is None:
+            return
+        e = self.entries.get(key)
+        if e is not None and e._param is ref:        # (the id may already belong to a newer parameter's entry)
+            del self.entries[key]
+            self.table = None
 
     def refresh_all(self):
         """One launch re-packs every registered layer if any weight changed since the last refresh."""
         if not self.entries:
             return
         vs = 0
-        for e in self.entries.values():
-            vs += e.param._version
+        for e in list(self.entries.values()):
+            p = e.param
+            if p is not None:
+                vs += p._version
         if vs != self.versions:
             if self.versions is not None:
                 weights_changed()
@@ -209,7 +230,8 @@ class PackRegistry:
         if not stale:
             return
         if self.table is None:
-            live = [e for e in self.entries.values() if e.jobs is not None and e.ptr == e.param.data_ptr()]
+            live = [e for e in self.entries.values()
+                    if e.jobs is not None and e.param is not None and e.ptr == e.param.data_ptr()]
             jobs = np.concatenate([e.jobs for e in live]) if live else None
             if jobs is None or len(jobs) == 0:
                 return
@@ -221,7 +243,9 @@ class PackRegistry:
         dev, n, total, live = self.table
         call("jp_pack_replay", dev, n, total)
         for e in live:
-            e.epoch, e.ver = ep, e.param._version
+            p = e.param
+            if p is not None:
+                e.epoch, e.ver = ep, p._version
 
 
 def _conv_call(name, w: Var, which: str, sig, nfloats: int, args_before_ws, args_after_ws):

@@ -67,6 +67,9 @@ def _split_name(w):
         return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2>"            # narrow twin: two K groups per workgroup
     if w == "jp_wgrad_w1_kernel" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w1s_kernel"
+    if w == "S2F":                                                   # stride-2 forward: patch kernel (igemm_p9s2f.h) or the generic engine
+        on = os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0"
+        return "jp_igemm_p9s2f_kernel" if on else "jp_igemm_kernel"
     if w == "DgradS2B" and os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0":
         return "jp_igemm_p9s2d_kernel"                                # class-uniform stride-2 dgrad (igemm_p9s2d.h)
     if w == "WgradAP, WgradBP" and os.environ.get("JP_W9S", "1") != "0":
@@ -116,9 +119,9 @@ BENCH_CONV = [
      ["jp_igemm_p9_kernel<2, 2, false, true, DgradEpi, 9, 1>"],
      ["jp_wgrad_w9_kernel<2, 2, 1, false>"]),
     ("ResNet layer2.0 64->128 3x3 stride 2 @256^2", (8, 64, 256, 256, 128, 3, 2, 1, 0, 0, False),
-     ["jp_igemm_kernel"], ["DgradS2B"], ["jp_igemm_kernel"]),
+     ["S2F"], ["DgradS2B"], ["jp_igemm_kernel"]),
     ("ResNet layer3.0 128->256 3x3 stride 2 @128^2", (8, 128, 128, 128, 256, 3, 2, 1, 0, 0, False),
-     ["jp_igemm_kernel"], ["DgradS2B"], ["jp_igemm_kernel"]),
+     ["S2F"], ["DgradS2B"], ["jp_igemm_kernel"]),
     ("downsample 64->128 1x1 stride 2 @256^2", (8, 64, 256, 256, 128, 1, 2, 0, 0, 0, False), ["jp_igemm"], ["jp_igemm"], ["jp_igemm"]),
     ("stem 3->64 7x7 stride 2 @1024^2", (8, 3, 1024, 1024, 64, 7, 2, 3, 0, 0, False),
      ["FwdBC<7, 4>"], [], ["jp_wgrad_w7_kernel<3>"]),

@@ -73,3 +73,47 @@ def test_replayed_packs_equal_first_use_packs(ty, HW, B):
     assert torch.equal(ra["top"], rb["top"])
     ga, gb = ra["grads"], rb["grads"]
     assert float((ga - gb).norm() / gb.norm()) < 1e-5
+
+
+def test_registry_forgets_dropped_models_and_replays_long_tables():
+    """Pack entries die with their parameters (a registry that kept every model it ever saw alive replayed all of them each
+    step), and a replay table longer than the split-replay kernel's 2048-job LDS prefix is still replayed completely."""
+    import gc
+    import numpy as np
+    from jperceiver_amd import ops
+    from jperceiver_amd.ops import Var, PackRegistry, param
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    reg = PackRegistry.of(dev)
+    gc.collect()
+    before = len(reg.entries)
+    g = torch.Generator().manual_seed(3)
+    x = Var(torch.randn(8, 128, 64, 64, generator=g).cuda())        # enough pixel tiles for the split-bf16 patch kernel
+
+    def make(n):
+        ps = [torch.nn.Parameter(torch.randn(128, 128, 3, 3, generator=g).cuda() * 0.03) for _ in range(n)]
+        for p in ps:
+            with ops.recording(ops.Tape()):
+                ops.conv2d(x, param(p), None, 1, 1, 0, 0)
+        return ps
+
+    ps = make(3)
+    assert len(reg.entries) == before + 3
+    del ps
+    gc.collect()
+    assert len(reg.entries) == before
+
+    # > 2048 split-pack jobs in one table: the last layer's pack must still follow its weights
+    ps = make(2100)
+    last = ps[-1]
+    with ops.recording(ops.Tape()):
+        y0 = ops.conv2d(x, param(last), None, 1, 1, 0, 0).t.clone()
+    with torch.no_grad():
+        last.mul_(2.0)                      # in-place edit: caught through the version counter
+    reg.refresh_all()
+    with ops.recording(ops.Tape()):
+        y1 = ops.conv2d(x, param(last), None, 1, 1, 0, 0).t
+    assert torch.allclose(y1, 2.0 * y0, rtol=1e-5, atol=1e-6), float((y1 - 2.0 * y0).abs().max())
+    del ps, last
+    gc.collect()
+    assert len(reg.entries) == before

@@ -1,4 +1,5 @@
-"""Accuracy of the split-product kernels (igemm_p9s.h / igemm_w9s.h / igemm_p9us.h) against FLOAT64.
+"""Accuracy of the split-product kernels (igemm_p9s.h / igemm_w9s.h / igemm_p9us.h / igemm_p9sd.h / igemm_w4s.h / igemm_p9s2*.h)
+against FLOAT64.
 
 The patch convolutions form every fp32 product on the bf16 matrix pipe as 6 bf16 products of exact three-way bf16 splits
 of both operands, accumulated in fp32.  The claim that makes this "fp32 arithmetic" rather than reduced precision is
@@ -43,23 +44,23 @@ def _emit():
         return dict(rms=float(e.pow(2).mean().sqrt() / ref64.pow(2).mean().sqrt()), max=float(e.max() / ref64.abs().max()),
                     rel_bound=float((e / bound64.clamp_min(1e-300)).max()))
 
-    def conv_case(name, N, Cin, H, W, Cout, K, pad, pm, wide):
+    def conv_case(name, N, Cin, H, W, Cout, K, pad, pm, wide, stride=1):
         g = torch.Generator().manual_seed(11)
         x, w = data((N, Cin, H, W), g, wide), data((Cout, Cin, K, K), g, wide) * (Cin * K * K) ** -0.5
-        gy = data((N, Cout, H, W), g, wide)
+        gy = data((N, Cout, (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1), g, wide)
         xv, wv = Var(x.cuda(), True), Var(w.cuda(), True, torch.zeros_like(w).cuda())
         tape = Tape()
         with recording(tape):
-            y = ops.conv2d(xv, wv, None, 1, pad, pm, 0)
+            y = ops.conv2d(xv, wv, None, stride, pad, pm, 0)
         y.g = gy.cuda()
         tape.backward()
         xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
         pad_ = (lambda t: F.pad(t, (pad,) * 4, mode="reflect")) if (pm == 1 and pad) else (lambda t: t)
-        yd = F.conv2d(pad_(xd), wd, None, 1, 0 if pm == 1 else pad)
+        yd = F.conv2d(pad_(xd), wd, None, stride, 0 if pm == 1 else pad)
         yd.backward(gy.double())
         # sum |a||b| bounds of the three GEMMs
         xa, wa, ga = x.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True), gy.double().abs()
-        ya = F.conv2d(pad_(xa), wa, None, 1, 0 if pm == 1 else pad)
+        ya = F.conv2d(pad_(xa), wa, None, stride, 0 if pm == 1 else pad)
         ya.backward(ga)
         res[name + "/fwd"] = metrics(y.t.cpu(), yd.detach(), ya.detach())
         res[name + "/dgrad"] = metrics(xv.g.cpu(), xd.grad, xa.grad)
@@ -70,6 +71,7 @@ def _emit():
         conv_case(f"3x3_zero_128_{tag}", 8, 128, 64, 64, 128, 3, 1, 0, wide)
         conv_case(f"3x3_reflect_256_{tag}", 8, 256, 64, 64, 256, 3, 1, 1, wide)
         conv_case(f"1x1_256_{tag}", 8, 256, 64, 64, 256, 1, 0, 0, wide)
+        conv_case(f"3x3_stride2_64_128_{tag}", 8, 64, 128, 128, 128, 3, 1, 0, wide, stride=2)      # P9S2F / P9S2D
         # iconv (P9US): cat(skip 64, up2x(x 96), disp 1) -> 256, reflect
         g = torch.Generator().manual_seed(12)
         N, H, W, Cr, Cx, Cout = 2, 64, 128, 64, 96, 256
@@ -81,6 +83,26 @@ def _emit():
         yd = F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), w.double())
         ya = F.conv2d(F.pad(cat.abs(), (1, 1, 1, 1), mode="reflect"), w.double().abs())
         res[f"iconv_{tag}/fwd"] = metrics(y.t.cpu(), yd, ya)
+        # iconv backward of the upsampled segment (P9SD dgrad at half resolution, W4S weight gradient): cat(skip 128, up2x(x 128))
+        g = torch.Generator().manual_seed(13)
+        N, H, W, Cr, Cx, Cout = 4, 128, 128, 128, 128, 256
+        r, xh = data((N, Cr, H, W), g, wide), data((N, Cx, H // 2, W // 2), g, wide)
+        w = data((Cout, Cr + Cx, 3, 3), g, wide) * (9 * (Cr + Cx)) ** -0.5
+        gy = data((N, Cout, H, W), g, wide)
+        rv_, xv_, wv_ = Var(r.cuda(), True), Var(xh.cuda(), True), Var(w.cuda(), True, torch.zeros_like(w).cuda())
+        tape = Tape()
+        with recording(tape):
+            y = ops.conv2d(None, wv_, None, 1, 1, 1, 0, srcs=[(rv_, 0), (xv_, 1)])
+        y.g = gy.cuda()
+        tape.backward()
+        xd, wd = xh.double().requires_grad_(True), w.double().requires_grad_(True)
+        cat = torch.cat((r.double(), F.interpolate(xd, scale_factor=2, mode="nearest")), 1)
+        F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), wd).backward(gy.double())
+        xa, wa = xh.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True)
+        cata = torch.cat((r.double().abs(), F.interpolate(xa, scale_factor=2, mode="nearest")), 1)
+        F.conv2d(F.pad(cata, (1, 1, 1, 1), mode="reflect"), wa).backward(gy.double().abs())
+        res[f"iconv_up_{tag}/dgrad"] = metrics(xv_.g.cpu(), xd.grad, xa.grad)
+        res[f"iconv_up_{tag}/wgrad"] = metrics(wv_.g.cpu()[:, Cr:], wd.grad[:, Cr:], wa.grad[:, Cr:])
     print("JSON" + json.dumps(res))
 
 
@@ -94,8 +116,8 @@ def _run(env_extra):
 
 
 def test_split_product_accuracy_vs_float64():
-    split = _run(dict(JP_P9S="1", JP_W9S="1", JP_P9US="1"))
-    exact = _run(dict(JP_P9S="0", JP_W9S="0", JP_P9US="0"))
+    split = _run(dict(JP_P9S="1", JP_W9S="1", JP_P9US="1", JP_P9SD="1", JP_P9S2="1"))
+    exact = _run(dict(JP_P9S="0", JP_W9S="0", JP_P9US="0", JP_P9SD="0", JP_P9S2="0"))
     assert set(split) == set(exact)
     report = []
     for k in sorted(split):
