@@ -1487,6 +1487,23 @@ struct DgradS2Epi {  // dx[img][ci][2i+py][2j+px] (= or +=) acc
     }
 };
 
+struct DgradS2PointEpi {  // dgrad of a 1x1 stride-2 conv: dx[img][ci][2i][2j] (= or +=) acc, the other three pixels of the 2x2 cell = 0
+    typedef size_t St;
+    float* dx;
+    int Cin, ohw, OW, accumulate;
+    __device__ __forceinline__ St col(int p) const {
+        const int img = p / ohw, pix = p - img * ohw;
+        const int i = pix / OW, j = pix - i * OW;
+        return (size_t)img * Cin * (4 * ohw) + (size_t)(2 * i) * (2 * OW) + 2 * j;
+    }
+    __device__ __forceinline__ void put(St base, int m, float v) const {
+        float* q = dx + base + (size_t)m * (4 * ohw);
+        if (accumulate) { *q += v; return; }
+        *reinterpret_cast<float2*>(q) = make_float2(v, 0.f);
+        *reinterpret_cast<float2*>(q + 2 * OW) = make_float2(0.f, 0.f);
+    }
+};
+
 // Border pass of the reflection-pad adjoint.  N enumerates the 2W+2H border-adjacent pixels of every image
 // (rows 1 and H-2, columns 1 and W-2; duplicates masked); the gather returns only the folded-in ("extra")
 // dY entries: row extras r1 = 0 (y==1, ty==0) / H-1 (y==H-2, ty==2), column extras likewise.
@@ -2121,6 +2138,30 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
     }
     jp_prof_after(st);
 }
+// 1x1 stride-2 (ResNet downsample branches) on the same tiles: forward = P9S with a stride-2 staging gather (igemm_p9s.h, XS = 2);
+// dgrad = the stride-1 kernel over the half-resolution grid with a scattering epilogue (DgradS2PointEpi)
+template <int WM, int WN, class E>
+const char* p9sx2_tag() { return __PRETTY_FUNCTION__; }
+inline bool p1s2_ok(int rows, int red, int N, int OH, int OW) {
+    const int tr = rows <= 64 ? 8 : 4;
+    return p9s_enabled() && p9s2_enabled() && rows >= 32 && red >= 64 && red % 64 == 0 && OW % 32 == 0 && OH % tr == 0 &&
+           (long)N * red * OH * OW * 16 < (1L << 31) &&
+           (long)jp_cdiv(rows, p9_bmt(rows, 1, p9_ptiles(N, OH, OW))) * N * (OH / tr) * (OW / 32) >= 192;
+}
+template <class E>
+void launch_p1s2(const float* wp, const float* x, E e, int rows, int red, int N, int OH, int OW, hipStream_t st) {
+    const int bmt = p9_bmt(rows, 1, p9_ptiles(N, OH, OW)), NST = red / 32;
+    const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
+    jp_prof_before(bmt == 64 ? p9sx2_tag<1, 4, E>() : (bmt == 256 ? p9sx2_tag<4, 2, E>() : p9sx2_tag<2, 2, E>()),
+                   6.0 * 2.0 * rows * (double)N * OH * OW * red, st);
+    if (bmt == 64)
+        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<1, 4, 2, E>), dim3(N * (OH / 8) * (OW / 32), 1, 1), dim3(256), 0, st, wq, x, e, rows, red, NST, OH, OW, 0);
+    else if (bmt == 256)
+        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<4, 2, 2, E>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(rows, 256), 1), dim3(512), 0, st, wq, x, e, rows, red, NST, OH, OW, 0);
+    else
+        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<2, 2, 2, E>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(rows, 128), 1), dim3(256), 0, st, wq, x, e, rows, red, NST, OH, OW, 0);
+    jp_prof_after(st);
+}
 template <bool REFLECT, bool REV, class E>
 void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off = 0,
                int bank_rows = -1) {
@@ -2475,6 +2516,12 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                             c2 == 0 && p9_ok(Cout, Cin, N, H, W);
         const bool use_p1 = KH == 1 && stride == 1 && pad == 0 && !((c0 && up0) || (c1 && up1) || (c2 && up2)) && c1 == 0 &&
                             c2 == 0 && p9_ok(Cout, Cin, N, H, W, 1);
+        if (KH == 1 && stride == 2 && pad == 0 && c1 == 0 && c2 == 0 && !up0 && H % 2 == 0 && W % 2 == 0 &&
+            p1s2_ok(Cout, Cin, N, OH, OW)) {
+            if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, p9_bmt(Cout, 1, p9_ptiles(N, OH, OW)), 1, st);
+            launch_p1s2(ws, x0, e, Cout, Cin, N, OH, OW, st);
+            JP_LAUNCH_CHECK();
+        }
         if (use_p1) {      // 1x1: weights stream in fragment order, two channel chunks of the pixel tile staged per barrier pair
             if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, p9_bmt(Cout, 1, p9_ptiles(N, H, W)), 1, st);
             launch_p1(ws, x0, e, Cout, Cin, N, H, W, st);
@@ -2642,6 +2689,15 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                 hipLaunchKernelGGL((jp_igemm_p9s2d_kernel<2, 2, 2, DgradEpi>), dim3(4 * N * (OH / 4) * (OW / 32), jp_cdiv(Cin, 128), 1),
                                    dim3(256), 0, st, wq, dy, e, Cin, Cout, NST, OH, OW);
             jp_prof_after(st);
+            JP_LAUNCH_CHECK();
+        }
+        if (KH == 1 && stride == 2 && pad == 0 && H % 2 == 0 && W % 2 == 0 && 2 * OH == H && 2 * OW == W && p1s2_ok(Cin, Cout, N, OH, OW)) {
+            // 1x1 stride 2: the stride-1 1x1 kernel over the half-resolution dY, scattering epilogue
+            float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
+            const int bmt = p9_bmt(Cin, 1, p9_ptiles(N, OH, OW));
+            if (!ws_state) pack_p9(w, wfr, Cout, Cin, 1, bmt, 1, st);
+            DgradS2PointEpi ep{dx, Cin, OH * OW, OW, accumulate};
+            launch_p9s<false, false, DgradS2PointEpi, 1>(wfr, dy, ep, Cin, Cout, N, OH, OW, st, 0, bmt);
             JP_LAUNCH_CHECK();
         }
         if (!ws_state && !p9_only) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 1, st);

@@ -57,11 +57,13 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 #ifndef P9S_OCC
 #define P9S_OCC 2          // waves per SIMD the 4-wave variants are compiled for (3: <= 168 VGPRs, B fragments re-read per row)
 #endif
-template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
+// XS = input stride (1x1 only): output pixel (y, x) reads input pixel (XS*y, XS*x) of an (XS*H) x (XS*W) map.
+template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS, int XS>
+__device__ __forceinline__ void jp_igemm_p9s_body(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     constexpr int NT = 64 * WM * WN;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
+    static_assert(XS == 1 || TAPS == 1, "strided input: 1x1 only");
     constexpr int HALO = TAPS == 9 ? 1 : 0;
     constexpr int TR = WN * NJ, PR = TR + 2 * HALO, COLS = 32 + 2 * HALO;
     constexpr int KH = 2 * KGS;                               // k-halves (8 channels each) per stage
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC :
     const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
     const int y0 = (tr_ / tiles_x) * TR, x0 = (tr_ % tiles_x) * 32;
     const int m0 = mt * BMT;
-    const long HW = (long)H * W;
-    const float* xin = x + (long)img * C * HW;
+    const long HW = (long)H * W, HWI = HW * XS * XS;
+    const float* xin = x + (long)img * C * HWI;
 
     // ---- staging map: item e = t + NT*q -> (k-half, patch row, column); source offset relative to the stage's first
     // channel (or -1: zero), LDS word index
@@ -108,15 +110,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC :
         int yy = y0 - HALO + pr, xx = x0 - HALO + col;
         if (REFLECT) { yy = jp_reflect(yy, H); xx = jp_reflect(xx, W); }
         const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        soff[q] = ok ? (unsigned)(kh * 8 * HW + (long)yy * W + xx) * 4u : 1u;
+        soff[q] = ok ? (unsigned)(kh * 8 * HWI + (long)(yy * XS) * (W * XS) + xx * XS) * 4u : 1u;
         loff[q] = e < ITEMS ? (kh * PR + pr) * COLS + col : -1;
     }
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)((long)C * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)((long)C * HWI * 4), 0x00020000);
     float rv[NQ][8];
     auto gload = [&](int stage) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int ub = __builtin_amdgcn_readfirstlane((int)(((long)stage * CS + k) * HW * 4));
+            const int ub = __builtin_amdgcn_readfirstlane((int)(((long)stage * CS + k) * HWI * 4));
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const float v = jp_gather(xrs, soff[q] & ~1u, ub);
@@ -272,4 +274,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC :
             }
         }
     }
+}
+
+template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
+    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off);
+}
+// 1x1 stride-2 (the ResNet downsample branches): same tiles, the staging gather reads every second input pixel
+template <int WM, int WN, int NJ, class Epi>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_x2_kernel(
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
+    jp_igemm_p9s_body<WM, WN, NJ, false, false, Epi, 1, 2, 2>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
