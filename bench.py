@@ -606,15 +606,19 @@ def measure_roofline(runner, batch, B, t_step, rank):
                             "kernels": [f"{n} {m:.3f}" for n, m in zip(k[2], v["kernel_ms"])]}
                            for k, v in sorted(layers.items(), key=lambda kv: -kv[1]["ms"])]
     # HBM-bound entry points: algorithmic bytes against the event time of the same (single-stream) step
-    hb = {}
+    hb, hb_shape = {}, {}
     for (name, e0, e1, lo, hi, shp), args in zip(calls, call_args):
         by = _hbm_bytes(name, args)
         if by is None:
             continue
-        d = hb.setdefault(name, [0, 0.0, 0.0])
-        d[0] += 1
-        d[1] += e0.elapsed_time(e1)
-        d[2] += by
+        ints = tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool) and abs(x) < (1 << 28))
+        for d in (hb.setdefault(name, [0, 0.0, 0.0]), hb_shape.setdefault((name, ints), [0, 0.0, 0.0])):
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += by
+    table["hbm_calls"] = [{"entry": k[0], "ints": list(k[1]), "calls": v[0], "ms": round(v[1], 3),
+                           "algorithmic_TBps": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
+                          for k, v in sorted(hb_shape.items(), key=lambda kv: -kv[1][1])[:40]]
     table["hbm_entry_points"] = [{"entry": k, "calls": v[0], "ms": round(v[1], 3), "algorithmic_GB": round(v[2] / 1e9, 3),
                                   "algorithmic_TBps": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
                                  for k, v in sorted(hb.items(), key=lambda kv: -kv[1][1])]

@@ -378,10 +378,77 @@ __global__ __launch_bounds__(TPB) void maxpool5_rows_bwd_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------ 3x3 stride-2 pad-1 max pool backward (the ResNet stem)
+// Output (i, j) covers input rows 2i-1 .. 2i+1, so the 2x2 input cell (2i .. 2i+1, 2j .. 2j+1) gathers from the four outputs
+// (i .. i+1, j .. j+1) only: [2i][2j] <- (i,j) tap 4;  [2i][2j+1] <- (i,j) tap 5, (i,j+1) tap 3;  [2i+1][2j] <- (i,j) tap 7,
+// (i+1,j) tap 1;  [2i+1][2j+1] <- (i,j) tap 8, (i,j+1) tap 6, (i+1,j) tap 2, (i+1,j+1) tap 0.  A thread owns two output columns
+// (-> one float4 of each of the two input rows) and walks down a band of RB output rows, keeping the previous output row in
+// registers: dy and the argmax byte are read once, dx is written once with 16-byte stores.
+__global__ __launch_bounds__(TPB) void maxpool3s2_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                             float* __restrict__ dx, const float* __restrict__ addend, long units,
+                                                             int OH, int OW, int RB, int bands) {
+    const long u = (long)blockIdx.x * TPB + threadIdx.x;
+    if (u >= units) return;
+    const int OW2 = OW >> 1, W = 2 * OW;
+    const int q = (int)(u % OW2);
+    const long v = u / OW2;
+    const int b = (int)(v % bands);
+    const long nc = v / bands;
+    const int i0 = b * RB, i1 = min(OH, i0 + RB);
+    const float* dp = dy + nc * (long)OH * OW + 2 * q;
+    const uint8_t* ip = idx + nc * (long)OH * OW + 2 * q;
+    float* op = dx + nc * 4L * OH * OW + 4 * q;
+    const float* ap = addend ? addend + nc * 4L * OH * OW + 4 * q : nullptr;
+    const bool right = 2 * q + 2 < OW;
+    float g[2][3];                 // [row parity: current / next][output columns 2q, 2q+1, 2q+2]
+    int k[2][3];
+    auto load = [&](int slot, int i) {
+        if (i < OH) {
+            const float2 a = *reinterpret_cast<const float2*>(dp + (long)i * OW);
+            const uchar2 c = *reinterpret_cast<const uchar2*>(ip + (long)i * OW);
+            g[slot][0] = a.x; g[slot][1] = a.y; k[slot][0] = c.x; k[slot][1] = c.y;
+            g[slot][2] = right ? dp[(long)i * OW + 2] : 0.f;
+            k[slot][2] = right ? (int)ip[(long)i * OW + 2] : -1;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { g[slot][c] = 0.f; k[slot][c] = -1; }
+        }
+    };
+    load(0, i0);
+    for (int i = i0; i < i1; ++i) {
+        load(1, i + 1);
+        float4 r0, r1;
+        // input row 2i, columns 4q .. 4q+3 (outputs of row i only)
+        r0.x = k[0][0] == 4 ? g[0][0] : 0.f;
+        r0.y = (k[0][0] == 5 ? g[0][0] : 0.f) + (k[0][1] == 3 ? g[0][1] : 0.f);
+        r0.z = k[0][1] == 4 ? g[0][1] : 0.f;
+        r0.w = (k[0][1] == 5 ? g[0][1] : 0.f) + (k[0][2] == 3 ? g[0][2] : 0.f);
+        // input row 2i+1 (outputs of rows i and i+1)
+        r1.x = (k[0][0] == 7 ? g[0][0] : 0.f) + (k[1][0] == 1 ? g[1][0] : 0.f);
+        r1.y = (k[0][0] == 8 ? g[0][0] : 0.f) + (k[0][1] == 6 ? g[0][1] : 0.f) + (k[1][0] == 2 ? g[1][0] : 0.f) + (k[1][1] == 0 ? g[1][1] : 0.f);
+        r1.z = (k[0][1] == 7 ? g[0][1] : 0.f) + (k[1][1] == 1 ? g[1][1] : 0.f);
+        r1.w = (k[0][1] == 8 ? g[0][1] : 0.f) + (k[0][2] == 6 ? g[0][2] : 0.f) + (k[1][1] == 2 ? g[1][1] : 0.f) + (k[1][2] == 0 ? g[1][2] : 0.f);
+        if (ap) {
+            const float4 a0 = *reinterpret_cast<const float4*>(ap + (long)(2 * i) * W);
+            const float4 a1 = *reinterpret_cast<const float4*>(ap + (long)(2 * i + 1) * W);
+            r0.x += a0.x; r0.y += a0.y; r0.z += a0.z; r0.w += a0.w;
+            r1.x += a1.x; r1.y += a1.y; r1.z += a1.z; r1.w += a1.w;
+        }
+        *reinterpret_cast<float4*>(op + (long)(2 * i) * W) = r0;
+        *reinterpret_cast<float4*>(op + (long)(2 * i + 1) * W) = r1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { g[0][c] = g[1][c]; k[0][c] = k[1][c]; }
+    }
+}
+
 template <int L>
 static void launch_pool5_rows(bool fwd, const float* a, float* out, uint8_t* idx, const uint8_t* cidx, const float* addend,
                               int NC, int H, hipStream_t st) {
-    const int RB = H <= 64 ? H : 64, bands = jp_cdiv(H, RB), G = 64 / L;
+    // band height: enough (plane, band) units for >= ~16 waves per CU (a wave has one row load in flight) -- 4 halo rows per band
+    const int G = 64 / L;
+    int RB = H <= 64 ? H : 64;
+    while (RB > 16 && (long)NC * jp_cdiv(H, RB) / G < 4096) RB >>= 1;
+    const int bands = jp_cdiv(H, RB);
     const long units = (long)NC * bands;
     const dim3 grid((unsigned)jp_cdiv(units, 4L * G));
     if (fwd) hipLaunchKernelGGL((maxpool5_rows_fwd_kernel<L>), grid, dim3(TPB), 0, st, a, out, idx, NC, H, RB, bands);
@@ -966,6 +1033,13 @@ extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, co
     if (k == 5 && s == 1) {
         hipLaunchKernelGGL((maxpool_bwd_s1_kernel<5>), dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MPF_TH), NC), dim3(TPB), 0, st,
                            dy, idx, dx, addend, H, W, OH, OW, p);
+        JP_LAUNCH_CHECK();
+    }
+    if (k == 3 && s == 2 && p == 1 && H == 2 * OH && W == 2 * OW && OW % 2 == 0) {
+        const int RB = OH >= 128 ? 32 : 8, bands = jp_cdiv(OH, RB);
+        const long units = (long)NC * bands * (OW / 2);
+        hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)jp_cdiv(units, (long)TPB)), dim3(TPB), 0, st, dy, idx, dx, addend,
+                           units, OH, OW, RB, bands);
         JP_LAUNCH_CHECK();
     }
     // outputs that can cover a 64x8 input tile

@@ -236,7 +236,9 @@ def test_batchnorm_train(relu, res, nup, shape):
                                        # row-streaming 5x5 kernels (W = 32 / 64 / 128 / 256): several row bands, ragged last
                                        # band, dead lane groups in the last wave, many exact ties
                                        (5, 1, 2, 32, 32), (5, 1, 2, 64, 64), (5, 1, 2, 70, 128), (5, 1, 2, 130, 256),
-                                       (5, 1, 2, 7, 32), (5, 1, 2, 3, 64)])
+                                       (5, 1, 2, 7, 32), (5, 1, 2, 3, 64),
+                                       # 3x3 stride-2 stem backward (2x2-cell gather kernel): row bands (ragged last one), ties
+                                       (3, 2, 1, 64, 128), (3, 2, 1, 300, 64), (3, 2, 1, 2, 4)])
 def test_maxpool(k, s, p, H, W):
     x = rnd(2, 5, H, W, seed=1)
     if H > 30:
