@@ -30,6 +30,7 @@
 #include "igemm_w4s.h"
 #include "igemm_p9s2d.h"
 #include "igemm_p9s2f.h"
+#include "igemm_p7s.h"
 #include "igemm_w9.h"
 #include "igemm_p9u.h"
 #include "igemm_w7.h"
@@ -51,7 +52,7 @@ __device__ float jp_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 // The host keeps the descriptors of all layers in one device table and refreshes EVERY pack of the model with ONE
 // launch of jp_pack_replay per step (conv entry points then run with ws_state 1 = "scratch already packed"): ~310
 // tiny launches per step become one.
-enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7, PACK_SPLITSEG = 8, PACK_SPLITUPD = 9 };
+enum { PACK_TAP = 0, PACK_ROWMAJOR = 1, PACK_SEG = 2, PACK_UP_DGRAD = 3, PACK_FLIP = 4, PACK_FRAG = 5, PACK_FRAGSEG = 6, PACK_SPLIT = 7, PACK_SPLITSEG = 8, PACK_SPLITUPD = 9, PACK_SPLIT7 = 10 };
 struct JpPackJob {          // 64 bytes, mirrored by jperceiver_amd/ops.py (struct layout "PPqqi6i")
     const float* w;
     float* wp;
@@ -157,6 +158,25 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                 const int cc = c + k;
                 const int co = for_dgrad ? cc : m, ci = for_dgrad ? m : cc;
                 v[k] = cc < red ? w[((size_t)co * Cin + ci) * KHW + tap] : 0.f;
+            }
+            unsigned s0, s1, s2;
+            jp_split3(v[0], v[1], s0, s1, s2);
+            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+        }
+        case PACK_SPLIT7: {    // p = Cout (<= 64), Cin: 7x7 stem weights as bf16 three-way splits in the fragment order of the P7S kernel
+                               // (igemm_p7s.h): [step u = (c, tap-row pair v)][split][k-half][64 rows][4 words]; word w4 of k-half h =
+                               // the taps (ky = 2v + h, kx = 2*w4 + {0, 1}) of channel c = u / 4 (ky, kx = 7: zero padding)
+            const int Cout = p[0], Cin = p[1];
+            const int w4 = (int)(i & 3), m = (int)((i >> 2) & 63), khalf = (int)((i >> 8) & 1);
+            const long t = i >> 9;
+            const int sp = (int)(t % 3);
+            const long U = t / 3;
+            const int c = (int)(U >> 2), ky = 2 * (int)(U & 3) + khalf;
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int kx = 2 * w4 + k;
+                v[k] = (c < Cin && m < Cout && ky < 7 && kx < 7) ? w[(((size_t)m * Cin + c) * 7 + ky) * 7 + kx] : 0.f;
             }
             unsigned s0, s1, s2;
             jp_split3(v[0], v[1], s0, s1, s2);
@@ -2064,6 +2084,8 @@ template <int WM, int WN, class E>
 const char* p9s2d_tag() { return __PRETTY_FUNCTION__; }
 template <class E>
 const char* p9s2f_tag() { return __PRETTY_FUNCTION__; }
+template <int CIN, class E>
+const char* p7s_tag() { return __PRETTY_FUNCTION__; }
 // channels per M tile of a bank with `rows` rows: 64 x (8x32 px), 128 x (4x32 px), or -- 3x3 banks whose row count is a
 // multiple of 256 -- 256 x (4x32 px) on 8 waves (JP_P9_M256=0 turns that variant off)
 inline bool p9_m256() {
@@ -2432,6 +2454,19 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
     if (ws && Cin <= 8 && Cout <= 64 && c1 == 0 && c2 == 0 && !up0 && pad_mode != JP_PAD_REFLECT && (KH == 7 || KH == 3) &&
         npix / 256 >= 192 && (long)2 * Cin * H * W * 4 < (1L << 32)) {
+        if (KH == 7 && stride == 2 && pad == 3 && (Cin == 3 || Cin == 6) && p9s_enabled() && p9s2_enabled() && H == 2 * OH && W == 2 * OW &&
+            OH % 8 == 0 && OW % 32 == 0 && (long)Cin * H * W * 4 < (1L << 31)) {
+            // P7S stem kernel (igemm_p7s.h): split-bf16 products, the whole K of a tile staged once
+            const long tot = (4L * Cin + 1) * 1536;
+            if (!ws_state) do_pack(PACK_SPLIT7, w, ws, tot, Cout, Cin, 0, 0, 0, 0, st);
+            const int ntiles = N * (OH / 8) * (OW / 32);
+            const unsigned* wq = reinterpret_cast<const unsigned*>(ws);
+            jp_prof_before(Cin == 3 ? p7s_tag<3, FwdEpi>() : p7s_tag<6, FwdEpi>(), 6.0 * 2.0 * 64 * (double)npix * 64.0 * Cin, st);
+            if (Cin == 3) hipLaunchKernelGGL((jp_igemm_p7s_kernel<3, FwdEpi>), dim3(ntiles), dim3(256), 0, st, wq, x0, e, Cout, OH, OW, ntiles);
+            else hipLaunchKernelGGL((jp_igemm_p7s_kernel<6, FwdEpi>), dim3(ntiles), dim3(256), 0, st, wq, x0, e, Cout, OH, OW, ntiles);
+            jp_prof_after(st);
+            JP_LAUNCH_CHECK();
+        }
         // stem convs: whole taps per K chunk
         const int CP = Cin <= 4 ? 4 : 8;
         const int Kp = jp_cdiv(KH * KH * CP, KC) * KC;

@@ -67,6 +67,9 @@ def _split_name(w):
         return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2>"            # narrow twin: two K groups per workgroup
     if w == "jp_wgrad_w1_kernel" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w1s_kernel"
+    if w.startswith("STEM<"):                                        # 7x7 stem forward: P7S (igemm_p7s.h) or the generic engine's FwdBC
+        on = os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0"
+        return f"jp_igemm_p7s_kernel<{w[5]}" if on else ("FwdBC<7, 4>" if w[5] == "3" else "FwdBC<7, 8>")
     if w == "S2F":                                                   # stride-2 forward: patch kernel (igemm_p9s2f.h) or the generic engine
         on = os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0"
         return "jp_igemm_p9s2f_kernel" if on else "jp_igemm_kernel"
@@ -124,9 +127,9 @@ BENCH_CONV = [
      ["S2F"], ["DgradS2B"], ["jp_igemm_kernel"]),
     ("downsample 64->128 1x1 stride 2 @256^2", (8, 64, 256, 256, 128, 1, 2, 0, 0, 0, False), ["jp_igemm"], ["jp_igemm"], ["jp_igemm"]),
     ("stem 3->64 7x7 stride 2 @1024^2", (8, 3, 1024, 1024, 64, 7, 2, 3, 0, 0, False),
-     ["FwdBC<7, 4>"], [], ["jp_wgrad_w7_kernel<3>"]),
+     ["STEM<3>"], [], ["jp_wgrad_w7_kernel<3>"]),
     ("pose stem 6->64 7x7 stride 2 @192x640 (both pairs stacked: N = 16)", (16, 6, 192, 640, 64, 7, 2, 3, 0, 0, False),
-     ["FwdBC<7, 8>"], [], ["jp_wgrad_w7_kernel<6>"]),
+     ["STEM<6>"], [], ["jp_wgrad_w7_kernel<6>"]),
     ("pose encoder layer1 64->64 3x3 @48x160, N = 16", (16, 64, 48, 160, 64, 3, 1, 1, 0, 0, False), ["jp_igemm"], ["jp_igemm"], ["jp_"]),
     ("pose encoder layer4 512->512 3x3 @6x20, N = 16 (small grid: split K)", (16, 512, 6, 20, 512, 3, 1, 1, 0, 0, False),
      ["jp_igemm"], ["jp_igemm"], ["jp_"]),

@@ -72,6 +72,7 @@ def _emit():
         conv_case(f"3x3_reflect_256_{tag}", 8, 256, 64, 64, 256, 3, 1, 1, wide)
         conv_case(f"1x1_256_{tag}", 8, 256, 64, 64, 256, 1, 0, 0, wide)
         conv_case(f"3x3_stride2_64_128_{tag}", 8, 64, 128, 128, 128, 3, 1, 0, wide, stride=2)      # P9S2F / P9S2D
+        conv_case(f"7x7_stem_{tag}", 4, 3, 256, 256, 64, 7, 3, 0, wide, stride=2)                  # P7S
         # iconv (P9US): cat(skip 64, up2x(x 96), disp 1) -> 256, reflect
         g = torch.Generator().manual_seed(12)
         N, H, W, Cr, Cx, Cout = 2, 64, 128, 64, 96, 256
