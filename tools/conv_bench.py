@@ -30,6 +30,9 @@ CASES = [
     ("layer2 128->128 3x3 @128^2", 8, 128, 128, 128, 128, 3, 1, 1, 0),
     ("layer3 256->256 3x3 @64^2", 8, 256, 64, 64, 256, 3, 1, 1, 0),
     ("layer4 512->512 3x3 @32^2", 8, 512, 32, 32, 512, 3, 1, 1, 0),
+    ("pose layer1 64->64 3x3 @48x160 (N = 16)", 16, 64, 48, 160, 64, 3, 1, 1, 0),
+    ("layer2.0 64->128 3x3 stride 2 @256^2", 8, 64, 256, 256, 128, 3, 2, 1, 0),
+    ("stem 3->64 7x7 stride 2 @1024^2", 8, 3, 1024, 1024, 64, 7, 2, 3, 0),
 ]
 
 
@@ -53,7 +56,7 @@ def run_case(c, iters):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, Cin, H, W, generator=g).cuda()
     w = (torch.randn(Cout, Cin, K, K, generator=g) * (Cin * K * K) ** -0.5).cuda()
-    gy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    gy = torch.randn(N, Cout, (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1, generator=g).cuda()
     wv = Var(w, True, torch.zeros_like(w))
     wv.p = torch.nn.Parameter(w)          # persistent pack, as in the model
     wv.t = wv.p.data
@@ -75,7 +78,7 @@ def run_case(c, iters):
             a[0] += 1
             a[1] += ms
             a[2] += fl
-    alg = 2.0 * N * H * W * Cout * Cin * K * K
+    alg = 2.0 * N * ((H + 2 * p - K) // s + 1) * ((W + 2 * p - K) // s + 1) * Cout * Cin * K * K
     print(f"== {label}: algorithmic {alg / 1e9:.1f} GFLOP per pass")
     for name, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         per = ms / iters
