@@ -664,6 +664,43 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(const float* __restrict__ 
             [&](long i) { dx[i] = act_bwd1(dy[i], y[i], act); });
 }
 
+// activation backward + bias gradient in ONE pass over (N, C, HW): dx = dy * act'(y), dbias[c] += sum dx.  Replaces act_bwd followed
+// by channel_sum (a second read of dx) for the convolutions that carry both a bias and an activation (Conv3x3 blocks, layers.py:147-167).
+// grid (C, N * CH): block = one chunk of one (n, c) plane; fp32 short runs -> double, one float atomic per block (as channel_sum).
+__global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                           float* __restrict__ dbias, int C, int HW, int CH, int chunk, int act) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
+    const int beg = ck * chunk, end = min(HW, beg + chunk);
+    const size_t base = ((size_t)n * C + c) * HW;
+    double s = 0.0;
+    float fs = 0.f;
+    int run = 0;
+    if (((HW | chunk) & 3) == 0) {
+        const float4* d4 = reinterpret_cast<const float4*>(dy + base);
+        const float4* y4 = reinterpret_cast<const float4*>(y + base);
+        float4* o4 = reinterpret_cast<float4*>(dx + base);
+        for (int i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += TPB) {
+            const float4 d = d4[i], v = y4[i];
+            const float4 o = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act), act_bwd1(d.w, v.w, act));
+            o4[i] = o;
+            fs += (o.x + o.y) + (o.z + o.w);
+            if (++run == 8) { s += fs; fs = 0.f; run = 0; }
+        }
+    } else {
+        for (int i = beg + threadIdx.x; i < end; i += TPB) {
+            const float o = act_bwd1(dy[base + i], y[base + i], act);
+            dx[base + i] = o;
+            fs += o;
+            if (++run == 32) { s += fs; fs = 0.f; run = 0; }
+        }
+    }
+    s += fs;
+    s = jp_block_sum_d(s, sm);
+    if (threadIdx.x == 0) atomicAdd(&dbias[c], (float)s);
+}
+
 // out[n][c][hw] = a[n][c][hw] * s[n][0][hw]   (CrossViewTransformer.py:68) and its two adjoints
 __global__ __launch_bounds__(TPB) void mul_bcast_c_kernel(const float* __restrict__ a, const float* __restrict__ s,
                                                           float* __restrict__ out, long total, int C, int HW) {
@@ -1134,6 +1171,21 @@ extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, in
     JP_CHECK_ARG(dy && y && dx && n > 0, "act_bwd: bad args");
     JP_ST;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, dy, y, dx, n, act);
+    JP_LAUNCH_CHECK();
+}
+
+// dx = dy * act'(y) and dbias[c] += sum over (n, hw) of dx, one pass (dbias is accumulated into: zero it for a fresh gradient)
+extern "C" int jp_act_bwd_bias(const float* dy, const float* y, float* dx, float* dbias, int N, int C, int HW, int act,
+                               void* stream) {
+    JP_CHECK_ARG(dy && y && dx && dbias && N > 0 && C > 0 && HW > 0 && C <= 65535, "act_bwd_bias: bad args");
+    JP_ST;
+    int ch = std::max(1, 2048 / std::max(1, N * C));
+    ch = std::min(ch, std::max(1, HW / 2048));
+    int chunk = (HW + ch - 1) / ch;
+    chunk = (chunk + 3) & ~3;                       // chunks start on 16-byte boundaries when HW allows vector accesses
+    const int CH = (HW + chunk - 1) / chunk;
+    JP_CHECK_ARG((long)N * CH <= 65535, "act_bwd_bias: too many chunks");
+    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, y, dx, dbias, C, HW, CH, chunk, act);
     JP_LAUNCH_CHECK();
 }
 

@@ -333,12 +333,18 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
         if out.g is None:
             return
         dy = out.g
+        bias_done = False
         if act != ACT_NONE:
             d2 = torch.empty_like(dy)
-            call("jp_act_bwd", dy, y, d2, dy.numel(), act)
+            if b is not None and b.rg and Cout <= 65535:
+                # activation backward and bias gradient in one pass (the bias gradient is a sum over the tensor this pass writes)
+                call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act)
+                bias_done = True
+            else:
+                call("jp_act_bwd", dy, y, d2, dy.numel(), act)
             dy = d2
         def param_grads():
-            if b is not None and b.rg:
+            if b is not None and b.rg and not bias_done:
                 call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
             if w.rg:
                 nms = 0

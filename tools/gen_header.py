@@ -25,7 +25,7 @@ GROUPS = [
      "nearest upsample " + R + "layers.py:110; torch.cat; Dropout multiply " + R + "depth_decoder.py:52-53; F.interpolate bilinear "
      + R + "net.py:196,632,692 and area " + R + "net.py:762.",
      ["jp_maxpool_fwd", "jp_maxpool_bwd", "jp_upsample2x_fwd", "jp_upsample2x_bwd", "jp_copy_channels", "jp_axpby", "jp_sum_n", "jp_mul",
-      "jp_affine", "jp_act_fwd", "jp_act_bwd", "jp_mul_bcast_c", "jp_mul_bcast_c_bwd_s", "jp_bilinear_fwd", "jp_bilinear_bwd",
+      "jp_affine", "jp_act_fwd", "jp_act_bwd", "jp_act_bwd_bias", "jp_mul_bcast_c", "jp_mul_bcast_c_bwd_s", "jp_bilinear_fwd", "jp_bilinear_bwd",
       "jp_area_downsample", "jp_fill", "jp_warp_perspective", "jp_softmax_c2", "jp_disp_to_depth",
       "jp_scale_label_assemble", "jp_fill_convex_poly"]),
     ("Small dense algebra of the BEV branch — CVP MLP " + R + "CycledViewProjection.py:33-38,54-67; CCT attention "
