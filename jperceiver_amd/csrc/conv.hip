@@ -2080,6 +2080,8 @@ inline bool p9s2_enabled() {
     static const bool on = [] { const char* e = getenv("JP_P9S2"); return !(e && e[0] == '0'); }();
     return on;
 }
+// per-kernel switches below JP_P9S2 (A/B and bisection): JP_P9S2D / JP_P9S2F / JP_P1S2 / JP_P7S = 0 keep the generic engine
+#define JP_ENV_ON(NAME) ([] { static const bool on = [] { const char* e = getenv(NAME); return !(e && e[0] == '0'); }(); return on; }())
 template <int WM, int WN, class E>
 const char* p9s2d_tag() { return __PRETTY_FUNCTION__; }
 template <class E>
@@ -2166,7 +2168,7 @@ template <int WM, int WN, class E>
 const char* p9sx2_tag() { return __PRETTY_FUNCTION__; }
 inline bool p1s2_ok(int rows, int red, int N, int OH, int OW) {
     const int tr = rows <= 64 ? 8 : 4;
-    return p9s_enabled() && p9s2_enabled() && rows >= 32 && red >= 64 && red % 64 == 0 && OW % 32 == 0 && OH % tr == 0 &&
+    return p9s_enabled() && p9s2_enabled() && JP_ENV_ON("JP_P1S2") && rows >= 32 && red >= 64 && red % 64 == 0 && OW % 32 == 0 && OH % tr == 0 &&
            (long)N * red * OH * OW * 16 < (1L << 31) &&
            (long)jp_cdiv(rows, p9_bmt(rows, 1, p9_ptiles(N, OH, OW))) * N * (OH / tr) * (OW / 32) >= 192;
 }
@@ -2390,7 +2392,8 @@ int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c
 int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
                    hipStream_t st);
 int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, int h, int wd, int accumulate, hipStream_t st);
-int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st);
+int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st, float* ws,
+                     long ws_floats);
 // one-channel head on a single nearest-2x-upsampled source (the disparity heads): upsample-aware direct kernels
 static inline bool up_head(int c0, int up0, int c1, int c2, int Cout, int KH, int stride, int pad, int pad_mode, int H, int W) {
     return Cout == 1 && c1 == 0 && c2 == 0 && up0 && c0 >= 8 && c0 <= 768 && KH == 3 && stride == 1 && pad == 1 &&
@@ -2454,7 +2457,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
     if (ws && Cin <= 8 && Cout <= 64 && c1 == 0 && c2 == 0 && !up0 && pad_mode != JP_PAD_REFLECT && (KH == 7 || KH == 3) &&
         npix / 256 >= 192 && (long)2 * Cin * H * W * 4 < (1L << 32)) {
-        if (KH == 7 && stride == 2 && pad == 3 && (Cin == 3 || Cin == 6) && p9s_enabled() && p9s2_enabled() && H == 2 * OH && W == 2 * OW &&
+        if (KH == 7 && stride == 2 && pad == 3 && (Cin == 3 || Cin == 6) && p9s_enabled() && p9s2_enabled() && JP_ENV_ON("JP_P7S") && H == 2 * OH && W == 2 * OW &&
             OH % 8 == 0 && OW % 32 == 0 && (long)Cin * H * W * 4 < (1L << 31)) {
             // P7S stem kernel (igemm_p7s.h): split-bf16 products, the whole K of a tile staged once
             const long tot = (4L * Cin + 1) * 1536;
@@ -2563,7 +2566,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             JP_LAUNCH_CHECK();
         }
         if (KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && c1 == 0 && c2 == 0 && !up0 && p9s_enabled() &&
-            p9s2_enabled() && H == 2 * OH && W == 2 * OW && OH % 4 == 0 && OW % 32 == 0 && Cin % 16 == 0 && Cin >= 32 && Cout > 64 &&
+            p9s2_enabled() && JP_ENV_ON("JP_P9S2F") && H == 2 * OH && W == 2 * OW && OH % 4 == 0 && OW % 32 == 0 && Cin % 16 == 0 && Cin >= 32 && Cout > 64 &&
             (long)N * Cin * H * W * 4 < (1L << 31) && (long)jp_cdiv(Cout, 128) * N * (OH / 4) * (OW / 32) >= 192) {
             // 3x3 stride 2: P9S2F patch kernel (igemm_p9s2f.h) on the P9S forward pack (instead of the tap-major one)
             if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, 128, 9, st);
@@ -2707,7 +2710,7 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
         // 3x3 stride-2 layers: class-uniform split-bf16 kernel on the half-resolution grid (its own fragment-order pack only)
         const bool s2_form = KH == 3 && stride == 2 && pad == 1 && pad_mode != JP_PAD_REFLECT && H % 2 == 0 && W % 2 == 0 &&
                              2 * OH == H && 2 * OW == W;
-        if (s2_form && p9s_enabled() && p9s2_enabled() && Cin >= 32 && Cout % 16 == 0 && OW % 32 == 0 &&
+        if (s2_form && p9s_enabled() && p9s2_enabled() && JP_ENV_ON("JP_P9S2D") && Cin >= 32 && Cout % 16 == 0 && OW % 32 == 0 &&
             OH % (Cin <= 64 ? 8 : 4) == 0 && (long)N * Cout * OH * OW * 4 < (1L << 31) &&
             (long)jp_cdiv(Cin, Cin <= 64 ? 64 : 128) * N * (OH / (Cin <= 64 ? 8 : 4)) * (OW / 32) * 4 >= 192) {
             float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
@@ -2963,7 +2966,7 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     const int Kw = Cin * KH * KH;
     const bool whole = dw_coff == 0 && dw_ctot == Cin;
     if (whole && up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
-        jp_up_head_wgrad(x0, dy, dw, N, c0, H / 2, W / 2, st);
+        jp_up_head_wgrad(x0, dy, dw, N, c0, H / 2, W / 2, st, ws, ws_floats);
         JP_LAUNCH_CHECK();
     }
     if (whole && small_head(Cin, Cout, KH, stride, pad)) {

@@ -297,6 +297,58 @@ __global__ __launch_bounds__(TPB) void up_head_fwd_kernel(const float* __restric
     *reinterpret_cast<float2*>(yo + 2 * wd) = make_float2(jp_act(o10 + bv, act), jp_act(o11 + bv, act));
 }
 
+// forward, two horizontally adjacent half-resolution pixels (j, j+1; j even) per thread: a 3 x 4 window per channel (three
+// aligned float2 + two scalars per row pair instead of 2 x 9 scalars), the 16 slot weights of a channel as four broadcast
+// 16-byte LDS reads shared by both pixels.  wq[c][16] here.
+__global__ __launch_bounds__(TPB) void up_head_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                           int h, int wd, int act) {
+    extern __shared__ float wq[];   // [16][C] built, then read transposed below
+    up_build_weights(w, wq, C);
+    __syncthreads();
+    const int img = blockIdx.y, hw = h * wd, w2 = wd >> 1;
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= h * w2) return;
+    const int i = p / w2, j = 2 * (p - i * w2);
+    const int r0 = max(i - 1, 0) * wd, r1 = i * wd, r2 = min(i + 1, h - 1) * wd;
+    const int cl = max(j - 1, 0), cr = min(j + 2, wd - 1);
+    float o[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[k][q] = 0.f;
+    const float* xp = x + (size_t)img * C * hw;
+    // (a thread's channel loop is a chain of dependent-latency loads: four channels in flight)
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float* q = xp + (size_t)c * hw;
+        float v[3][4];
+        const int rr[3] = {r0, r1, r2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float2 m = *reinterpret_cast<const float2*>(q + rr[r] + j);
+            v[r][0] = q[rr[r] + cl]; v[r][1] = m.x; v[r][2] = m.y; v[r][3] = q[rr[r] + cr];
+        }
+        float wc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wc[t] = wq[t * C + c];
+        // pixel k reads columns k .. k+2 of the window; class (a, b), slot (r, s) reads v[a + r][k + b + s]
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            o[k][0] += wc[0] * v[0][k] + wc[1] * v[0][k + 1] + wc[2] * v[1][k] + wc[3] * v[1][k + 1];
+            o[k][1] += wc[4] * v[0][k + 1] + wc[5] * v[0][k + 2] + wc[6] * v[1][k + 1] + wc[7] * v[1][k + 2];
+            o[k][2] += wc[8] * v[1][k] + wc[9] * v[1][k + 1] + wc[10] * v[2][k] + wc[11] * v[2][k + 1];
+            o[k][3] += wc[12] * v[1][k + 1] + wc[13] * v[1][k + 2] + wc[14] * v[2][k + 1] + wc[15] * v[2][k + 2];
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    float* yo = y + (size_t)img * 4 * hw + (size_t)(2 * i) * (2 * wd) + 2 * j;
+    *reinterpret_cast<float4*>(yo) = make_float4(jp_act(o[0][0] + bv, act), jp_act(o[0][1] + bv, act), jp_act(o[1][0] + bv, act),
+                                                 jp_act(o[1][1] + bv, act));
+    *reinterpret_cast<float4*>(yo + 2 * wd) = make_float4(jp_act(o[0][2] + bv, act), jp_act(o[0][3] + bv, act),
+                                                          jp_act(o[1][2] + bv, act), jp_act(o[1][3] + bv, act));
+}
+
 // dgrad: dx[c][i][j] (= | +=) sum_q W'[q][c] * D_q(i, j), straight at half resolution
 __global__ __launch_bounds__(TPB) void up_head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                             float* __restrict__ dx, int C, int h, int wd,
@@ -350,6 +402,59 @@ __global__ __launch_bounds__(TPB) void up_head_wgrad_kernel(const float* __restr
     }
     __syncthreads();
     if (threadIdx.x < UP_CB * 16) {
+        const int k = threadIdx.x >> 4, q = threadIdx.x & 15;
+        if (c0 + k < C) {
+            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            int y0, y1, x0, x1;
+            up_tap_range(q >> 3, (q >> 1) & 1, y0, y1);
+            up_tap_range((q >> 2) & 1, q & 1, x0, x1);
+            for (int ty = y0; ty <= y1; ++ty)
+                for (int tx = x0; tx <= x1; ++tx) atomicAdd(dw + (size_t)(c0 + k) * 9 + ty * 3 + tx, s);
+        }
+    }
+}
+
+// wgrad with the 16 gathered dY sums D_q(i, j) PRECOMPUTED (up_head_D_kernel -> D[img][q][h*w]): the gather (16 values x up to 4
+// loads + boundary logic) is done once per pixel instead of once per pixel and 8-channel block (C/8 = 32 times).
+__global__ __launch_bounds__(TPB) void up_head_D_kernel(const float* __restrict__ dy, float* __restrict__ D, int h, int wd) {
+    const int img = blockIdx.y, hw = h * wd;
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    float d[16];
+    up_gather_D(dy + (size_t)img * 4 * hw, p / wd, p % wd, h, wd, d);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) D[((size_t)img * 16 + q) * hw + p] = d[q];
+}
+constexpr int UPD_CB = 8;
+__global__ __launch_bounds__(TPB) void up_head_wgrad_D_kernel(const float* __restrict__ x, const float* __restrict__ D,
+                                                              float* __restrict__ dw, int C, int hw, int band) {
+    __shared__ float red[4][UPD_CB * 16];
+    const int c0 = blockIdx.x * UPD_CB, img = blockIdx.z;
+    const float* xp = x + ((size_t)img * C + c0) * hw;
+    const float* dp = D + (size_t)img * 16 * hw;
+    float acc[UPD_CB * 16];
+#pragma unroll
+    for (int i = 0; i < UPD_CB * 16; ++i) acc[i] = 0.f;
+    const int pend = min(hw, (int)(blockIdx.y + 1) * band);
+    for (int p = blockIdx.y * band + threadIdx.x; p < pend; p += TPB) {
+        float d[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = dp[(size_t)q * hw + p];
+#pragma unroll
+        for (int k = 0; k < UPD_CB; ++k) {
+            const float xv = (c0 + k < C) ? xp[(size_t)k * hw + p] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[k * 16 + q] = fmaf(xv, d[q], acc[k * 16 + q]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < UPD_CB * 16; ++i) {
+        const float s = jp_wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < UPD_CB * 16) {
         const int k = threadIdx.x >> 4, q = threadIdx.x & 15;
         if (c0 + k < C) {
             const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -420,6 +525,11 @@ int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c
 // x: (N, C, h, w), y / dy: (N, 1, 2h, 2w)
 int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
                    hipStream_t st) {
+    if (wd % 4 == 0) {       // two pixels per thread (aligned float2 / float4 accesses)
+        hipLaunchKernelGGL(up_head_fwd2_kernel, dim3(jp_cdiv(h * (wd / 2), TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w, bias,
+                           y, C, h, wd, act);
+        return 0;
+    }
     hipLaunchKernelGGL(up_head_fwd_kernel, dim3(jp_cdiv(h * wd, TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w, bias, y,
                        C, h, wd, act);
     return 0;
@@ -430,8 +540,17 @@ int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, i
                        h, wd, accumulate);
     return 0;
 }
-int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st) {
+int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st, float* ws,
+                     long ws_floats) {
     const int hw = h * wd;
+    if (ws && ws_floats >= 16L * N * hw) {       // caller scratch for the gathered dY sums: gather once, stream afterwards
+        hipLaunchKernelGGL(up_head_D_kernel, dim3(jp_cdiv(hw, TPB), N), dim3(TPB), 0, st, dy, ws, h, wd);
+        const int bands = std::max(1, std::min(hw / (TPB * 16), 16));
+        const int band = jp_cdiv(jp_cdiv(hw, bands), TPB) * TPB;
+        hipLaunchKernelGGL(up_head_wgrad_D_kernel, dim3(jp_cdiv(C, UPD_CB), jp_cdiv(hw, band), N), dim3(TPB), 0, st, x, ws, dw, C, hw,
+                           band);
+        return 0;
+    }
     const int bands = std::max(1, std::min(hw / (TPB * 16), 16));     // (64 bands of 4 iterations measured slower: 361 vs 278 us)
     const int band = jp_cdiv(jp_cdiv(hw, bands), TPB) * TPB;
     hipLaunchKernelGGL(up_head_wgrad_kernel, dim3(jp_cdiv(C, UP_CB), jp_cdiv(hw, band), N), dim3(TPB), 0, st, x, dy, dw, C, h, wd,

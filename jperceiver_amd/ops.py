@@ -354,7 +354,10 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 up_head = len(srcs) == 1 and srcs[0][1] and int(_jplib().fn["jp_conv2d_up_head_ok"](
                     s3[1], s3[2], 0, 0, Cout, KH, stride, pad, pad_mode, H, W))
                 if up_head:     # disparity head on an upsampled source: upsample-aware direct kernel, nothing materialised
-                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, None, 0)
+                    nup = 4 * N * H * W                     # 16 gathered dY sums per half-resolution pixel
+                    ws_w = _new((nup,), dy)
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nup)
+                    del ws_w
                 elif nms:
                     # per-segment wgrad inside the library: full-resolution segments from their own tensors, the
                     # upsampled one in parity-class form -- no materialised concat
