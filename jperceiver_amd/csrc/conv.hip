@@ -2389,6 +2389,13 @@ int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1,
 int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
                         int up2, const float* dy, float* dw, int N, int H, int W, int Cout, int reflect,
                         hipStream_t st);
+// conv_c16.hip: direct kernels for the 16 / 32-channel 3x3 layers of the BEV decoder
+bool jp_c16_ok(int Cin, int Cout, int KH, int stride, int pad, int pad_mode, int H, int W);
+int jp_c16_fwd(const float* x, int up, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int H, int W, int act,
+               hipStream_t st);
+int jp_c16_dgrad(const float* dy, const float* w, float* dx, int up, int N, int Cin, int Cout, int H, int W, int accumulate,
+                 hipStream_t st);
+int jp_c16_wgrad(const float* x, int up, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, hipStream_t st);
 int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
                    hipStream_t st);
 int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, int h, int wd, int accumulate, hipStream_t st);
@@ -2452,6 +2459,10 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     if (small_head(Cin, Cout, KH, stride, pad)) {
         jp_conv_small_fwd(x0, c0, up0, x1, c1, up1, x2, c2, up2, w, bias, y, N, H, W, Cout, act,
                           pad_mode == JP_PAD_REFLECT, st);
+        JP_LAUNCH_CHECK();
+    }
+    if (c1 == 0 && c2 == 0 && jp_c16_ok(c0, Cout, KH, stride, pad, pad_mode, H, W)) {
+        jp_c16_fwd(x0, up0, w, bias, y, N, c0, Cout, H, W, act, st);
         JP_LAUNCH_CHECK();
     }
     const Src3 src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
@@ -2698,6 +2709,10 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     const long npix = (long)N * H * W;
     JP_CHECK_ARG(npix < (1L << 31), "conv2d_dgrad: tensor too large");
     hipStream_t st = (hipStream_t)stream;
+    if (jp_c16_ok(Cin, Cout, KH, stride, pad, pad_mode, H, W)) {
+        jp_c16_dgrad(dy, w, dx, 0, N, Cin, Cout, H, W, accumulate, st);
+        JP_LAUNCH_CHECK();
+    }
     DgradEpi e{dx, Cin, H * W, accumulate};
     if (ws && Cout >= 16) {
         const int Cp = pad32(Cout), Kp = KH * KH * Cp;
@@ -2967,6 +2982,10 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     const bool whole = dw_coff == 0 && dw_ctot == Cin;
     if (whole && up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
         jp_up_head_wgrad(x0, dy, dw, N, c0, H / 2, W / 2, st, ws, ws_floats);
+        JP_LAUNCH_CHECK();
+    }
+    if (whole && c1 == 0 && c2 == 0 && jp_c16_ok(c0, Cout, KH, stride, pad, pad_mode, H, W)) {
+        jp_c16_wgrad(x0, up0, dy, dw, N, c0, Cout, H, W, st);
         JP_LAUNCH_CHECK();
     }
     if (whole && small_head(Cin, Cout, KH, stride, pad)) {

@@ -703,3 +703,53 @@ def test_iou_and_bd_loss_classes_match_reference_vectors(golden_dir):
         IoULoss(apply_nonlin=None)
     with pytest.raises(NotImplementedError):
         IoULoss(apply_nonlin=softmax_helper, batch_dice=True)
+
+
+@pytest.mark.parametrize("N,C,H,W,act", [(3, 5, 37, 13, 2), (8, 16, 64, 64, 2), (2, 7, 128, 96, 1), (1, 3, 1, 5, 2)])
+def test_act_bwd_bias_one_pass(N, C, H, W, act):
+    """jp_act_bwd_bias: dx = dy * act'(y) and dbias[c] += sum over (n, pixels) of dx in one pass (layers.py:147-167 Conv3x3 blocks:
+    bias + LeakyReLU) -- against the two-kernel form (jp_act_bwd, jp_channel_sum) and a float64 sum; dbias is accumulated into."""
+    dy, y = rnd(N, C, H, W, seed=3), rnd(N, C, H, W, seed=4)
+    dx = torch.empty_like(dy)
+    db = torch.full((C,), 0.25, device=DEV)
+    call("jp_act_bwd_bias", dy, y, dx, db, N, C, H * W, act)
+    dx2 = torch.empty_like(dy)
+    call("jp_act_bwd", dy, y, dx2, dy.numel(), act)
+    assert torch.equal(dx, dx2)
+    slope = 0.01 if act == 2 else 0.0
+    ref = dy.double() * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope)).double()
+    close(dx, ref.float(), rtol=1e-6, atol=1e-7, msg="dx")
+    close(db, (0.25 + ref.sum(dim=(0, 2, 3))).float(), rtol=1e-5, atol=1e-5, msg="dbias")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,up,act,bias", [(2, 16, 16, 64, 128, 1, 0, False),    # BEV upconv 16 -> 16 on the upsampled map
+                                                        (3, 16, 16, 96, 128, 0, 1, True),      # full-resolution source, bias + ReLU, 3 images
+                                                        (1, 16, 16, 64, 64, 1, 2, True),
+                                                        (2, 32, 32, 64, 64, 1, 1, True)])      # (32 channels: implicit-GEMM engine)
+def test_small_channel_direct_conv(N, Cin, Cout, H, W, up, act, bias):
+    """The 16 / 32-channel 3x3 zero-pad layers of the BEV decoder (layout_model.py:138-153) run on direct VALU kernels
+    (conv_c16.hip): forward, input gradient (through the nearest-2x upsample where the source is stored at half resolution) and
+    weight / bias gradients against ATen."""
+    from tests.test_bench_shapes_gpu import kernel_tags
+    h, w_ = (H // 2, W // 2) if up else (H, W)
+    x = rnd(N, Cin, h, w_, seed=1)
+    wt, b = rnd(Cout, Cin, 3, 3, seed=2, scale=0.1), (rnd(Cout, seed=3) if bias else None)
+    xv, wv, bv = Var(x, True), pvar(wt), (pvar(b) if bias else None)
+    tape = Tape()
+    with recording(tape), kernel_tags() as kt:
+        y = ops.conv2d(None, wv, bv, 1, 1, 0, act, srcs=[(xv, up)])
+    if Cin == 16 and Cout == 16:        # the library dispatches 16 -> 16 to the direct kernels (the 32-channel layers stay on the engine)
+        assert not kt.names, f"expected the direct kernels (no implicit-GEMM launch), got {kt.names}"
+    xr, wr = x.detach().cpu().clone().requires_grad_(True), wt.detach().cpu().clone().requires_grad_(True)
+    br = b.detach().cpu().clone().requires_grad_(True) if bias else None
+    src = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    yr = kink_act(F.conv2d(src, wr, br, 1, 1), y.t, act)
+    close(y.t, yr, msg="fwd")
+    gy = rnd(*yr.shape, seed=4)
+    y.g = gy.clone()
+    tape.backward()
+    yr.backward(gy.cpu())
+    close(xv.g, xr.grad, rtol=2e-4, msg="dx")
+    close(wv.g, wr.grad, rtol=2e-4, msg="dw")
+    if bias:
+        close(bv.g, br.grad, rtol=2e-4, msg="db")
