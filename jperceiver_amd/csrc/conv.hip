@@ -1642,6 +1642,22 @@ struct DgradBorderEpi {  // dx[img][ci][y][x] += acc for the border pixel b
     }
 };
 
+// border pass through scratch: the K loop is split into slices that store part[slice][ci][b] (coalesced along the border pixels),
+// then ONE small pass folds the slices into dx in a fixed order -- more workgroups on a launch that has only a few dozen tiles,
+// the scattered read-modify-write done once, no atomics
+__global__ void border_add_kernel(const float* __restrict__ part, float* __restrict__ dx, int Cin, int Nb, int H, int W,
+                                  int slices) {
+    const long total = (long)Cin * Nb;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / Nb), b = (int)(i - (long)m * Nb);
+        const InPixSt px = border_pix(b, Nb, H, W);
+        if (!px.valid) continue;
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += part[(size_t)k * total + i];
+        dx[((size_t)px.img * Cin + m) * H * W + px.y * W + px.x] += s;
+    }
+}
+
 template <int KH>
 struct WgradBT {  // B[k=pixel][n=(tap,ci)], any source layout (per-element decode)
     static constexpr bool ALONG_K = true;
@@ -2680,10 +2696,13 @@ extern "C" long jp_conv2d_dgrad_split_floats(int N, int Cin, int H, int W, int C
     const long npix = (long)N * H * W;
     const int Kp = KH * KH * pad32(Cout);
     if (KH == 3 && stride == 2) return 0;          // parity-class path, no split
+    // reflection layers (the pad mode is not an argument here: every 3x3 stride-1 pad-1 layer gets it): <= 4 slices of the
+    // border pass, part[slice][Cin][N * (2H + 2W)]
+    const long border = (KH == 3 && stride == 1 && pad == 1) ? 4L * Cin * N * (2L * H + 2L * W) : 0;
     const int sp = small_grid_splits(Cin, npix, Kp);
-    if (sp <= 1) return 0;
+    if (sp <= 1) return border;
     const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
-    return (long)jp_cdiv(Kp, kps) * Cin * npix;
+    return std::max(border, (long)jp_cdiv(Kp, kps) * Cin * npix);
 }
 
 // floats of optional caller scratch (`split_ws`) for the split-K forward of layers whose tile grid cannot fill the
@@ -2837,6 +2856,18 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             DgradBorderEpi be{dx, Cin, H, W, Nb, 0};
             // a few dozen tiles only: split K so the pass is not one workgroup's whole K loop long
             const long btiles = (long)jp_cdiv(Cin, Cin <= 64 ? 64 : 128) * jp_cdiv(Nb, Cin <= 64 ? 256 : 128);
+            static const bool via_ws = [] { const char* e_ = getenv("JP_BORDER_WS"); return !(e_ && e_[0] == '0'); }();
+            const int chunks = Kp / KC;
+            const int wsl = (int)std::max<long>(1, std::min<long>(std::min<long>(4, chunks / 9), jp_cdiv(512, btiles)));
+            if (via_ws && split_ws && wsl > 1) {
+                const int wkps = jp_cdiv(jp_cdiv(Kp, wsl), KC) * KC, nsl = jp_cdiv(Kp, wkps);
+                WgradEpiWS es{split_ws, Cin, Nb};
+                launch_auto(a, bb, es, Cin, Nb, Kp, nsl, wkps, st);
+                const long total = (long)Cin * Nb;
+                hipLaunchKernelGGL(border_add_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, split_ws, dx,
+                                   Cin, Nb, H, W, nsl);
+                JP_LAUNCH_CHECK();
+            }
             const int bsp = border_splits(btiles, Kp / KC);
             const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
             be.split = jp_cdiv(Kp, bkps) > 1;
