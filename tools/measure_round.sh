@@ -17,8 +17,8 @@ timeout 600 rocprofv3 --kernel-trace -d $OUT/prof2 -o kt -- python $ROOT/bench.p
 JP_PMC_CALIB=1 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc -o fetch -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > $OUT/pmc_fetch.log 2>&1
 JP_PMC_CALIB=1 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc -o write -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > $OUT/pmc_write.log 2>&1
 cd $ROOT
-python tools/rocpd_stats.py $(find $OUT/prof -name "*.db" | head -1) 50 > $OUT/kernel_stats.md 2>&1
-python tools/rocpd_stats.py $(find $OUT/prof2 -name "*.db" | head -1) 50 > $OUT/kernel_stats_overlapped.md 2>&1
+python tools/rocpd_stats.py $(find $OUT/prof -name "*.db" | head -1) 80 > $OUT/kernel_stats.md 2>&1
+python tools/rocpd_stats.py $(find $OUT/prof2 -name "*.db" | head -1) 80 > $OUT/kernel_stats_overlapped.md 2>&1
 python tools/timeline.py $(find $OUT/prof2 -name "*.db" | head -1) 2 > $OUT/timeline.txt 2>&1
 python tools/pmc_traffic.py $(find $OUT/pmc -name "fetch*.db" | head -1) $(find $OUT/pmc -name "write*.db" | head -1) $OUT/pmc_traffic.json $OUT/bench_families.json > $OUT/pmc_traffic.log 2>&1
 rm -rf $OUT/prof $OUT/prof2 $OUT/pmc   # the databases are large; the summaries above are what gets committed
