@@ -2718,6 +2718,32 @@ extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cou
     return (long)jp_cdiv(Kp, kps) * Cout * npix;
 }
 
+// reflection border pass of a dgrad (rows of `a` = the C input channels of this call): through caller scratch when there is some
+// (K slices stored coalesced, one fixed-order fold into dx), else the read-modify-write epilogue
+static void border_pass(const PackA& a, const float* dy, float* dx, int C, int Cp, int Kp, int Cout, int N, int H, int W,
+                        float* split_ws, hipStream_t st) {
+    const int Nb = N * (2 * W + 2 * H);
+    DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
+    const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
+    static const bool via_ws = [] { const char* e_ = getenv("JP_BORDER_WS"); return !(e_ && e_[0] == '0'); }();
+    const int chunks = Kp / KC;
+    const int wsl = (int)std::max<long>(1, std::min<long>(std::min<long>(4, chunks / 9), jp_cdiv(512, btiles)));
+    if (via_ws && split_ws && wsl > 1 && C > 4) {      // (a one-row launch -- the disparity channel -- gains nothing from slices)
+        const int wkps = jp_cdiv(jp_cdiv(Kp, wsl), KC) * KC, nsl = jp_cdiv(Kp, wkps);
+        WgradEpiWS es{split_ws, C, Nb};
+        launch_auto(a, bb, es, C, Nb, Kp, nsl, wkps, st);
+        const long total = (long)C * Nb;
+        hipLaunchKernelGGL(border_add_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, split_ws, dx, C, Nb, H,
+                           W, nsl);
+        return;
+    }
+    DgradBorderEpi be{dx, C, H, W, Nb, 0};
+    const int bsp = border_splits(btiles, Kp / KC);
+    const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
+    be.split = jp_cdiv(Kp, bkps) > 1;
+    launch_auto(a, bb, be, C, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
+}
+
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
                                int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, int ws_state,
                                float* split_ws, void* stream) {
@@ -2850,29 +2876,8 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
                 }
             });
         }
-        if (pad_mode == JP_PAD_REFLECT) {   // fold the reflected ring back in (border-adjacent lines only)
-            const int Nb = N * (2 * W + 2 * H);
-            DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
-            DgradBorderEpi be{dx, Cin, H, W, Nb, 0};
-            // a few dozen tiles only: split K so the pass is not one workgroup's whole K loop long
-            const long btiles = (long)jp_cdiv(Cin, Cin <= 64 ? 64 : 128) * jp_cdiv(Nb, Cin <= 64 ? 256 : 128);
-            static const bool via_ws = [] { const char* e_ = getenv("JP_BORDER_WS"); return !(e_ && e_[0] == '0'); }();
-            const int chunks = Kp / KC;
-            const int wsl = (int)std::max<long>(1, std::min<long>(std::min<long>(4, chunks / 9), jp_cdiv(512, btiles)));
-            if (via_ws && split_ws && wsl > 1) {
-                const int wkps = jp_cdiv(jp_cdiv(Kp, wsl), KC) * KC, nsl = jp_cdiv(Kp, wkps);
-                WgradEpiWS es{split_ws, Cin, Nb};
-                launch_auto(a, bb, es, Cin, Nb, Kp, nsl, wkps, st);
-                const long total = (long)Cin * Nb;
-                hipLaunchKernelGGL(border_add_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, split_ws, dx,
-                                   Cin, Nb, H, W, nsl);
-                JP_LAUNCH_CHECK();
-            }
-            const int bsp = border_splits(btiles, Kp / KC);
-            const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
-            be.split = jp_cdiv(Kp, bkps) > 1;
-            launch_auto(a, bb, be, Cin, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
-        }
+        if (pad_mode == JP_PAD_REFLECT)     // fold the reflected ring back in (border-adjacent lines only)
+            border_pass(a, dy, dx, Cin, Cp, Kp, Cout, N, H, W, split_ws, st);
     } else {
         const int K = Cout * KH * KH;
         JP_KH_SWITCH(KH, {
@@ -2902,10 +2907,17 @@ extern "C" int jp_conv2d_dgrad_src3_ok(int c0, int up0, int c1, int up1, int c2,
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) return 1;
     return dgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode) ? 1 : 0;
 }
+// scratch for jp_conv2d_dgrad_src3's `split_ws`: <= 4 K slices of the widest full-resolution segment's border pass
+extern "C" long jp_conv2d_dgrad_src3_split_floats(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W) {
+    const int cm = std::max(std::max(up0 ? 0 : c0, up1 ? 0 : c1), up2 ? 0 : c2);
+    return 4L * cm * N * (2L * H + 2L * W);
+}
+
 extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
                                     int c1, int up1, int acc1, float* dx2, int c2, int up2, int acc2, int N, int H, int W,
                                     int Cout, int KH, int stride, int pad, int pad_mode, float* ws, int ws_state,
-                                    void* stream) {
+                                    float* split_ws, void* stream) {
+    // split_ws: optional scratch of jp_conv2d_dgrad_src3_split_floats floats for the border passes (NULL: read-modify-write epilogue)
     JP_CHECK_ARG(dy && w, "conv2d_dgrad_src3: null pointer");
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
         if (dx0) jp_up_head_dgrad(dy, w, dx0, N, c0, H / 2, W / 2, acc0, (hipStream_t)stream);
@@ -2958,14 +2970,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
                     launch_auto(a, b, e, C, (int)npix, Kp, 1, Kp, st);
                 }
             }
-            const int Nb = N * (2 * W + 2 * H);
-            DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
-            DgradBorderEpi be{dx, C, H, W, Nb, 0};
-            const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
-            const int bsp = border_splits(btiles, Kp / KC);
-            const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
-            be.split = jp_cdiv(Kp, bkps) > 1;
-            launch_auto(a, bb, be, C, Nb, Kp, jp_cdiv(Kp, bkps), bkps, st);
+            border_pass(a, dy, dx, C, Cp, Kp, Cout, N, H, W, split_ws, st);
         } else if (dx) {
             const int h2 = H / 2, w2 = W / 2, KpU = 16 * Cp;
             const long tot = 16L * C * Cp, np2 = (long)N * h2 * w2;

@@ -422,8 +422,12 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                     else:
                         ga += [None, s3[3 * i + 1], s3[3 * i + 2], 0]
                 rgs = tuple(ga[0::4][i] is not None for i in range(3))
+                nsd = int(_jplib().fn["jp_conv2d_dgrad_src3_split_floats"](*[v for i in range(3) for v in (s3[3 * i + 1], s3[3 * i + 2])],
+                                                                          N, H, W))
+                ws_s = _new((nsd,), dy) if nsd else None
                 _conv_call("jp_conv2d_dgrad_src3", w, "dgrad3", sig + rgs, nwd,
-                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode), ())
+                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode), (ws_s,))
+                del ws_s
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
                 _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,

@@ -16,7 +16,7 @@ GROUPS = [
      "(jp_conv2d_ws_floats) and whether it already holds this layer's pack (1) or must be packed by this call (0); packs recorded with "
      "jp_pack_record_begin/end can be refreshed for the whole model by one jp_pack_replay launch per step (job table in device memory; every job's `begin` is the running sum of the totals rounded up to a multiple of 4, "
      "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements).",
-     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
+     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
     ("Train-mode BatchNorm2d (+fused residual add / ReLU) — " + R + "resnet.py:21-24,41-45,92; " + R + "layout_model.py:146,152. "
      "ws = jp_bn_ws_doubles(N, C, HW) doubles of caller scratch.  n_updates = number of momentum updates of the running stats (2 for the layout "
      "branch the reference evaluates twice, " + R + "net.py:73-74).",
