@@ -118,7 +118,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     auto gload = [&](int stage) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+#ifdef P9S_PROBE_X      // timing probe (wrong results): every stage re-reads channel k of the first one -- input traffic from L2 only
+            const int ub = __builtin_amdgcn_readfirstlane((int)((long)k * HWI * 4));
+#else
             const int ub = __builtin_amdgcn_readfirstlane((int)(((long)stage * CS + k) * HWI * 4));
+#endif
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const float v = jp_gather(xrs, soff[q] & ~1u, ub);
@@ -165,7 +169,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
+#ifdef P9S_PROBE_W      // timing probe (wrong results): every step re-reads the first one -- weight stream latency / bandwidth out of the picture
+                ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), 0, 0);
+#else
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
+#endif
     };
 #pragma unroll
     for (int d = 0; d < P9S_AHEAD; ++d) aload(d, d * SBYTES);
