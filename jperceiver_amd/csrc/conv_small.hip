@@ -362,7 +362,23 @@ __global__ __launch_bounds__(TPB) void up_head_dgrad_kernel(const float* __restr
     float D[16];
     up_gather_D(dy + (size_t)img * 4 * hw, p / wd, p % wd, h, wd, D);
     float* dp = dx + (size_t)img * C * hw + p;
-    for (int c = 0; c < C; ++c) {
+    // four channels per iteration, the read-modify-write loads issued together (the compiler cannot move a load above the previous
+    // channel's store on its own: the 256-iteration chain of dependent-latency accesses was the kernel's whole run time)
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+        float old[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) old[k] = accumulate ? dp[(size_t)(c + k) * hw] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[k] = fmaf(wq[q * C + c + k], D[q], v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dp[(size_t)(c + k) * hw] = old[k] + v[k];
+    }
+    for (; c < C; ++c) {
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v = fmaf(wq[q * C + c], D[q], v);
