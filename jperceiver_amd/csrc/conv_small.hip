@@ -349,6 +349,80 @@ __global__ __launch_bounds__(TPB) void up_head_fwd2_kernel(const float* __restri
                                                           jp_act(o[1][2] + bv, act), jp_act(o[1][3] + bv, act));
 }
 
+// the same with the channel loop split over the workgroup's 4 waves (64 pixel pairs per workgroup): the small maps
+template <int groups>
+__global__ __launch_bounds__(TPB) void up_head_fwd2s_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                           int h, int wd, int act) {
+    extern __shared__ float wq[];   // [16][C]
+    __shared__ float red[3][64][8];
+    up_build_weights(w, wq, C);
+    __syncthreads();
+    // 64 pixel pairs per workgroup; wave cg takes a quarter of the channels (a thread's channel loop is a chain of dependent-latency
+    // loads: four chains of C/4 instead of one of C, four times the waves on the small maps), partial sums meet in LDS
+    const int img = blockIdx.y, hw = h * wd, w2 = wd >> 1;
+    // (groups = 1 on the large maps: 256 pairs per workgroup, one chain -- there the kernel is throughput-bound and four times the
+    // workgroups only rebuild the slot weights four times as often: 0.39 vs 0.50 ms at 8 x 256 x 256^2)
+    constexpr int ppb = groups == 4 ? 64 : TPB;
+    const int cg = threadIdx.x / ppb;
+    const int p = blockIdx.x * ppb + (threadIdx.x % ppb);
+    const bool live = p < h * w2;
+    const int pc = live ? p : 0;
+    const int i = pc / w2, j = 2 * (pc - i * w2);
+    const int r0 = max(i - 1, 0) * wd, r1 = i * wd, r2 = min(i + 1, h - 1) * wd;
+    const int cl = max(j - 1, 0), cr = min(j + 2, wd - 1);
+    float o[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[k][q] = 0.f;
+    const float* xp = x + (size_t)img * C * hw;
+    const int cq = (C + groups - 1) / groups, cbeg = cg * cq, cend = min(C, cbeg + cq);
+#pragma unroll 4
+    for (int c = cbeg; c < cend; ++c) {
+        const float* q = xp + (size_t)c * hw;
+        float v[3][4];
+        const int rr[3] = {r0, r1, r2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float2 m = *reinterpret_cast<const float2*>(q + rr[r] + j);
+            v[r][0] = q[rr[r] + cl]; v[r][1] = m.x; v[r][2] = m.y; v[r][3] = q[rr[r] + cr];
+        }
+        float wc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wc[t] = wq[t * C + c];
+        // pixel k reads columns k .. k+2 of the window; class (a, b), slot (r, s) reads v[a + r][k + b + s]
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            o[k][0] += wc[0] * v[0][k] + wc[1] * v[0][k + 1] + wc[2] * v[1][k] + wc[3] * v[1][k + 1];
+            o[k][1] += wc[4] * v[0][k + 1] + wc[5] * v[0][k + 2] + wc[6] * v[1][k + 1] + wc[7] * v[1][k + 2];
+            o[k][2] += wc[8] * v[1][k] + wc[9] * v[1][k + 1] + wc[10] * v[2][k] + wc[11] * v[2][k + 1];
+            o[k][3] += wc[12] * v[1][k + 1] + wc[13] * v[1][k + 2] + wc[14] * v[2][k + 1] + wc[15] * v[2][k + 2];
+        }
+    }
+    const int lp = threadIdx.x & 63;
+    if (groups == 1) {
+        if (!live) return;
+    } else {
+    if (cg > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[cg - 1][lp][k] = o[k >> 2][k & 3];
+    }
+    __syncthreads();
+    if (cg > 0 || !live) return;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k >> 2][k & 3] += red[g][lp][k];
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    float* yo = y + (size_t)img * 4 * hw + (size_t)(2 * i) * (2 * wd) + 2 * j;
+    *reinterpret_cast<float4*>(yo) = make_float4(jp_act(o[0][0] + bv, act), jp_act(o[0][1] + bv, act), jp_act(o[1][0] + bv, act),
+                                                 jp_act(o[1][1] + bv, act));
+    *reinterpret_cast<float4*>(yo + 2 * wd) = make_float4(jp_act(o[0][2] + bv, act), jp_act(o[0][3] + bv, act),
+                                                          jp_act(o[1][2] + bv, act), jp_act(o[1][3] + bv, act));
+}
+
 // dgrad: dx[c][i][j] (= | +=) sum_q W'[q][c] * D_q(i, j), straight at half resolution
 __global__ __launch_bounds__(TPB) void up_head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                             float* __restrict__ dx, int C, int h, int wd,
@@ -542,8 +616,12 @@ int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c
 int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
                    hipStream_t st) {
     if (wd % 4 == 0) {       // two pixels per thread (aligned float2 / float4 accesses)
-        hipLaunchKernelGGL(up_head_fwd2_kernel, dim3(jp_cdiv(h * (wd / 2), TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w, bias,
-                           y, C, h, wd, act);
+        if ((long)N * h * (wd / 2) <= 8L * 2048)      // small maps: a thread's 256-channel chain of dependent-latency loads split over 4 waves
+            hipLaunchKernelGGL(up_head_fwd2s_kernel<4>, dim3(jp_cdiv(h * (wd / 2), 64), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w,
+                               bias, y, C, h, wd, act);
+        else
+            hipLaunchKernelGGL(up_head_fwd2_kernel, dim3(jp_cdiv(h * (wd / 2), TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w,
+                               bias, y, C, h, wd, act);
         return 0;
     }
     hipLaunchKernelGGL(up_head_fwd_kernel, dim3(jp_cdiv(h * wd, TPB), N), dim3(TPB), sizeof(float) * 16 * C, st, x, w, bias, y,

@@ -170,7 +170,8 @@ def test_conv2d_fused_upsample_concat(N, H, W, Cr, Cx, Cout):
         close(got, ref.grad, rtol=2e-4, msg=nm)
 
 
-@pytest.mark.parametrize("N,C,h,w", [(2, 40, 6, 10), (1, 256, 20, 36), (3, 64, 2, 2), (1, 256, 64, 64)])
+@pytest.mark.parametrize("N,C,h,w", [(2, 40, 6, 10), (1, 256, 20, 36), (3, 64, 2, 2), (1, 256, 64, 64),
+                                     (8, 64, 128, 128)])      # large map: the one-chain two-pixel forward, precomputed-gather wgrad
 def test_disparity_head_on_upsampled_source(N, C, h, w):
     """disp_k = sigmoid(Conv3x3_reflect(up2x(x))) (depth_decoder.py:36-39,70-71): upsample-aware direct kernels."""
     x = rnd(N, C, h, w, seed=1)
