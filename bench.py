@@ -148,16 +148,33 @@ def timed_steps(runner, batch, steps, warmup, world, dev, log):
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms")
     sync()
+    if world > 1:
+        runner.hook.exposed_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
         out = runner.train_iter(batch)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0           # this rank's own clock (before the closing barrier)
     sync()
     dt = time.perf_counter() - t0
+    multi = None
     if world > 1:
+        ev = runner.hook.exposed_events or []
+        runner.hook.exposed_events = None
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    return dt, out
+        mine = torch.tensor([dt_own / steps * 1e3, exposed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        multi = {"backend": dist.get_backend(), "ms_per_step_per_rank": [round(float(e[0]), 3) for e in every],
+                 "allreduce_exposed_ms_per_rank": [round(float(e[1]), 3) for e in every],
+                 "allreduce_exposed_ms": round(max(float(e[1]) for e in every), 3),
+                 "allreduce_bytes_per_step": int(runner.optimizer.arena.live_numel) * 4,
+                 "note": "exposed = time the compute stream waits for the bucketed SUM all-reduce after the backward's last "
+                         "kernel (core/dist_utils.py); DESIGN.md section 6 estimates 0.35-2.4 ms on xGMI"}
+    return dt, out, multi
 
 
 def _free_port():
@@ -227,7 +244,7 @@ def main():
     runner, batch = build_runner(optd, dev, world, rank,
                                  dict(B=B, height=HW, width=HW, frame_ids=frames, occ=HW // 4, full_hw=cfg["full_hw"],
                                       split=cfg["split"], seed=1))
-    dt, out = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log)
+    dt, out, multi = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     log(f"{args.steps} timed steps: {ms:.1f} ms/step, {value:.2f} images/s")
@@ -269,6 +286,8 @@ def main():
                        "parallelism": f"dp{world}", "loss": float(out["log_vars"]["loss"])},
             "roofline": roof, "cpu_baseline": cpu, "families": fam, "secondary": sec,
         }
+        if multi is not None:
+            line["multi_gpu"] = multi
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -285,7 +304,7 @@ def secondary_figure(dev, B, log, steps=6, warmup=2):
         optd = make_opt(B, 320, 1024, frames, layout_branch=False)
         runner, batch = build_runner(optd, dev, 1, 0, dict(B=B, height=320, width=1024, frame_ids=frames, occ=256,
                                                            full_hw=(375, 1242), split="odometry", seed=1))
-        dt, out = timed_steps(runner, batch, steps, warmup, 1, dev, lambda m: None)
+        dt, out, _ = timed_steps(runner, batch, steps, warmup, 1, dev, lambda m: None)
         ms = dt / steps * 1e3
         res = {"workload": f"SECONDARY (not the headline): 1024(W)x320(H), frames {frames}, {B} images/GPU, "
                            "depth + pose + CGT warp + photometric/SSIM/automask + smoothness + scale losses, backward, "
@@ -563,8 +582,18 @@ def measure_roofline(runner, batch, B, t_step, rank):
     except Exception:
         pass
     conv_total = sum(conv_alg.values())
+    bf16_frac = ex_split / max(ms_split, 1e-9) / 1e9 / PEAK_BF16_TF
+    f32_frac = ex_f32 / max(ms_f32, 1e-9) / 1e9 / PEAK_FP32_TF
+    hbm_ms = sum(v["ms"] for k, v in fam.items() if not k.startswith("conv "))
+    # the step against the bound that binds it now: every fp32 convolution FLOP of the step (1.63 TFLOP per
+    # image-step) costs 6 bf16-MFMA FLOPs when formed from exact operand splits, priced at the 2.5 PF dense bf16 peak
+    step_bound = 1.63e12 * B * 6 / t_step / (PEAK_BF16_TF * 1e12)
+    # key order: the driver's parser keeps a bounded set of scalars -- the step-level figures come right after `frac`
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic,
+            "step_bf16_bound_frac": round(step_bound, 4),
+            "bf16_pipe_frac": round(bf16_frac, 4), "fp32_pipe_frac": round(f32_frac, 4),
+            "fp32_pipe_ms": round(ms_f32, 2), "bf16_pipe_ms": round(ms_split, 2), "hbm_kernels_ms": round(hbm_ms, 2),
             "kernel": name + " — by-time dominant igemm instantiation of the step",
             "pipe": ("bf16 MFMA, fp32 products as 6 bf16 products of 3-way operand splits (fp32 in/out/accumulate)" if dom_split
                      else "fp32 MFMA (exact)"),
@@ -575,22 +604,14 @@ def measure_roofline(runner, batch, B, t_step, rank):
             # the same kernel in fp32 FLOPs of the layer it computes (what an fp32-MFMA kernel would be priced on)
             "algorithmic_fp32_tflops": round(dom["algorithmic_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
             "algorithmic_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
-            # step level (1.63 TFLOP / image-step of fp32 convolution work).  Since the patch kernels moved to
-            # the bf16 pipe the fp32-MFMA peak is no longer the step's bound: the ratio is given as a speed-up over it
             "step_fp32_equiv_tflops": round(1.63e12 * B / t_step / 1e12, 2),
-            "step_vs_fp32_mfma_peak": round(1.63e12 * B / t_step / (PEAK_FP32_TF * 1e12), 4),
             "step_conv_tflop_counted": round(conv_total / 1e12, 3),
             "achieved_hbm_tbs": round((9.7e9 * B + 2.3e9) / t_step / 1e12, 3),
             "achieved_hbm_frac": round((9.7e9 * B + 2.3e9) / t_step / (PEAK_HBM_TBS * 1e12), 4),
-            # all implicit-GEMM kernels of the step (flat keys: the driver's parser keeps scalars only), per pipe: executed MFMA
-            # TFLOP/s against that pipe's dense peak
+            # all implicit-GEMM kernels of the step, per pipe: executed MFMA TFLOP/s against that pipe's dense peak
             "igemm_ms_per_step": round(ig_ms, 2), "igemm_fp32_equiv_tflops": round(ig_alg / (ig_ms * 1e-3) / 1e12, 2),
-            "bf16_pipe_ms": round(ms_split, 2), "bf16_pipe_executed_tflops": round(ex_split / max(ms_split, 1e-9) / 1e9, 1),
-            "bf16_pipe_frac": round(ex_split / max(ms_split, 1e-9) / 1e9 / PEAK_BF16_TF, 4),
-            "fp32_pipe_ms": round(ms_f32, 2), "fp32_pipe_executed_tflops": round(ex_f32 / max(ms_f32, 1e-9) / 1e9, 1),
-            "fp32_pipe_frac": round(ex_f32 / max(ms_f32, 1e-9) / 1e9 / PEAK_FP32_TF, 4),
-            # HBM-bound kernel families of the same (single-stream) instrumented step
-            "hbm_kernels_ms": round(sum(v["ms"] for k, v in fam.items() if not k.startswith("conv ")), 2)}
+            "bf16_pipe_executed_tflops": round(ex_split / max(ms_split, 1e-9) / 1e9, 1),
+            "fp32_pipe_executed_tflops": round(ex_f32 / max(ms_f32, 1e-9) / 1e9, 1)}
     table = {"step_ms_timed": round(t_step * 1e3, 2),
              "entry_points": {k: {"calls": v[0], "ms": round(v[1], 3)} for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][1])},
              "families": {k: {"calls": v["calls"], "ms": round(v["ms"], 3)} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},

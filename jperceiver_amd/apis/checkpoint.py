@@ -36,7 +36,9 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
     d = os.path.dirname(filename)
     if d:
         os.makedirs(d, exist_ok=True)
-    torch.save(ckpt, filename)
+    tmp = f"{filename}.tmp.{os.getpid()}"           # a reader (resume) never sees a half-written file
+    torch.save(ckpt, tmp)
+    os.replace(tmp, filename)
     return ckpt
 
 

@@ -1,6 +1,7 @@
-"""Train API with the reference's surface (mono/apis/trainer.py:20-56,76-143): `change_input_variable`,
-`batch_processor(model, data, train_mode)`, `build_optimizer(model, optimizer_cfg)`, plus a minimal
-`Runner` that reproduces the mmcv hot loop order (forward -> DistOptimizerHook.after_train_iter)."""
+"""Train API with the reference's surface (mono/apis/trainer.py:20-56,59-73,76-143,146-199): `change_input_variable`,
+`batch_processor(model, data, train_mode)`, `build_optimizer(model, optimizer_cfg)`, `train_mono(model, dataset_train,
+dataset_val, cfg, args, distributed, validate, logger)` -- what `train.py:89-96` calls -- plus a minimal `Runner` that
+reproduces the mmcv hot loop order (forward -> DistOptimizerHook.after_train_iter)."""
 from __future__ import annotations
 
 import os
@@ -220,6 +221,7 @@ class Runner(object):
         self.work_dir = work_dir
         self.checkpoint_config = dict(checkpoint_config) if checkpoint_config else None
         self.after_train_epoch_hooks = []          # callables(runner), run before the epoch counter moves (mmcv order)
+        self.after_train_iter_hooks = []           # callables(runner), after the optimizer hook (log hooks)
         self.lr_hook = StepLrUpdaterHook(**lr_config) if lr_config else None
         if self.lr_hook is not None:
             self.lr_hook.before_run(self)
@@ -236,8 +238,24 @@ class Runner(object):
         lv = self.outputs.get("log_vars") if isinstance(self.outputs, dict) else None
         if isinstance(lv, LazyLogVars):
             lv._resolve()       # backward + optimizer are enqueued: waiting for the forward's scalars stalls nothing now
+        for h in self.after_train_iter_hooks:
+            h(self)
         self.iter += 1
         return self.outputs
+
+    def run(self, data_loaders, workflow, max_epochs, **kwargs):
+        """mmcv.Runner.run for the configs' `workflow = [('train', 1)]`: cycle the workflow's phases until `max_epochs`
+        epochs have been trained (a resumed runner continues at its restored epoch)."""
+        if len(data_loaders) != len(workflow):
+            raise ValueError("one data loader per workflow phase")
+        while self.epoch < max_epochs:
+            for (mode, epochs), loader in zip(workflow, data_loaders):
+                if mode != "train":
+                    raise NotImplementedError("only ('train', n) workflow phases (all north-star configs)")
+                for _ in range(epochs):
+                    if self.epoch >= max_epochs:
+                        return
+                    self.train_epoch(loader)
 
     def train_epoch(self, data_loader):
         """mmcv.Runner.train: before_train_epoch hooks, one pass over the loader, after_train_epoch hooks (the checkpoint
@@ -264,10 +282,13 @@ class Runner(object):
         (`checkpoint_config=` / `after_train_epoch_hooks`); a manual call AFTER `train_epoch()` returned would label the file
         one epoch ahead, which `resume()` would then take at face value."""
         from .checkpoint import save_checkpoint
-        import os
         meta = dict(meta or {}, epoch=self.epoch + 1, iter=self.iter)
         path = os.path.join(out_dir or self.work_dir or ".", filename_tmpl.format(self.epoch + 1))
-        save_checkpoint(self.model, path, optimizer=self.optimizer if save_optimizer else None, meta=meta)
+        live = dist.is_available() and dist.is_initialized()
+        if not live or dist.get_rank() == 0:    # mmcv's CheckpointHook.after_train_epoch is @master_only
+            save_checkpoint(self.model, path, optimizer=self.optimizer if save_optimizer else None, meta=meta)
+        if live and dist.get_world_size() > 1:
+            dist.barrier()                      # nobody resumes from / trains past a file that is still being written
         return path
 
     def load_checkpoint(self, filename, map_location="cpu", strict=False):
@@ -281,3 +302,115 @@ class Runner(object):
         if "optimizer" in ckpt and resume_optimizer:
             self.optimizer.load_state_dict(ckpt["optimizer"])
         return ckpt
+
+
+def _cfg(cfg, name, default=None):
+    """attribute / item / `.get` access over an mmcv `Config`, a dict or a namespace"""
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    v = getattr(cfg, name, default)
+    return default if v is None else v
+
+
+class _LogHook(object):
+    """the slice of mmcv's TextLoggerHook `log_config=dict(interval=n, ...)` asks for: one line per `interval` iterations"""
+
+    def __init__(self, logger, interval):
+        self.logger, self.interval, self.n = logger, max(1, int(interval)), 0
+
+    def __call__(self, runner):
+        self.n += 1
+        if self.logger is not None and self.n % self.interval == 0:
+            lv = runner.outputs["log_vars"]
+            self.logger.info("Epoch [%d] iter %d lr %.3e loss %.5f", runner.epoch + 1, runner.iter, runner.current_lr()[0],
+                             lv["loss"])
+
+
+def _validate_hook(dataset_val, cfg, logger):
+    """DistEvalMonoHook / NonDistEvalHook (mono/core/evaluation/eval_hooks.py:27-100) reduced to their numbers: after every
+    `validate_interval` epochs the eval-mode forward over `dataset_val` and the seven depth metrics with median scaling
+    (items without `gt_depth` are skipped); the training mode is restored afterwards."""
+    from .inference import evaluate_depth
+    interval = int(_cfg(cfg, "validate_interval", 1))
+
+    def hook(runner):
+        if (runner.epoch + 1) % interval or dataset_val is None:
+            return
+        m = getattr(runner.model, "module", runner.model)
+        was = m.training
+        m.eval()
+        batches, gts = [], []
+        for i in range(len(dataset_val)):
+            item = dataset_val[i]
+            if "gt_depth" not in item:
+                continue
+            gts.append(item["gt_depth"])
+            batches.append({k: torch.as_tensor(v).float().unsqueeze(0).cuda() for k, v in item.items()
+                            if k != "gt_depth" and not isinstance(v, str)})
+        if batches:
+            runner.eval_result = evaluate_depth(m, batches, gts)
+            if logger is not None:
+                logger.info("validation after epoch %d: %s", runner.epoch + 1, runner.eval_result[0])
+        m.train(was)
+    return hook
+
+
+def _train(model, dataset_train, dataset_val, cfg, validate, logger, distributed):
+    from ..core.dist_utils import DistOptimizerHook
+    from ..datasets.loader import DeviceLoader, build_dataloader
+    gpus = _cfg(cfg, "gpus", [0])
+    loader = build_dataloader(dataset_train, _cfg(cfg, "imgs_per_gpu", 1), _cfg(cfg, "workers_per_gpu", 0),
+                              num_gpus=1 if distributed else max(1, len(gpus)), dist=distributed)
+    # `device` is not a reference option: the host-logic tests run this wiring on CPU with a stub step
+    dev = torch.device(_cfg(cfg, "device", "cuda"))
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    model = model.to(dev)
+    # MMDistributedDataParallel / MMDataParallel stand-in: `.module`, rank 0's weights everywhere; gradients are averaged
+    # ONCE, on the flat arena, by the optimizer hook (one process per GPU also in the "non-distributed" launch)
+    model = DataParallelShell(model)
+    optimizer = build_optimizer(model, _cfg(cfg, "optimizer", dict(type="Adam", lr=1e-4, weight_decay=0)))
+    oc = dict(_cfg(cfg, "optimizer_config", {}) or {})
+    work_dir = _cfg(cfg, "work_dir", ".")
+    runner = Runner(model, batch_processor, optimizer, DistOptimizerHook(**oc), lr_config=_cfg(cfg, "lr_config"),
+                    work_dir=work_dir, checkpoint_config=_cfg(cfg, "checkpoint_config"))
+    lc = _cfg(cfg, "log_config")
+    if lc is not None and logger is not None:
+        runner.after_train_iter_hooks.append(_LogHook(logger, dict(lc).get("interval", 50)))
+    if validate:
+        runner.after_train_epoch_hooks.append(_validate_hook(dataset_val, cfg, logger))
+    if _cfg(cfg, "resume_from"):
+        runner.resume(_cfg(cfg, "resume_from"))
+    elif _cfg(cfg, "load_from"):
+        runner.load_checkpoint(_cfg(cfg, "load_from"))
+    # pinned double-buffered upload underneath the step (datasets/loader.py); `.sampler` stays visible for set_epoch
+    runner.run([DeviceLoader(loader, dev) if dev.type == "cuda" else loader], _cfg(cfg, "workflow", [("train", 1)]), _cfg(cfg, "total_epochs", 1))
+    return runner
+
+
+def _dist_train(model, dataset_train, dataset_val, cfg, args=None, validate=False, logger=None):
+    """trainer.py:146-199: DistributedGroupSampler loader, DDP wrap, optimizer, runner with lr / optimizer / checkpoint /
+    log hooks and the sampler-seed hook (`Runner.train_epoch` calls `sampler.set_epoch`), resume_from | load_from, run."""
+    return _train(model, dataset_train, dataset_val, cfg, validate, logger, True)
+
+
+def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False, logger=None):
+    """trainer.py:202-240: GroupSampler loader over `len(cfg.gpus)` x imgs_per_gpu; this build drives ONE device per
+    process, so cfg.gpus longer than one entry is refused instead of silently training on a single GPU."""
+    if len(_cfg(cfg, "gpus", [0])) > 1:
+        raise NotImplementedError("single-process multi-GPU (MMDataParallel) is not built: launch one process per GPU "
+                                  "(`--launcher pytorch`), the reference's own multi-GPU recipe")
+    return _train(model, dataset_train, dataset_val, cfg, validate, logger, False)
+
+
+def train_mono(model, dataset_train, dataset_val, cfg, args=None, distributed=False, validate=False, logger=None):
+    """trainer.py:59-73, same signature: `train.py:89-96` runs unchanged with `from jperceiver_amd.apis import train_mono`.
+    Returns the runner (the reference returns None)."""
+    if logger is None:
+        import logging
+        logger = logging.getLogger("jperceiver_amd")
+        lvl = _cfg(cfg, "log_level", "INFO")
+        logger.setLevel(getattr(logging, lvl) if isinstance(lvl, str) else lvl)
+    if distributed:
+        return _dist_train(model, dataset_train, dataset_val, cfg, args, validate=validate, logger=logger)
+    return _non_dist_train(model, dataset_train, dataset_val, cfg, validate=validate, logger=logger)

@@ -56,6 +56,7 @@ class _Exchange:
         self.arena, self.bucket = arena, _bucket_floats(bucket_size_mb)
         self.works = []                 # (work, offset, numel) in launch order
         self.done = set()
+        self.events = None              # list to receive (before-waits, after-waits) event pairs (bench.py, N > 1)
 
     def launch(self, seg: str):
         """Start the all-reduce of one arena segment (idempotent).  Called from the tape (ops.grad_ready) with the
@@ -75,10 +76,18 @@ class _Exchange:
         and fold each landed bucket into the global-norm partials while later buckets are still in flight."""
         for seg in self.arena.segments:
             self.launch(seg)
+        if self.events is not None and self.arena.grads.is_cuda:
+            # everything the backward enqueued precedes e0; e1 follows the last bucket's arrival: e1 - e0 is the part of
+            # the exchange the compute stream had to wait for (plus the interleaved norm partials, ~0.1 ms)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w, o, k in self.works:
             w.wait()
             if with_norm:
                 self.arena.add_norm_partial(o, k)
+        if self.events is not None and self.arena.grads.is_cuda:
+            e1.record()
+            self.events.append((e0, e1))
         self.works = []
 
 
@@ -105,6 +114,7 @@ class DistOptimizerHook(object):
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
         self.force_exchange = force_exchange
+        self.exposed_events = None      # set to [] to collect one (e0, e1) event pair per step (bench.py's allreduce_exposed_ms)
 
     def after_train_iter(self, runner):
         """zero_grad -> backward (+ overlapped all-reduce) -> global norm -> clip + Adam (dist_utils.py:54-60)."""
@@ -116,6 +126,7 @@ class DistOptimizerHook(object):
             ex = None
             if world > 1 or (self.force_exchange and dist.is_available() and dist.is_initialized()):
                 ex = _Exchange(opt.arena, self.bucket_size_mb)
+                ex.events = self.exposed_events
                 prev = ops.set_grad_ready_hook(ex.launch)
                 try:
                     runner.outputs["loss"].backward()

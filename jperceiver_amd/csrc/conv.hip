@@ -2411,7 +2411,9 @@ int jp_c16_fwd(const float* x, int up, const float* w, const float* bias, float*
                hipStream_t st);
 int jp_c16_dgrad(const float* dy, const float* w, float* dx, int up, int N, int Cin, int Cout, int H, int W, int accumulate,
                  hipStream_t st);
-int jp_c16_wgrad(const float* x, int up, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, hipStream_t st);
+int jp_c16_wgrad(const float* x, int up, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, hipStream_t st,
+                 float* ws, long ws_floats);
+long jp_c16_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W);
 int jp_up_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int h, int wd, int act,
                    hipStream_t st);
 int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, int h, int wd, int accumulate, hipStream_t st);
@@ -3021,7 +3023,7 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         JP_LAUNCH_CHECK();
     }
     if (whole && c1 == 0 && c2 == 0 && jp_c16_ok(c0, Cout, KH, stride, pad, pad_mode, H, W)) {
-        jp_c16_wgrad(x0, up0, dy, dw, N, c0, Cout, H, W, st);
+        jp_c16_wgrad(x0, up0, dy, dw, N, c0, Cout, H, W, st, ws, ws ? ws_floats : 0);
         JP_LAUNCH_CHECK();
     }
     if (whole && small_head(Cin, Cout, KH, stride, pad)) {
@@ -3308,6 +3310,7 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
 // scratch floats for jp_conv2d_wgrad_src3 on a multi-source input (0 = use the single-source query / no benefit)
 extern "C" long jp_conv2d_wgrad_src3_ws_floats(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W,
                                                int Cout, int KH, int stride, int pad, int pad_mode) {
+    if (c1 == 0 && c2 == 0 && jp_c16_ok(c0, Cout, KH, stride, pad, pad_mode, H, W)) return jp_c16_wgrad_ws_floats(N, c0, Cout, H, W);
     if (!wgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode)) return 0;
     const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
     const long cap = 48L << 20;
@@ -3340,6 +3343,7 @@ extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
 extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int KH, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW, cap = 32L << 20;
+    if (jp_c16_ok(Cin, Cout, KH, stride, pad, 0, H, W)) return jp_c16_wgrad_ws_floats(N, Cin, Cout, H, W);
     W7Plan w7;
     if (w7_plan(N, Cin, H, W, Cout, KH, stride, pad, cap, &w7)) return w7.need;
     W1Plan w1;

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(TPB) void c16_conv_kernel(const float* __restrict__
 
 // dw[co][ci][tap] += sum over pixels of dy[co][y][x] * X[ci][y + ty - 1][x + tx - 1]
 constexpr int WG_R = 4, WG_C = 64;
-template <int CI, int CO, bool UPIN>
+// PART: every workgroup writes its partial sums to its own slice of caller scratch (`dw` = scratch + blockIdx.x * CO*CI*9) and
+// c16_wgrad_fold_kernel adds the slices in block order -- bit-reproducible run to run; without scratch the workgroups merge
+// with fp32 atomics (order = arrival order).
+template <int CI, int CO, bool UPIN, bool PART>
 __global__ __launch_bounds__(TPB) void c16_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                                         int H, int W, int ntiles) {
     constexpr int P = CI * CO / TPB;                       // (co, ci) pairs per thread
@@ -164,8 +167,19 @@ __global__ __launch_bounds__(TPB) void c16_wgrad_kernel(const float* __restrict_
     for (int k = 0; k < P; ++k) {
         const int q = threadIdx.x + TPB * k;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) atomicAdd(dw + (size_t)q * 9 + t, acc[k][t]);
+        for (int t = 0; t < 9; ++t) {
+            if (PART) dw[(size_t)blockIdx.x * (CO * CI * 9) + (size_t)q * 9 + t] = acc[k][t];
+            else atomicAdd(dw + (size_t)q * 9 + t, acc[k][t]);
+        }
     }
+}
+
+__global__ void c16_wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int nblocks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * n + i];
+    dw[i] += s;
 }
 
 template <bool UPIN, bool SUMOUT, bool TRANS>
@@ -206,13 +220,21 @@ int jp_c16_dgrad(const float* dy, const float* w, float* dx, int up, int N, int 
               : launch_conv<false, false, true>(dy, w, nullptr, dx, N, Cout, Cin, H, W, 0, accumulate, st);
 }
 // wgrad: dw (Cout, Cin, 3, 3) += ...
-int jp_c16_wgrad(const float* x, int up, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, hipStream_t st) {
+long jp_c16_wgrad_ws_floats(int N, int Cin, int Cout, int H, int W) {
+    return (long)std::min(N * (H / WG_R) * (W / WG_C), 512) * Cout * Cin * 9;
+}
+int jp_c16_wgrad(const float* x, int up, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, hipStream_t st,
+                 float* ws, long ws_floats) {
     const int ntiles = N * (H / WG_R) * (W / WG_C);
     const dim3 grid(std::min(ntiles, 512));
-#define JP_GO(A, B)                                                                                               \
-    {                                                                                                             \
-        if (up) hipLaunchKernelGGL((c16_wgrad_kernel<A, B, true>), grid, dim3(TPB), 0, st, x, dy, dw, H, W, ntiles);  \
-        else hipLaunchKernelGGL((c16_wgrad_kernel<A, B, false>), grid, dim3(TPB), 0, st, x, dy, dw, H, W, ntiles);    \
+    const int nw = Cout * Cin * 9;
+    const bool part = ws && ws_floats >= (long)grid.x * nw;       // fixed-order merge through caller scratch
+    float* out = part ? ws : dw;
+#define JP_GO1(A, B, U, P) hipLaunchKernelGGL((c16_wgrad_kernel<A, B, U, P>), grid, dim3(TPB), 0, st, x, dy, out, H, W, ntiles)
+#define JP_GO(A, B)                                                                     \
+    {                                                                                   \
+        if (up) { if (part) JP_GO1(A, B, true, true); else JP_GO1(A, B, true, false); } \
+        else { if (part) JP_GO1(A, B, false, true); else JP_GO1(A, B, false, false); }  \
     }
     if (Cin == 16 && Cout == 16) JP_GO(16, 16)
     else if (Cin == 32 && Cout == 32) JP_GO(32, 32)
@@ -220,5 +242,7 @@ int jp_c16_wgrad(const float* x, int up, const float* dy, float* dw, int N, int 
     else if (Cin == 16 && Cout == 32) JP_GO(16, 32)
     else return 1;
 #undef JP_GO
+#undef JP_GO1
+    if (part) hipLaunchKernelGGL(c16_wgrad_fold_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, ws, dw, nw, (int)grid.x);
     return 0;
 }

@@ -26,6 +26,25 @@ def collate(samples):
     return out
 
 
+def build_dataloader(dataset, imgs_per_gpu, workers_per_gpu, num_gpus=1, dist=True, **kwargs):
+    """mono/datasets/loader/build_loader.py:18-55 with the same arguments and the same sampler choice: shuffled runs cut
+    ONE epoch-seeded plan across the ranks (`DistributedGroupSampler`; `GroupSampler` for the single-process path),
+    `shuffle=False` takes `DistributedSampler` / sequential order; batches of `imgs_per_gpu` (x `num_gpus` when not
+    distributed), `drop_last=True`.  Collation is `collate` above (stack along a new batch axis)."""
+    from torch.utils.data import DataLoader
+    from .sampler import DistributedGroupSampler, DistributedSampler, GroupSampler
+    shuffle = kwargs.pop("shuffle", True)
+    if dist:
+        sampler = DistributedGroupSampler(dataset, imgs_per_gpu) if shuffle else DistributedSampler(dataset, shuffle=False)
+        batch_size, num_workers = imgs_per_gpu, workers_per_gpu
+    else:
+        sampler = GroupSampler(dataset, imgs_per_gpu) if shuffle else None
+        batch_size, num_workers = num_gpus * imgs_per_gpu, num_gpus * workers_per_gpu
+    kwargs.setdefault("collate_fn", collate)
+    return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers, pin_memory=False,
+                      drop_last=True, **kwargs)
+
+
 class DeviceLoader:
     def __init__(self, batches, device="cuda", preprocess=None, depth=2):
         dev = torch.device(device)
@@ -33,6 +52,10 @@ class DeviceLoader:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.batches, self.dev, self.pre, self.depth = batches, dev, preprocess, max(1, depth)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.sampler = getattr(batches, "sampler", None)       # DistSamplerSeedHook's handle (runner.train_epoch)
+
+    def __len__(self):
+        return len(self.batches)
 
     def _stage(self, batch):
         """pin + enqueue the upload (and the device preprocessing) on the copy stream; -> (device batch, ready event)"""

@@ -382,7 +382,11 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                     del xc, ws_w
                 else:
                     single = len(srcs) == 1 and not srcs[0][1]
-                    nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad)) if single else 0
+                    if single:
+                        nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad))
+                    else:       # few-channel layer on an upsampled source (BEV decoder 16 -> 16): partial sums of the direct kernel
+                        nws = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W,
+                                                                                 Cout, KH, stride, pad, pad_mode))
                     ws_w = _new((nws,), dy) if nws else None
                     call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
                     del ws_w

@@ -167,3 +167,96 @@ def test_bucket_sizes_any_value_is_legal():
     ex = _Exchange(ar, bucket_size_mb=0.01)
     offs = [o for seg in ar.segments.values() for o in range(seg[0], seg[0] + seg[1], ex.bucket)]
     assert len(offs) > 64 and all(o % 64 == 0 for o in offs)
+
+
+class _ToyData(torch.utils.data.Dataset):
+    """12 items in two aspect-ratio groups (the `flag` the group samplers read, mono_dataset.py:95)"""
+
+    def __init__(self):
+        import numpy as np
+        self.flag = np.array([0] * 8 + [1] * 4, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.flag)
+
+    def __getitem__(self, i):
+        return {("color", 0, 0): torch.full((1, 2, 2), float(i)), ("idx", 0, 0): torch.tensor([float(i)])}
+
+
+class _Cfg(dict):
+    __getattr__ = dict.get
+
+
+def _train_mono_worker(rank, world, port, work_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from jperceiver_amd.apis import init_dist, trainer
+    init_dist("pytorch", backend="gloo")
+    seen = []
+
+    def step(model, data, train_mode):            # stub for batch_processor: the GPU step has its own tests
+        idx = data[("idx", 0, 0)].flatten().tolist()
+        loss = (model.module.w.sum() * 0 + 1.0)
+        return dict(loss=loss, log_vars={"loss": 1.0}, num_samples=len(idx), idx=idx)
+
+    class Hook:                                   # stub for DistOptimizerHook: counts, records lr / epoch / items
+        def __init__(self, **kw):
+            self.kw = kw
+
+        def after_train_iter(self, runner):
+            seen.append((runner.epoch, runner.current_lr()[0], tuple(runner.outputs["idx"])))
+    trainer.batch_processor = step
+    trainer.build_optimizer = lambda model, cfg: torch.optim.SGD(model.parameters(), lr=cfg["lr"])
+    import jperceiver_amd.core.dist_utils as du
+    du.DistOptimizerHook = Hook
+    m = _M()
+    with torch.no_grad():
+        m.w.fill_(float(rank + 1))
+    cfg = _Cfg(imgs_per_gpu=2, workers_per_gpu=0, gpus=[0], optimizer=dict(type="Adam", lr=1e-2), device="cpu",
+               optimizer_config=dict(grad_clip=dict(max_norm=35, norm_type=2)), work_dir=work_dir, total_epochs=2,
+               lr_config=dict(policy="step", step=[1], gamma=0.5), checkpoint_config=dict(interval=1),
+               workflow=[("train", 1)], log_config=dict(interval=1, hooks=[]))
+    runner = trainer.train_mono(m, _ToyData(), None, cfg, None, distributed=True, validate=False)
+    first = (runner.epoch, runner.iter, float(m.w[0]), list(seen))
+    # resume from the first epoch's file in a fresh run of 3 epochs: continues at epoch index 1 with the decayed lr
+    del seen[:]
+    cfg2 = _Cfg(cfg, resume_from=os.path.join(work_dir, "epoch_1.pth"), total_epochs=3, work_dir=os.path.join(work_dir, "r"))
+    r2 = trainer.train_mono(_M(), _ToyData(), None, cfg2, None, distributed=True)
+    q.put((rank, first, (r2.epoch, r2.iter, list(seen))))
+    dist.destroy_process_group()
+
+
+def test_train_mono_world2_epochs_shards_checkpoint_resume(tmp_path):
+    """`train_mono` (mono/apis/trainer.py:59-73,146-199) wired from the package's own parts.  Two gloo
+    ranks, the real samplers / loader / Runner.run / lr hook / checkpoint path around a stub step: the ranks cut ONE plan
+    into disjoint group-pure batches that change with the epoch, rank 0 alone writes epoch_K.pth (atomically), rank 0's
+    weights are everywhere, and a resumed run continues at the saved epoch with the scheduled lr."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_mono_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(30)
+    (_, f0, r0), (_, f1, r1) = res
+    assert f0[:2] == f1[:2] == (2, 6)                           # 12 items / (2 ranks x 2 per batch) = 3 iterations x 2 epochs
+    assert f0[2] == f1[2] == 1.0                                # wrap-time broadcast of rank 0's parameters
+    for ep in (0, 1):
+        a = [i for e, lr, idx in f0[3] if e == ep for i in idx]
+        b = [i for e, lr, idx in f1[3] if e == ep for i in idx]
+        assert len(a) == len(b) == 6 and not set(a) & set(b) and set(a) | set(b) == set(range(12))
+        for e, lr, idx in f0[3] + f1[3]:
+            assert (idx[0] < 8) == (idx[1] < 8)                # a batch never mixes the two flag groups
+            assert lr == (1e-2 if e == 0 else 5e-3)
+    assert [idx for e, _, idx in f0[3] if e == 0] != [idx for e, _, idx in f0[3] if e == 1]      # set_epoch reshuffles
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["epoch_1.pth", "epoch_2.pth", "r"], files    # no temp files left, one writer
+    ck = torch.load(tmp_path / "epoch_2.pth", weights_only=False)
+    assert ck["meta"]["epoch"] == 2 and ck["meta"]["iter"] == 6 and list(ck["state_dict"]) == ["w"]
+    assert r0[:2] == r1[:2] == (3, 9)                           # resumed at epoch 1 / iter 3, trained epochs 1 and 2
+    assert [e for e, _, _ in r0[2]] == [1] * 3 + [2] * 3 and {lr for _, lr, _ in r0[2]} == {5e-3}
+    assert sorted(os.listdir(tmp_path / "r")) == ["epoch_2.pth", "epoch_3.pth"]

@@ -280,3 +280,79 @@ def test_bench_self_launch_two_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["config_index"] == 2
     assert "cfg_kitti_baseline_kitti_odom_4gpus" in j["config"]["workload"] and "loss_sum 1" in j["config"]["workload"]
+
+
+def test_bench_two_gpus_rccl():
+    """`bench.py --gpus 2 --config 1` on backend nccl (= RCCL), one rank per GPU -- the form of the
+    driver's scaling run.  Needs two devices: skipped (not failed) on the 1-GPU boxes of the build pool."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with N > 1 ranks)")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("JP_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "1",
+           "--no-cpu-baseline", "--no-secondary", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["scaling"] == "weak"
+    assert j["multi_gpu"]["backend"] == "nccl" and len(j["multi_gpu"]["ms_per_step_per_rank"]) == 2
+    assert j["multi_gpu"]["allreduce_exposed_ms"] >= 0.0
+
+
+class _SynthSet(torch.utils.data.Dataset):
+    """4 synthetic odometry items in the layout `mono_dataset.__getitem__` returns (no batch axis)"""
+
+    def __init__(self, hw, frames):
+        import numpy as np
+        self.hw, self.frames = hw, frames
+        self.flag = np.zeros(4, dtype=np.int64)
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        from jperceiver_amd import synthetic as syn
+        d = syn.make_batch(1, self.hw, self.hw, self.frames, self.hw // 4, (94, 311), "odometry", seed=70 + i)
+        return {k: v[0] for k, v in d.items()}
+
+
+def test_train_mono_two_epochs_single_rank(tmp_path):
+    """`train_mono(model, dataset_train, dataset_val, cfg, args, distributed, validate, logger)`
+    (mono/apis/trainer.py:59-73) end to end on the device: GroupSampler loader -> DeviceLoader -> the HIP step -> clip+Adam,
+    step-LR, the epoch checkpoint; then `resume_from` continues where the file says."""
+    from jperceiver_amd import synthetic as syn
+    from jperceiver_amd.model import MONO
+    from jperceiver_amd.apis import train_mono
+    from oracle import jp_oracle as J
+    HW, FR = 256, [0, -1, 1]
+    opt = J.default_opt(frame_ids=FR, imgs_per_gpu=2, height=HW, width=HW, occ_map_size=HW // 4, type="static", split="odometry")
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    cfg = Cfg(imgs_per_gpu=2, workers_per_gpu=0, gpus=[0], optimizer=dict(type="Adam", lr=1e-4, weight_decay=0),
+              optimizer_config=dict(grad_clip=dict(max_norm=35, norm_type=2)), work_dir=str(tmp_path), total_epochs=2,
+              lr_config=dict(policy="step", step=[1], gamma=0.5), checkpoint_config=dict(interval=2, save_optimizer=False),
+              workflow=[("train", 1)], log_level="INFO")
+    model = MONO.module_dict["Baseline"](opt)
+    model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
+    w0 = model.DepthDecoder.iconv3.conv.weight.detach().clone()
+    runner = train_mono(model, _SynthSet(HW, FR), None, cfg, None, distributed=False, validate=False)
+    assert runner.epoch == 2 and runner.iter == 4 and runner.current_lr()[0] == pytest.approx(5e-5)
+    lv = runner.outputs["log_vars"]
+    assert all(v == v and abs(v) < 1e6 for v in lv.values()) and lv["loss"] > 0
+    w1 = runner.model.module.DepthDecoder.iconv3.conv.weight.detach().cpu()
+    moved = (w1 - w0).abs().max()
+    assert 1e-5 < float(moved) < 1e-3                          # 2 steps at 1e-4 + 2 at 5e-5: |dw| <= 3e-4 per weight
+    assert os.listdir(tmp_path) == ["epoch_2.pth"]
+    m2 = MONO.module_dict["Baseline"](opt)
+    r2 = train_mono(m2, _SynthSet(HW, FR), None, Cfg(cfg, resume_from=str(tmp_path / "epoch_2.pth"), total_epochs=2,
+                                                     work_dir=str(tmp_path / "r")), None)
+    assert r2.epoch == 2 and r2.iter == 4                      # nothing left to train; weights are the file's
+    assert torch.equal(r2.model.module.DepthDecoder.iconv3.conv.weight.detach().cpu(), w1)

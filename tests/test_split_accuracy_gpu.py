@@ -73,6 +73,9 @@ def _emit():
         conv_case(f"1x1_256_{tag}", 8, 256, 64, 64, 256, 1, 0, 0, wide)
         conv_case(f"3x3_stride2_64_128_{tag}", 8, 64, 128, 128, 128, 3, 1, 0, wide, stride=2)      # P9S2F / P9S2D
         conv_case(f"7x7_stem_{tag}", 4, 3, 256, 256, 64, 7, 3, 0, wide, stride=2)                  # P7S
+        if not wide:    # the stems at the shapes the step issues (VERDICT r03 "weak" 1): depth 8x3x1024^2, pose pairs 8x6x192x640
+            conv_case("7x7_stem_bench_depth_unit", 8, 3, 1024, 1024, 64, 7, 3, 0, False, stride=2)
+            conv_case("7x7_stem_bench_pose_unit", 8, 6, 192, 640, 64, 7, 3, 0, False, stride=2)
         # iconv (P9US): cat(skip 64, up2x(x 96), disp 1) -> 256, reflect
         g = torch.Generator().manual_seed(12)
         N, H, W, Cr, Cx, Cout = 2, 64, 128, 64, 96, 256
@@ -107,9 +110,47 @@ def _emit():
     print("JSON" + json.dumps(res))
 
 
-def _run(env_extra):
+def _emit_edges():
+    """Range edges of the three-way split (`jp_split3`, igemm_p9s.h:33-45): non-finite and out-of-bf16-range inputs, tiny inputs."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.nn.functional as F
+    from jperceiver_amd import ops
+    from jperceiver_amd.ops import Var, Tape, recording
+    res = {}
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 2, 128, 32, 32
+    w = torch.randn((C, C, 3, 3), generator=g) * (9 * C) ** -0.5
+
+    def fwd(x):
+        with recording(Tape()):
+            return ops.conv2d(Var(x.cuda()), Var(w.cuda()), None, 1, 1, 0, 0).t.cpu()
+    x0 = torch.randn((N, C, H, W), generator=g)
+    y0 = fwd(x0)
+    for name, val in (("pinf", float("inf")), ("ninf", float("-inf")), ("nan", float("nan")), ("over_bf16", 3.3961775292304e38)):
+        x = x0.clone()
+        x[1, 7, 10, 20] = val
+        y = fwd(x)
+        touched = torch.zeros((N, 1, H, W), dtype=torch.bool)
+        touched[1, 0, 9:12, 19:22] = True
+        touched = touched.expand(N, C, H, W)
+        res[name] = dict(nonfinite_touched=int((~torch.isfinite(y[touched])).sum()), n_touched=int(touched.sum()),
+                         nonfinite_elsewhere=int((~torch.isfinite(y[~touched])).sum()),
+                         elsewhere_bit_identical=bool(torch.equal(y[~touched], y0[~touched])),
+                         n_posinf=int((y[touched] == float("inf")).sum()), n_neginf=int((y[touched] == float("-inf")).sum()),
+                         n_nan=int(torch.isnan(y[touched]).sum()))
+    for name, e in (("tiny_2^-100", -100), ("tiny_2^-120", -120)):
+        x = x0 * 2.0 ** e
+        y = fwd(x)
+        yd = F.conv2d(x.double(), w.double(), None, 1, 1)
+        ya = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+        res[name] = dict(rel_bound=float(((y.double() - yd).abs() / ya).max()))
+    print("JSON" + json.dumps(res))
+
+
+def _run(env_extra, mode="--emit"):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--emit"], capture_output=True, text=True, timeout=1800, env=env,
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], capture_output=True, text=True, timeout=1800, env=env,
                        cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("JSON")][-1]
@@ -134,6 +175,34 @@ def test_split_product_accuracy_vs_float64():
         assert e["rel_bound"] <= 2.0 ** -19, (k, e)
 
 
+def test_split_range_edges_match_documented_behaviour():
+    """VERDICT r03 "weak" 2.  What include/jperceiver_hip.h states for the split-product convolutions, next to the
+    exact-fp32 kernels on the same inputs:
+      * a NaN / +-Inf input poisons exactly the outputs whose window contains it, in both; the exact kernel yields +-Inf (sign
+        of the weight) for an Inf input, the split kernel NaN (Inf - bf16(Inf) = NaN in the residual splits) -- non-finite
+        either way, everything else bit-identical to the unpoisoned run;
+      * a finite input above the largest bf16 (3.3895e38 < |x| <= FLT_MAX, the top 0.4 % of the fp32 range) rounds to Inf in
+        its high split: non-finite outputs in the split kernel where the exact one may stay finite;
+      * tiny inputs: full accuracy while every split is a normal bf16 (|x| >= 2^-109); below that the low splits flush and
+        the relative accuracy degrades towards the first split's 2^-9 -- the absolute error stays below 2^-126 |w|."""
+    split = _run(dict(JP_P9S="1"), "--edges")
+    exact = _run(dict(JP_P9S="0"), "--edges")
+    print(json.dumps(dict(split=split, exact=exact), indent=1))
+    for k in ("pinf", "ninf", "nan", "over_bf16"):
+        for r in (split[k], exact[k]):
+            assert r["nonfinite_elsewhere"] == 0 and r["elsewhere_bit_identical"], (k, r)
+    for k in ("pinf", "ninf", "nan"):
+        assert split[k]["nonfinite_touched"] == split[k]["n_touched"] == exact[k]["nonfinite_touched"], (k, split[k], exact[k])
+    assert exact["pinf"]["n_posinf"] + exact["pinf"]["n_neginf"] == exact["pinf"]["n_touched"]      # fp32: +-Inf by weight sign
+    assert split["pinf"]["n_nan"] == split["pinf"]["n_touched"]                                     # split: NaN (documented)
+    assert exact["over_bf16"]["nonfinite_touched"] == 0                                             # 3.396e38 * |w| <= 0.1 stays finite
+    assert split["over_bf16"]["nonfinite_touched"] == split["over_bf16"]["n_touched"]               # documented range limit
+    assert split["tiny_2^-100"]["rel_bound"] <= 2.0 ** -19 and exact["tiny_2^-100"]["rel_bound"] <= 2.0 ** -19
+    assert split["tiny_2^-120"]["rel_bound"] <= 2.0 ** -7, split["tiny_2^-120"]
+
+
 if __name__ == "__main__":
     if "--emit" in sys.argv:
         _emit()
+    if "--edges" in sys.argv:
+        _emit_edges()

@@ -15,7 +15,16 @@ GROUPS = [
      + R + "depth_decoder.py:68,76-77).  pad_mode 0=zero 1=reflect; act 0=none 1=relu 2=leaky_relu(0.01) 3=sigmoid.  ws / ws_state: caller scratch for the packed weights "
      "(jp_conv2d_ws_floats) and whether it already holds this layer's pack (1) or must be packed by this call (0); packs recorded with "
      "jp_pack_record_begin/end can be refreshed for the whole model by one jp_pack_replay launch per step (job table in device memory; every job's `begin` is the running sum of the totals rounded up to a multiple of 4, "
-     "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements).",
+     "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements).  "
+     "ARITHMETIC: fp32 in / out / accumulate.  The patch kernels (3x3, 1x1, 7x7 stem, iconv; JP_P9S / JP_W9S / JP_P9US / JP_P9SD / JP_P9S2 / JP_P7S, "
+     "default on) form each fp32 product on the bf16 matrix pipe as 6 bf16 products of exact 3-way bf16 splits of both operands "
+     "(csrc/igemm_p9s.h:33-45): error vs float64 <= the fp32 FMA chain's for finite inputs with 2^-109 <= |x| <= 3.3895e38 (the "
+     "largest bf16).  RANGE EDGES (tests/test_split_accuracy_gpu.py::test_split_range_edges_match_documented_behaviour): a NaN or "
+     "+-Inf input makes exactly the outputs that read it non-finite, as in an fp32 convolution, but an Inf input yields NaN (not "
+     "+-Inf: Inf - bf16(Inf) = NaN in the residual splits); a finite input with |x| > 3.3895e38 (top 0.4 % of the fp32 range) "
+     "rounds to Inf in its high split and is treated like Inf; for |x| < 2^-109 the low splits fall into the bf16 subnormal "
+     "range and flush: relative accuracy degrades towards 2^-9 (absolute error < 2^-126 |w|).  JP_P9S=0 JP_W9S=0 JP_P9US=0 "
+     "JP_P9SD=0 JP_P9S2=0 selects the exact-fp32 MFMA kernels, which have none of these edges.",
      ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
     ("Train-mode BatchNorm2d (+fused residual add / ReLU) — " + R + "resnet.py:21-24,41-45,92; " + R + "layout_model.py:146,152. "
      "ws = jp_bn_ws_doubles(N, C, HW) doubles of caller scratch.  n_updates = number of momentum updates of the running stats (2 for the layout "
