@@ -24,6 +24,7 @@
 //   "G"  generic (channel-major K, per-element decode): whatever the fast paths do not cover.
 #include "igemm_p9.h"
 #include "igemm_p9s.h"
+#include "conv_p9sm.h"
 #include "igemm_w9s.h"
 #include "igemm_p9us.h"
 #include "igemm_p9sd.h"
@@ -2442,6 +2443,19 @@ static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
 
 // floats of caller-owned scratch for the packed-weight fast path (0 = the generic path will be used).
 // which: 0 forward, 1 dgrad, 2 wgrad
+// does the small-map split-bf16 path (conv_p9sm.hip) take this stride-1 3x3 / 1x1 GEMM (rows x red over N x H x W pixels)?
+// JP_P9SM = 1 (default): only what the regular patch kernels reject for their tile shape or grid size (maps that are not
+// multiples of the pixel tile, fewer than 192 workgroups); 2: every eligible layer the patch kernels do not run; 0: off.
+static bool p9sm_wanted(int rows, int red, int N, int H, int W, int KH, int stride, int pad, JpP9smPlan* sm) {
+    static const int mode = [] { const char* e = getenv("JP_P9SM"); return e ? atoi(e) : 1; }();
+    if (!mode || stride != 1 || !((KH == 3 && pad == 1) || (KH == 1 && pad == 0))) return false;
+    if (p9_ok(rows, red, N, H, W, KH * KH)) return false;
+    if (!jp_p9sm_plan(rows, red, N, H, W, KH * KH, sm)) return false;
+    const bool odd_shape = W % 32 != 0 || H % sm->tr != 0;
+    return mode >= 2 || odd_shape || sm->splits > 1 ||
+           (long)jp_cdiv(rows, sm->bmt) * N * jp_cdiv(H, sm->tr) * jp_cdiv(W, 32) < 192;
+}
+
 extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
@@ -2613,6 +2627,19 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             else launch_p9<false, false>(ws, x0, e, Cout, Cin, N, H, W, st);
             JP_LAUNCH_CHECK();
         }
+        {   // small maps (partial tiles, split-K over the channel stages) on the split-bf16 patch kernel (conv_p9sm.hip)
+            JpP9smPlan sm;
+            if (c1 == 0 && c2 == 0 && !up0 && p9sm_wanted(Cout, Cin, N, H, W, KH, stride, pad, &sm) && (sm.splits == 1 || split_ws)) {
+                if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, sm.bmt, KH * KH, st);
+                jp_p9sm_launch(sm, ws, x0, y, bias, act, 0, split_ws, Cout, Cin, N, H, W, KH * KH, pad_mode == JP_PAD_REFLECT, 0, st);
+                if (sm.splits > 1) {
+                    const long total = npix * Cout;
+                    hipLaunchKernelGGL(slice_reduce_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0,
+                                       st, split_ws, y, bias, Cout, (int)npix, OH * OW, sm.splits, act, 0);
+                }
+                JP_LAUNCH_CHECK();
+            }
+        }
         if (!ws_state) pack_weights(w, ws, Cout, Cin, KH * KH, Cp, 0, st);
         PackA a{ws, Cout, Kp, Cp, KH * KH};
         const int sp = small_grid_splits(Cout, npix, Kp);
@@ -2700,7 +2727,9 @@ extern "C" long jp_conv2d_dgrad_split_floats(int N, int Cin, int H, int W, int C
     if (KH == 3 && stride == 2) return 0;          // parity-class path, no split
     // reflection layers (the pad mode is not an argument here: every 3x3 stride-1 pad-1 layer gets it): <= 4 slices of the
     // border pass, part[slice][Cin][N * (2H + 2W)]
-    const long border = (KH == 3 && stride == 1 && pad == 1) ? 4L * Cin * N * (2L * H + 2L * W) : 0;
+    long border = (KH == 3 && stride == 1 && pad == 1) ? 4L * Cin * N * (2L * H + 2L * W) : 0;
+    JpP9smPlan sm;
+    if (p9sm_wanted(Cin, Cout, N, H, W, KH, stride, pad, &sm)) border = std::max(border, sm.part_floats);
     const int sp = small_grid_splits(Cin, npix, Kp);
     if (sp <= 1) return border;
     const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
@@ -2714,10 +2743,12 @@ extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cou
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW;
     const int Kp = KH * KH * pad32(Cin);
+    JpP9smPlan sm;
+    const long smf = p9sm_wanted(Cout, Cin, N, H, W, KH, stride, pad, &sm) ? sm.part_floats : 0;
     const int sp = small_grid_splits(Cout, npix, Kp);
-    if (sp <= 1) return 0;
+    if (sp <= 1) return smf;
     const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
-    return (long)jp_cdiv(Kp, kps) * Cout * npix;
+    return std::max(smf, (long)jp_cdiv(Kp, kps) * Cout * npix);
 }
 
 // reflection border pass of a dgrad (rows of `a` = the C input channels of this call): through caller scratch when there is some
@@ -2811,6 +2842,19 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             launch_auto(a2, b2, e2, Cin, (int)npix, 4 * Cp, 1, 4 * Cp, st);
             JP_LAUNCH_CHECK();
         }
+        JpP9smPlan sm;
+        const int sm_tail = (Cin > 128 && Cin % 128 <= 16) ? Cin % 128 : 0;
+        if (sm_tail == 0 && !(sp <= 1 && p9_only) && p9sm_wanted(Cin, Cout, N, H, W, KH, stride, pad, &sm) && (sm.splits == 1 || split_ws)) {
+            // small maps: main pass on the split-bf16 patch kernel (taps mirrored, zero fill), then the reflection fold as usual
+            float* wfr = ws + dgrad_tap_floats(Cin, Cout, KH);
+            if (!ws_state) pack_p9(w, wfr, Cout, Cin, 1, sm.bmt, KH * KH, st);
+            jp_p9sm_launch(sm, wfr, dy, dx, nullptr, JP_ACT_NONE, accumulate, split_ws, Cin, Cout, N, H, W, KH * KH, 0, 1, st);
+            if (sm.splits > 1) {
+                const long total = npix * Cin;
+                hipLaunchKernelGGL(slice_reduce_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st,
+                                   split_ws, dx, (const float*)nullptr, Cin, (int)npix, H * W, sm.splits, JP_ACT_NONE, accumulate);
+            }
+        } else
         if (sp > 1 && split_ws) {   // small grids: K slices to scratch, fixed-order reduction (no memset, no atomics)
             const int kps = jp_cdiv(jp_cdiv(Kp, sp), KC) * KC;
             WgradEpiWS es{split_ws, Cin, (int)npix};

@@ -58,9 +58,14 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 #define P9S_OCC 2          // waves per SIMD the 4-wave variants are compiled for (3: <= 168 VGPRs, B fragments re-read per row)
 #endif
 // XS = input stride (1x1 only): output pixel (y, x) reads input pixel (XS*y, XS*x) of an (XS*H) x (XS*W) map.
-template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS, int XS>
+// MASK (small maps, igemm_p9sm kernels below): H / W need not be multiples of the tile -- partial tiles stage zeros outside
+// the map and store only pixels inside it -- and the workgroup runs the stage range [s_begin, s_end) of the reduction only
+// (split-K over grid.z for launches whose tile grid cannot fill the chip; partial sums through a slice epilogue).
+template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS, int XS, bool MASK = false>
 __device__ __forceinline__ void jp_igemm_p9s_body(
-    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
+    int s_begin = 0, int s_end = -1) {
+    if (!MASK) { s_begin = 0; s_end = NST; }
     constexpr int NT = 64 * WM * WN;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     static_assert(XS == 1 || TAPS == 1, "strided input: 1x1 only");
@@ -92,7 +97,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             nt = G + i / gy;
         }
     }
-    const int tiles_x = W / 32, tiles_y = H / TR;
+    const int tiles_x = MASK ? (W + 31) / 32 : W / 32, tiles_y = MASK ? (H + TR - 1) / TR : H / TR;
     const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
     const int y0 = (tr_ / tiles_x) * TR, x0 = (tr_ % tiles_x) * 32;
     const int m0 = mt * BMT;
@@ -108,8 +113,10 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         const int e = t + NT * q;
         const int col = e % COLS, rp = e / COLS, pr = rp % PR, kh = rp / PR;
         int yy = y0 - HALO + pr, xx = x0 - HALO + col;
+        // partial tiles: positions beyond the one-pixel ring around the map feed only masked outputs -- zero, never reflected
+        const bool ring = !MASK || (yy <= H && xx <= W);
         if (REFLECT) { yy = jp_reflect(yy, H); xx = jp_reflect(xx, W); }
-        const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const bool ok = e < ITEMS && ring && yy >= 0 && yy < H && xx >= 0 && xx < W;
         soff[q] = ok ? (unsigned)(kh * 8 * HWI + (long)(yy * XS) * (W * XS) + xx * XS) * 4u : 1u;
         loff[q] = e < ITEMS ? (kh * PR + pr) * COLS + col : -1;
     }
@@ -176,7 +183,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #endif
     };
 #pragma unroll
-    for (int d = 0; d < P9S_AHEAD; ++d) aload(d, d * SBYTES);
+    for (int d = 0; d < P9S_AHEAD; ++d) aload(d, (s_begin * STEPS + d) * SBYTES);
     const jp_u32x4* bp = patch + (lhi * PR + wn * NJ) * COLS + l31;
 
 #if P9S_OCC >= 3
@@ -197,7 +204,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         constexpr int PAR = decltype(par_tag)::value;
         lstore();
         __syncthreads();
-        if (stage + 1 < NST) gload(stage + 1);
+        if (stage + 1 < s_end) gload(stage + 1);
         const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
         bload(0, 0);
 #pragma unroll
@@ -238,7 +245,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         constexpr int PAR = decltype(par_tag)::value;
         lstore();
         __syncthreads();
-        if (stage + 1 < NST) gload(stage + 1);              // next stage's patch: in flight during the MFMAs below
+        if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
         const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
         bload(0, 0);
 #pragma unroll
@@ -261,16 +268,17 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     };
 #endif
     static_assert(RING == 2, "two stage parities <-> two ring phases");
-    gload(0);
-    for (int stage = 0; stage < NST; stage += 2) {
+    gload(s_begin);
+    for (int stage = s_begin; stage < s_end; stage += 2) {
         run_stage(std::integral_constant<int, 0>{}, stage);
-        if (stage + 1 < NST) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
+        if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
     }
 #undef JP_P9S_MFMA
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+        if (MASK && (y0 + wn * NJ + j >= H || x0 + l31 >= W)) continue;
         const int p = img * (int)HW + (y0 + wn * NJ + j) * W + x0 + l31;
         const typename Epi::St se = epi.col(p);
 #pragma unroll
@@ -292,6 +300,16 @@ template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, i
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off);
+}
+// small maps (pose encoder 24x80 .. 6x20, BEV 32x32 .. 8x8): masked partial tiles + split-K over grid.z; the epilogue's
+// `slice` member receives blockIdx.z (conv_p9sm.hip)
+template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9sm_kernel(
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int sps) {
+    const int s_begin = blockIdx.z * sps;
+    epi.slice = blockIdx.z;
+    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1, true>(wp, x, epi, M, C, NST, H, W, 0, s_begin,
+                                                                          min(NST, s_begin + sps));
 }
 // 1x1 stride-2 (the ResNet downsample branches): same tiles, the staging gather reads every second input pixel
 template <int WM, int WN, int NJ, class Epi>

@@ -67,6 +67,9 @@ def _split_name(w):
         return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2>"            # narrow twin: two K groups per workgroup
     if w == "jp_wgrad_w1_kernel" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w1s_kernel"
+    if w.startswith("SM<"):                                          # small-map split-bf16 patch kernel (conv_p9sm.hip); JP_P9SM=0 / JP_P9S=0: generic engine
+        on = os.environ.get("JP_P9S", "1") != "0" and os.environ.get("JP_P9SM", "1") != "0"
+        return "jp_igemm_p9sm_kernel<" + w[3:].rstrip(">") if on else "jp_igemm_kernel"
     if w.startswith("STEM<"):                                        # 7x7 stem forward: P7S (igemm_p7s.h) or the generic engine's FwdBC
         on = os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0"
         return f"jp_igemm_p7s_kernel<{w[5]}" if on else ("FwdBC<7, 4>" if w[5] == "3" else "FwdBC<7, 8>")
@@ -131,10 +134,27 @@ BENCH_CONV = [
     ("pose stem 6->64 7x7 stride 2 @192x640 (both pairs stacked: N = 16)", (16, 6, 192, 640, 64, 7, 2, 3, 0, 0, False),
      ["STEM<6>"], [], ["jp_wgrad_w7_kernel<6>"]),
     ("pose encoder layer1 64->64 3x3 @48x160, N = 16", (16, 64, 48, 160, 64, 3, 1, 1, 0, 0, False), ["jp_igemm"], ["jp_igemm"], ["jp_"]),
-    ("pose encoder layer4 512->512 3x3 @6x20, N = 16 (small grid: split K)", (16, 512, 6, 20, 512, 3, 1, 1, 0, 0, False),
-     ["jp_igemm"], ["jp_igemm"], ["jp_"]),
+    # small maps (conv_p9sm.hip, round 4): partial tiles masked, reduction split over grid.z when the tile grid is small
+    ("pose encoder layer2 128->128 3x3 @24x80, N = 16 (W % 32 != 0: masked tiles)", (16, 128, 24, 80, 128, 3, 1, 1, 0, 0, False),
+     ["SM<2, 2, false, false, SmFwdEpi, 9>"], ["SM<2, 2, false, true, SmDgradEpi, 9>"], ["jp_"]),
+    ("pose encoder layer3 256->256 3x3 @12x40, N = 16", (16, 256, 12, 40, 256, 3, 1, 1, 0, 0, False),
+     ["SM<2, 2, false, false, Sm"], ["SM<2, 2, false, true, Sm"], ["jp_"]),
+    ("pose encoder layer4 512->512 3x3 @6x20, N = 16 (small grid: split K, H % 4 != 0)", (16, 512, 6, 20, 512, 3, 1, 1, 0, 0, False),
+     ["SM<2, 2, false, false, SmSliceEpi, 9>"], ["SM<2, 2, false, true, SmSliceEpi, 9>"], ["jp_"]),
+    ("pose decoder squeeze 512->256 1x1 @6x20, N = 16", (16, 512, 6, 20, 256, 1, 1, 0, 0, 1, True),
+     ["SM<2, 2, false, false, SmSliceEpi, 1>"], ["SM<2, 2, false, false, SmSliceEpi, 1>"], ["jp_"]),
     ("BEV decoder 128->64 3x3 @64^2", (8, 128, 64, 64, 64, 3, 1, 1, 0, 0, True), ["jp_igemm"], ["jp_igemm"], ["jp_"]),
-    ("layout encoder conv1 512->128 3x3 reflect @32^2", (8, 512, 32, 32, 128, 3, 1, 1, 1, 0, True), ["jp_igemm"], ["jp_igemm"], ["jp_"]),
+    ("layout encoder conv1 512->128 3x3 reflect @32^2 (64 tiles: split K)", (8, 512, 32, 32, 128, 3, 1, 1, 1, 0, True),
+     ["SM<2, 2, true, false, SmSliceEpi, 9>"], ["jp_igemm_p9"], ["jp_"]),
+    ("layout encoder conv2 128->128 3x3 reflect @16^2 (W < 32)", (8, 128, 16, 16, 128, 3, 1, 1, 1, 0, True),
+     ["SM<2, 2, true, false, SmSliceEpi, 9>"], ["SM<2, 2, false, true, SmSliceEpi, 9>"], ["jp_"]),
+    ("CCT 128->256 3x3 @8x8 (a quarter of a 4x32 tile: stays on the generic engine)", (8, 128, 8, 8, 256, 3, 1, 1, 0, 0, True),
+     ["jp_igemm_kernel"], ["jp_igemm_kernel"], ["jp_"]),
+    ("BEV 256->64 3x3 @32^2 (64-row tiles, 8x32 pixels)", (8, 256, 32, 32, 64, 3, 1, 1, 0, 1, True),
+     ["SM<1, 4, false, false, SmSliceEpi, 9>"], ["SM<2, 2, false, true, Sm"], ["jp_"]),
+    ("CCT value conv 256->256 1x1 @32^2", (8, 256, 32, 32, 256, 1, 1, 0, 0, 0, True), ["SM<2, 2, false, false, Sm"], ["SM<2, 2, false, "], ["jp_"]),
+    ("odd map 64->96 3x3 reflect @13x37, N = 3 (every edge partial; accumulate into dx)", (3, 64, 13, 37, 96, 3, 1, 1, 1, 2, True),
+     ["SM<2, 2, true, false, Sm"], ["SM<1, 4, false, true, Sm"], ["jp_"]),
 ]
 
 

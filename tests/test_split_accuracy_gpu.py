@@ -117,17 +117,22 @@ def _emit_edges():
     import torch.nn.functional as F
     from jperceiver_amd import ops
     from jperceiver_amd.ops import Var, Tape, recording
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     res = {}
     g = torch.Generator().manual_seed(5)
-    N, C, H, W = 2, 128, 32, 32
+    N, C, H, W = 8, 128, 64, 64             # the shape of the accuracy cases above: runs jp_igemm_p9s_kernel / jp_igemm_p9_kernel
     w = torch.randn((C, C, 3, 3), generator=g) * (9 * C) ** -0.5
+    from tests.test_bench_shapes_gpu import kernel_tags
 
     def fwd(x):
         with recording(Tape()):
             return ops.conv2d(Var(x.cuda()), Var(w.cuda()), None, 1, 1, 0, 0).t.cpu()
     x0 = torch.randn((N, C, H, W), generator=g)
-    y0 = fwd(x0)
-    for name, val in (("pinf", float("inf")), ("ninf", float("-inf")), ("nan", float("nan")), ("over_bf16", 3.3961775292304e38)):
+    with kernel_tags() as kt:
+        y0 = fwd(x0)
+    res["kernels"] = sorted(set(kt.names))
+    # 3.40e38: above the rounding threshold to the largest bf16 (0x7F7F8000 = 3.3962e38), below FLT_MAX (3.4028e38)
+    for name, val in (("pinf", float("inf")), ("ninf", float("-inf")), ("nan", float("nan")), ("over_bf16", 3.40e38)):
         x = x0.clone()
         x[1, 7, 10, 20] = val
         y = fwd(x)
@@ -188,6 +193,8 @@ def test_split_range_edges_match_documented_behaviour():
     split = _run(dict(JP_P9S="1"), "--edges")
     exact = _run(dict(JP_P9S="0"), "--edges")
     print(json.dumps(dict(split=split, exact=exact), indent=1))
+    assert any("jp_igemm_p9s_kernel" in k for k in split.pop("kernels")), "the split-bf16 kernel did not run"
+    assert any("jp_igemm_p9_kernel" in k for k in exact.pop("kernels")), "the exact-fp32 kernel did not run"
     for k in ("pinf", "ninf", "nan", "over_bf16"):
         for r in (split[k], exact[k]):
             assert r["nonfinite_elsewhere"] == 0 and r["elsewhere_bit_identical"], (k, r)
