@@ -121,3 +121,41 @@ def run_subpath_oracle(meta, force=None, label=None, dtype=torch.float32):
     total = J.total_loss(L)
     total.backward()
     return dict(P=P, Bf=Bf, out=out, L=L, total=total, opt=opt, inp=inp, masks=masks, noise=noise, state=state)
+
+
+# ---- the gradient referee (one rule for every step-parity test)
+_SPREAD = {}
+
+
+def referee_spread(case="argo_both_1024_b1"):
+    """tools/referee_spread.py: per-parameter distance to float64 of 12 fp32 evaluations of the SAME step that differ only in
+    summation order (thread counts, oneDNN on/off, 8 channel permutations of every convolution), measured on the CPU."""
+    import json
+    if case not in _SPREAD:
+        f = os.path.join(GOLDEN, f"referee_spread_{case}.json")
+        _SPREAD[case] = json.load(open(f))["per_parameter"] if os.path.exists(f) else {}
+    return _SPREAD[case]
+
+
+def referee_ratio():
+    """How much further from float64 one fp32 evaluation of a cancellation-limited gradient can be than another: the largest
+    max/min over the committed draws within the scale-3 decoder group (crp3 / merge3 / disp3 of argo_both_1024_b1, every
+    member >= 2.4 % from float64 in EVERY draw): 2.3."""
+    sp = referee_spread()
+    r = [v["max"] / v["min"] for n, v in sp.items()
+         if n.startswith(("DepthDecoder.crp3", "DepthDecoder.merge3", "DepthDecoder.disp3")) and v["min"] >= 2e-2]
+    return max(r) if r else 1.05
+
+
+def referee_bound(name, ec, case=None):
+    """Largest relative distance to the float64 oracle a device gradient may have once it missed the 2 % band around the fp32
+    oracle.  The device step is ONE MORE fp32 evaluation (its convolutions round in another order: MFMA tile order, split
+    products); it has to lie inside the envelope of fp32 evaluations --
+      * with a committed spread for this case and parameter: 1.1 x the worst of the committed draws and of today's oracle run
+        (`ec`, itself one draw);
+      * otherwise: today's oracle distance times the measured draw-to-draw ratio (`referee_ratio`).
+    Never below the 2 % band itself."""
+    sp = referee_spread(case) if case else {}
+    if name in sp:
+        return max(2e-2, 1.1 * max(ec, sp[name]["max"]))
+    return max(2e-2, referee_ratio() * ec)

@@ -17,7 +17,7 @@ from jperceiver_amd import synthetic as syn                                    #
 from jperceiver_amd.model import MONO                                          # noqa: E402
 from jperceiver_amd.apis import batch_processor, build_optimizer, Runner       # noqa: E402
 from jperceiver_amd.core import DistOptimizerHook                              # noqa: E402
-from tests.golden_util import load_case, case_inputs, oracle_opt, run_oracle, run_oracle_f64   # noqa: E402
+from tests.golden_util import load_case, case_inputs, oracle_opt, run_oracle, run_oracle_f64, referee_bound   # noqa: E402
 from oracle import jp_oracle as J                                              # noqa: E402
 
 
@@ -140,23 +140,23 @@ def test_train_step_matches_reference_and_oracle(case):
         if err > tol * rn + floor:
             bad.append((n, err, rn))
     if bad:
-        # Referee: some gradients are cancellation-limited in fp32 (at 1024^2 the scale-3 decoder group of the fp32
-        # CPU oracle itself sits 3-4 % from exact arithmetic, tools/debug_f64.py).  For the parameters that miss
-        # the 2 % band, require the HIP gradient to be as close to the float64 oracle as ANOTHER fp32 evaluation can be expected
-        # to be: the fp32 oracle's own distance is one draw of that rounding noise, the HIP step -- whose convolutions round
-        # differently (MFMA tile order, split-bf16 products: error vs float64 <= an fmaf chain's, test_split_accuracy_gpu.py) --
-        # is another draw.  Measured on argo_both_1024_b1, scale-3 decoder group (crp3 / merge3 / disp3): fp32 oracle 2.8-4.2 %,
-        # HIP 4.2-6.8 % with the split-bf16 stem kernel, < 2 % of the fp32 oracle (same rounding trajectory through the
-        # max-pool / ReLU / arg-min decisions) with the exact-fp32 stem (JP_P7S=0).  Bound: twice the fp32 oracle's distance.
+        # Referee: some gradients are cancellation-limited in fp32 -- at 1024^2 the scale-3 decoder group of an fp32 evaluation
+        # sits 2.4-7.2 % from exact arithmetic depending on nothing but its summation order (tools/referee_spread.py: 12 fp32 CPU
+        # draws of this very step, tests/golden/referee_spread_argo_both_1024_b1.json; crp3 2.8-6.3 %, merge3.bias 3.5-7.2 %,
+        # disp3 3.2-7.2 %).  The device step is one more draw (MFMA tile order, split-bf16 products: error vs float64 <= an
+        # fmaf chain's, test_split_accuracy_gpu.py): a parameter that misses the 2 % band around the fp32 oracle must lie inside
+        # the envelope of those draws around the FLOAT64 oracle (tests/golden_util.py::referee_bound, the same rule in
+        # test_config_steps_gpu.py and test_subpath_320x1024_gpu.py).
         g64 = run_oracle_f64(meta, force, label)
         worse = []
         for n, err, rn in bad:
             r64 = g64[n]
             eh = float((dict(model.named_parameters())[n].grad.detach().cpu().double() - r64).norm() / (r64.norm() + 1e-30))
             ec = float((ora2["P"][n].grad.double() - r64).norm() / (r64.norm() + 1e-30))
-            if eh > max(2e-2, 2.0 * ec):
-                worse.append((n, eh, ec))
-        assert not worse, f"gradients further from the float64 oracle than the fp32 oracle is (name, hip, cpu32): {worse[:8]}"
+            print(f"referee {case} {n}: hip {eh:.4f} fp32-oracle {ec:.4f} bound {referee_bound(n, ec, case):.4f}")
+            if eh > referee_bound(n, ec, case):
+                worse.append((n, eh, ec, referee_bound(n, ec, case)))
+        assert not worse, f"gradients outside the envelope of fp32 evaluations around the float64 oracle (name, hip, cpu32, bound): {worse[:8]}"
     ora = ora2
 
     # ---- BN buffers incl. the double update of the duplicated layout call (N4)

@@ -33,6 +33,27 @@ CASES = [
     ("pose layer1 64->64 3x3 @48x160 (N = 16)", 16, 64, 48, 160, 64, 3, 1, 1, 0),
     ("layer2.0 64->128 3x3 stride 2 @256^2", 8, 64, 256, 256, 128, 3, 2, 1, 0),
     ("stem 3->64 7x7 stride 2 @1024^2", 8, 3, 1024, 1024, 64, 7, 2, 3, 0),
+    # small maps of the step (conv_p9sm.hip; A/B with JP_P9SM=0 / 1 / 2)
+    ("small: pose layer2 128->128 3x3 @24x80 N16", 16, 128, 24, 80, 128, 3, 1, 1, 0),
+    ("small: pose layer3 256->256 3x3 @12x40 N16", 16, 256, 12, 40, 256, 3, 1, 1, 0),
+    ("small: pose layer4 512->512 3x3 @6x20 N16", 16, 512, 6, 20, 512, 3, 1, 1, 0),
+    ("small: pose squeeze 512->256 1x1 @6x20 N16", 16, 512, 6, 20, 256, 1, 1, 0, 0),
+    ("small: pose 256->256 3x3 @6x20 N16", 16, 256, 6, 20, 256, 3, 1, 1, 0),
+    ("small: layout conv1 512->128 3x3 refl @32^2", 8, 512, 32, 32, 128, 3, 1, 1, 1),
+    ("small: 512->256 3x3 refl @32^2", 8, 512, 32, 32, 256, 3, 1, 1, 1),
+    ("small: 256->256 3x3 refl @32^2", 8, 256, 32, 32, 256, 3, 1, 1, 1),
+    ("small: 128->128 3x3 refl @16^2", 8, 128, 16, 16, 128, 3, 1, 1, 1),
+    ("small: 256->128 3x3 @16^2", 8, 256, 16, 16, 128, 3, 1, 1, 0),
+    ("small: 128->64 3x3 @32^2", 8, 128, 32, 32, 64, 3, 1, 1, 0),
+    ("small: 64->32 3x3 @64^2", 8, 64, 64, 64, 32, 3, 1, 1, 0),
+    ("small: 128->256 3x3 @8^2", 8, 128, 8, 8, 256, 3, 1, 1, 0),
+    ("small: 256->256 1x1 @32^2", 8, 256, 32, 32, 256, 1, 1, 0, 0),
+    ("small: 128->128 1x1 @8^2", 8, 128, 8, 8, 128, 1, 1, 0, 0),
+    # 1x1 layers the patch kernels leave to the generic engine (JP_P9SM=2 takes them)
+    ("mode2: reduce 64->256 1x1 @256^2", 8, 64, 256, 256, 256, 1, 1, 0, 0),
+    ("mode2: reduce 128->256 1x1 @128^2", 8, 128, 128, 128, 256, 1, 1, 0, 0),
+    ("mode2: reduce 256->256 1x1 @64^2", 8, 256, 64, 64, 256, 1, 1, 0, 0),
+    ("mode2: 512->256 1x1 @32^2", 8, 512, 32, 32, 256, 1, 1, 0, 0),
 ]
 
 
@@ -123,7 +144,7 @@ if __name__ == "__main__":
     ap.add_argument("--acc", action="store_true")
     ap.add_argument("--only", type=str, default="")
     a = ap.parse_args()
-    print("JP_P9S =", os.environ.get("JP_P9S", "(default)"))
+    print("JP_P9S =", os.environ.get("JP_P9S", "(default)"), " JP_P9SM =", os.environ.get("JP_P9SM", "(default)"))
     if a.acc:
         accuracy()
     for c in CASES:
