@@ -117,7 +117,7 @@ def cpu_baseline(HW, cfg, seconds_budget=30.0):
                        f"loss_sum {cfg['loss_sum']} (the GPU workload's flags), {ms:.2f} s/step")
 
 
-def build_runner(optd, dev, world, rank, batch_kw):
+def build_runner(optd, dev, world, rank, batch_kw, step_graph=False):
     from jperceiver_amd import synthetic as syn
     from jperceiver_amd.model import MONO
     from jperceiver_amd.apis import batch_processor, build_optimizer, Runner, DataParallelShell, change_input_variable
@@ -128,7 +128,7 @@ def build_runner(optd, dev, world, rank, batch_kw):
     optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
     wrapped = DataParallelShell(model) if world > 1 else model
     hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
-    runner = Runner(wrapped, batch_processor, optim, hook)
+    runner = Runner(wrapped, batch_processor, optim, hook, step_graph=step_graph)
     # per-rank shard of the synthetic "dataset"; resident in HBM before timing starts
     batch = syn.make_batch(rank=rank, **batch_kw)
     batch = change_input_variable(batch, device=dev, opt=model.opt)
@@ -207,6 +207,9 @@ def main():
                     help="index into BASELINE.json `configs` (default 1 = the headline workload)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's, BASELINE.json)")
     ap.add_argument("--hw", type=int, default=1024)
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the whole iteration from one captured hipGraph (apis.trainer.CapturedStep); auto = on for "
+                         "single-process runs with <= 2 images per GPU (the B = 1 configs, host-bound when issued launch by launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -241,9 +244,12 @@ def main():
     cfg = CONFIGS[args.config]
     B, HW, frames = (args.batch or cfg["B"]), args.hw, cfg["frames"]
     optd = make_opt(B, HW, HW, frames, cfg["type"], cfg["split"], loss_sum=cfg["loss_sum"], **cfg.get("extra", {}))
+    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and B <= 2))
     runner, batch = build_runner(optd, dev, world, rank,
                                  dict(B=B, height=HW, width=HW, frame_ids=frames, occ=HW // 4, full_hw=cfg["full_hw"],
-                                      split=cfg["split"], seed=1))
+                                      split=cfg["split"], seed=1), step_graph=use_graph)
+    if use_graph and args.warmup < 3:
+        log("note: the captured step needs 2 eager iterations + the capture itself: --warmup < 3 puts them inside the timed region")
     dt, out, multi = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
@@ -260,6 +266,7 @@ def main():
     roof, fam, cpu, sec = None, None, None, None
     if not args.no_roofline:
         # every rank runs the instrumented step (it contains the gradient all-reduce); rank 0 reports
+        runner.step_graph = False          # the instrumented step is issued launch by launch (HIP events around each)
         roof, fam = measure_roofline(runner, batch, B, ms * 1e-3, rank)
         log(f"roofline: {json.dumps(roof)}")
     if world > 1:
@@ -283,7 +290,8 @@ def main():
             "config": {"workload": f"{cfg['name']}: {HW}x{HW}, frames {frames}, {B} images/GPU, type {cfg['type']}, "
                                    f"loss_sum {cfg['loss_sum']}, occ {HW // 4}, full-res frame {cfg['full_hw'][0]}x{cfg['full_hw'][1]}",
                        "config_index": args.config, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "loss": float(out["log_vars"]["loss"])},
+                       "parallelism": f"dp{world}", "loss": float(out["log_vars"]["loss"]),
+                       "step_graph": bool(use_graph)},
             "roofline": roof, "cpu_baseline": cpu, "families": fam, "secondary": sec,
         }
         if multi is not None:

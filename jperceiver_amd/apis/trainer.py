@@ -107,6 +107,134 @@ def batch_processor(model, data, train_mode):
     return dict(loss=loss, log_vars=log_vars, num_samples=len(data[("color", 0, 0)]))
 
 
+class CapturedStep:
+    """One whole training iteration -- batch_processor's forward, the loss sum, DistOptimizerHook's zero_grad / backward /
+    clip + Adam and the weight re-pack -- captured ONCE into a hipGraph and replayed per batch.
+
+    Why: the step's launch sequence is static per input signature (own tape, no host sync inside the step, `ops.py`), and at
+    one image per GPU (BASELINE.json configs[0] and [4]) its ~1 500 kernels are shorter than the ~16 us the host needs to
+    issue each of them through Python + ctypes: the eager B = 1 step is host-bound at 25-31 ms.  Replay costs one launch.
+
+    How: inputs are copied into static device buffers; everything that changes from step to step and used to be a kernel
+    ARGUMENT lives in device memory the host refreshes before a replay with one small H2D copy each --
+      * Adam's lr and bias corrections (`jp_adam_clip_step_dev`, runtime.FlatArena.dev_state),
+      * the seed base of the step's Dropout / automask-noise draws (`jp_rng_*_dev`, ops.rng_capture): a replay draws exactly
+        what the eager step would have drawn --
+    and the host-side counters the eager step advances (Adam step, RNG counter, BatchNorm `num_batches_tracked`, the pack
+    registry's weight epoch) are advanced per replay.  The first `WARMUP` iterations run eagerly on the same static buffers
+    (they are real training steps: packs are recorded, scratch and optimizer state are allocated); the graph is captured at
+    the next call and re-captured when the batch signature (keys, shapes, dtypes) changes.  Single process only: RCCL work
+    handles are not captured (world > 1 keeps the eager, overlapped exchange)."""
+    WARMUP = 2
+
+    def __init__(self, runner):
+        from ..runtime import FlatAdam
+        self.r = runner
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("CapturedStep: single-process steps only (the bucketed RCCL exchange runs eagerly)")
+        if not isinstance(runner.optimizer, FlatAdam):
+            raise RuntimeError("CapturedStep needs the flat-arena optimizer (apis.build_optimizer)")
+        if runner.batch_processor is not batch_processor:
+            raise RuntimeError("CapturedStep replays the stock batch_processor")
+        self.m = getattr(runner.model, "module", runner.model)
+        self.sig, self.static, self.graph, self.eager_done = None, None, None, 0
+        self.replays = 0
+
+    # ---- inputs
+    def _prepare(self, data):
+        """device fp32 batch (change_input_variable) with the scale-label homographies present: they are host algebra on the
+        calibration, which must not happen inside the captured region"""
+        data = change_input_variable(dict(data), opt=self.m.opt)
+        if ("scale_H", 0, 0) not in data and ("odometry_K", 0, 0) in data:
+            FH, FW = data[("color", 0, -1)].shape[2:4]
+            Hm, quad = scale_label_matrices(self.m.opt, data[("odometry_K", 0, 0)].float().cpu(),
+                                            data[("Tr_cam2_velo", 0, 0)].float().cpu(), FH, FW)
+            dev = data[("color", 0, 0)].device
+            data[("scale_H", 0, 0)], data[("scale_quad", 0, 0)] = Hm.to(dev), quad.to(device=dev, dtype=torch.int32)
+        return data
+
+    @staticmethod
+    def _signature(data):
+        return tuple(sorted((repr(k), tuple(v.shape), str(v.dtype)) for k, v in data.items() if torch.is_tensor(v)))
+
+    def _load(self, data):
+        sig = self._signature(data)
+        if sig != self.sig:            # new input signature: fresh static buffers, eager warm-up, new capture
+            self.sig, self.graph, self.eager_done = sig, None, 0
+            self.static = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+            return
+        for k, v in data.items():
+            if torch.is_tensor(v) and v.data_ptr() != self.static[k].data_ptr():
+                self.static[k].copy_(v, non_blocking=True)
+
+    # ---- the iteration body (what train_iter does between its hooks)
+    def _body(self):
+        r = self.r
+        model_out, losses = r.model(dict(self.static))
+        loss = losses.total()
+        r.outputs = dict(loss=loss, log_vars=None, num_samples=len(self.static[("color", 0, 0)]))
+        r.hook.after_train_iter(r)
+        return model_out, losses, loss
+
+    def _finish(self, losses, loss, model_out):
+        log_vars = LazyLogVars(losses._lv.names, losses._lv.vals)      # async D2H + event, OUTSIDE the captured region
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(self.static[("color", 0, 0)]), model_out=model_out)
+
+    def _bn_modules(self):
+        return [mod for mod in self.m.modules() if hasattr(mod, "_pending")]
+
+    def _capture(self):
+        from .. import ops
+        opt, arena = self.r.optimizer, self.r.optimizer.arena
+        dev = arena.params.device
+        self.state_host = torch.empty(3, dtype=torch.float32).pin_memory()
+        self.base_host = torch.empty(1, dtype=torch.int64).pin_memory()
+        self.state_dev = torch.zeros(3, device=dev, dtype=torch.float32)
+        self.base_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        bns = self._bn_modules()
+        saved = (arena.step_count, ops._EPOCH[0], [b._pending for b in bns])
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        arena.dev_state = self.state_dev
+        try:
+            with ops.rng_capture(self.base_dev) as cap, torch.cuda.graph(self.graph):
+                self.model_out, self.losses, self.loss = self._body()
+        finally:
+            arena.dev_state = None
+        self.rng_calls = cap.calls
+        self.bn_delta = [(b, b._pending - p0) for b, p0 in zip(bns, saved[2])]
+        # the capture executed nothing: take the host-side counters back
+        arena.step_count, ops._EPOCH[0] = saved[0], saved[1]
+        for b, p0 in zip(bns, saved[2]):
+            b._pending = p0
+
+    def step(self, data_batch):
+        from .. import ops
+        from ..runtime import FlatArena
+        r = self.r
+        self._load(self._prepare(data_batch))
+        if self.eager_done < self.WARMUP:                                # real steps, issued launch by launch
+            self.eager_done += 1
+            model_out, losses, loss = self._body()
+            return self._finish(losses, loss, model_out)
+        if self.graph is None:
+            self._capture()
+        opt, arena = r.optimizer, r.optimizer.arena
+        g = opt.param_groups[0]
+        arena.step_count += 1
+        self.state_host.copy_(torch.from_numpy(FlatArena.step_state(g["lr"], g["betas"], arena.step_count)))
+        self.base_host[0] = ops.rng_step_base()
+        self.state_dev.copy_(self.state_host, non_blocking=True)
+        self.base_dev.copy_(self.base_host, non_blocking=True)
+        self.graph.replay()
+        ops.rng_advance(self.rng_calls)
+        for b, d in self.bn_delta:
+            b._pending += d
+        ops.weights_changed()
+        self.replays += 1
+        return self._finish(self.losses, self.loss, self.model_out)
+
+
 def build_optimizer(model, optimizer_cfg):
     """trainer.py:76-143 for the configs' `dict(type='Adam', lr=1e-4, weight_decay=0)`; returns the flat-arena
     Adam and attaches the arena to the model for allreduce_grads / DistOptimizerHook."""
@@ -211,10 +339,17 @@ class Runner(object):
     step-policy learning-rate hook, and checkpoints in mmcv's layout (save / load / resume)."""
 
     def __init__(self, model, batch_processor, optimizer, optimizer_hook, lr_config=None, work_dir=None,
-                 checkpoint_config=None):
+                 checkpoint_config=None, step_graph=None):
         """`checkpoint_config` = the configs' `dict(interval=1)` (mmcv CheckpointHook): `train_epoch` then saves from its
-        after-train-epoch point, i.e. BEFORE the epoch counter is incremented, exactly where mmcv's hook runs."""
+        after-train-epoch point, i.e. BEFORE the epoch counter is incremented, exactly where mmcv's hook runs.
+        `step_graph` (not a reference option): replay the whole iteration from ONE captured hipGraph (`CapturedStep`) -- for
+        the B = 1 configs, whose ~1 500 launches per step are host-bound when issued one by one.  None = $JP_STEP_GRAPH
+        (default off)."""
         self.model, self.batch_processor, self.optimizer, self.hook = model, batch_processor, optimizer, optimizer_hook
+        if step_graph is None:
+            step_graph = os.environ.get("JP_STEP_GRAPH", "0") not in ("0", "")
+        self.step_graph = bool(step_graph)
+        self.captured = None
         self.outputs = None
         self.iter = 0
         self.epoch = 0
@@ -233,6 +368,17 @@ class Runner(object):
         self.model.train()
         if self.lr_hook is not None:
             self.lr_hook.before_train_iter(self)
+        if self.step_graph:
+            if self.captured is None:
+                self.captured = CapturedStep(self)
+            self.outputs = self.captured.step(data_batch)
+            lv = self.outputs["log_vars"]
+            if isinstance(lv, LazyLogVars):
+                lv._resolve()
+            for h in self.after_train_iter_hooks:
+                h(self)
+            self.iter += 1
+            return self.outputs
         self.outputs = self.batch_processor(self.model, data_batch, train_mode=True)
         self.hook.after_train_iter(self)
         lv = self.outputs.get("log_vars") if isinstance(self.outputs, dict) else None

@@ -2444,10 +2444,12 @@ static inline bool small_head(int Cin, int Cout, int KH, int stride, int pad) {
 // floats of caller-owned scratch for the packed-weight fast path (0 = the generic path will be used).
 // which: 0 forward, 1 dgrad, 2 wgrad
 // does the small-map split-bf16 path (conv_p9sm.hip) take this stride-1 3x3 / 1x1 GEMM (rows x red over N x H x W pixels)?
-// JP_P9SM = 1 (default): only what the regular patch kernels reject for their tile shape or grid size (maps that are not
-// multiples of the pixel tile, fewer than 192 workgroups); 2: every eligible layer the patch kernels do not run; 0: off.
+// JP_P9SM = 2 (default): every eligible layer the regular patch kernels do not run (also the 1x1 layers with 64 / 128-row
+// banks, which those leave to the generic engine: reduce 128->256 @128^2 dgrad 0.116 -> 0.066 ms, 64->256 @256^2 0.217 -> 0.187);
+// 1: only what they reject for their tile shape or grid size (maps that are not multiples of the pixel tile, < 192 workgroups);
+// 0: off.
 static bool p9sm_wanted(int rows, int red, int N, int H, int W, int KH, int stride, int pad, JpP9smPlan* sm) {
-    static const int mode = [] { const char* e = getenv("JP_P9SM"); return e ? atoi(e) : 1; }();
+    static const int mode = [] { const char* e = getenv("JP_P9SM"); return e ? atoi(e) : 2; }();
     if (!mode || stride != 1 || !((KH == 3 && pad == 1) || (KH == 1 && pad == 0))) return false;
     if (p9_ok(rows, red, N, H, W, KH * KH)) return false;
     if (!jp_p9sm_plan(rows, red, N, H, W, KH * KH, sm)) return false;

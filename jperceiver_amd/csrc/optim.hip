@@ -50,7 +50,8 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const double* __restrict__ normsq, float grad_scale,
                                                    float max_norm, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2) {
+                                                   float bc1, float bc2, const float* __restrict__ state) {
+    if (state) { lr = state[0]; bc1 = state[1]; bc2 = state[2]; }      // captured step: this step's scalars live in device memory
     float coef = grad_scale;
     if (normsq && max_norm > 0.f) {
         const float nrm = (float)sqrt(*normsq) * grad_scale;
@@ -90,7 +91,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 }
 
 // keep-mask in {0,1}: P(keep) = 1-p
-__global__ __launch_bounds__(TPB) void rng_mask_kernel(float* __restrict__ out, long n, uint64_t seed, float p) {
+__global__ __launch_bounds__(TPB) void rng_mask_kernel(float* __restrict__ out, long n, uint64_t seed, float p,
+                                                       const long* __restrict__ base) {
+    if (base) seed += (uint64_t)base[0];            // captured step: seed = this step's base (device memory) + the call's offset
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
         const uint64_t h = mix64((uint64_t)i ^ mix64(seed));
         const float u = (float)(h >> 40) * (1.f / 16777216.f);
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(TPB) void rng_mask_kernel(float* __restrict__ out, 
     }
 }
 
-__global__ __launch_bounds__(TPB) void rng_normal_kernel(float* __restrict__ out, long n, uint64_t seed) {
+__global__ __launch_bounds__(TPB) void rng_normal_kernel(float* __restrict__ out, long n, uint64_t seed,
+                                                         const long* __restrict__ base) {
+    if (base) seed += (uint64_t)base[0];
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
         const uint64_t h1 = mix64((uint64_t)i ^ mix64(seed));
         const uint64_t h2 = mix64(h1 ^ 0xD1B54A32D192ED03ULL);
@@ -145,21 +150,52 @@ extern "C" int jp_adam_clip_step(float* p, const float* g, float* m, float* v, l
     // bias corrections in double on the host, as torch.optim.Adam does with python floats
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, p, g, m, v, n, normsq, grad_scale, max_norm,
-                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)bc1, (float)bc2);
+                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)bc1, (float)bc2, (const float*)nullptr);
+    JP_LAUNCH_CHECK();
+}
+
+// The same pass with the step's scalars read from DEVICE memory: state = {lr, 1 - beta1^step, 1 - beta2^step} (fp32, the
+// values jp_adam_clip_step derives on the host).  Nothing that changes from step to step is a kernel argument, so the launch
+// can sit in a captured hipGraph of the whole training step (apis/trainer.py CapturedStep); the host refreshes `state` with
+// one small H2D copy before each replay.
+extern "C" int jp_adam_clip_step_dev(float* p, const float* g, float* m, float* v, long n, const double* normsq,
+                                     float grad_scale, float max_norm, double beta1, double beta2, double eps,
+                                     const float* state, void* stream) {
+    JP_CHECK_ARG(p && g && m && v && state && n > 0, "adam_clip_step_dev: bad args");
+    JP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_clip_step_dev: arenas must be 16-B aligned");
+    JP_ST;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, p, g, m, v, n, normsq, grad_scale, max_norm,
+                       0.f, (float)beta1, (float)beta2, (float)eps, 1.f, 1.f, state);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_rng_keep_mask(float* out, long n, uint64_t seed, float p_drop, void* stream) {
     JP_CHECK_ARG(out && n > 0, "rng_keep_mask: bad args");
     JP_ST;
-    hipLaunchKernelGGL(rng_mask_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, out, n, seed, p_drop);
+    hipLaunchKernelGGL(rng_mask_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, out, n, seed, p_drop, (const long*)nullptr);
+    JP_LAUNCH_CHECK();
+}
+
+// seed = base[0] + offset (mod 2^64), base in device memory: the captured-step forms of the two generators (same streams as
+// jp_rng_keep_mask / jp_rng_normal called with that seed)
+extern "C" int jp_rng_keep_mask_dev(float* out, long n, const long* base, long offset, float p_drop, void* stream) {
+    JP_CHECK_ARG(out && base && n > 0, "rng_keep_mask_dev: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(rng_mask_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, out, n, (uint64_t)offset, p_drop, base);
+    JP_LAUNCH_CHECK();
+}
+
+extern "C" int jp_rng_normal_dev(float* out, long n, const long* base, long offset, void* stream) {
+    JP_CHECK_ARG(out && base && n > 0, "rng_normal_dev: bad args");
+    JP_ST;
+    hipLaunchKernelGGL(rng_normal_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, out, n, (uint64_t)offset, base);
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_rng_normal(float* out, long n, uint64_t seed, void* stream) {
     JP_CHECK_ARG(out && n > 0, "rng_normal: bad args");
     JP_ST;
-    hipLaunchKernelGGL(rng_normal_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, out, n, seed);
+    hipLaunchKernelGGL(rng_normal_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, out, n, seed, (const long*)nullptr);
     JP_LAUNCH_CHECK();
 }
 

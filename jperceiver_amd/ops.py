@@ -760,7 +760,8 @@ def softmax2(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------- RNG
-_RNG_STATE = {"seed": 0x5EED, "ctr": 0}
+_RNG_STATE = {"seed": 0x5EED, "ctr": 0, "dev": None}
+_RNG_A, _RNG_B, _M64 = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03, 0xFFFFFFFFFFFFFFFF
 
 
 def manual_seed(seed: int):
@@ -769,18 +770,61 @@ def manual_seed(seed: int):
 
 def _next_seed():
     _RNG_STATE["ctr"] += 1
-    return (_RNG_STATE["seed"] * 0x9E3779B97F4A7C15 + _RNG_STATE["ctr"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return (_RNG_STATE["seed"] * _RNG_A + _RNG_STATE["ctr"] * _RNG_B) & _M64
+
+
+def _i64(u: int) -> int:
+    """uint64 -> the int64 with the same bits (the ABI passes the *_dev offsets / bases as `long`)"""
+    u &= _M64
+    return u - (1 << 64) if u >> 63 else u
+
+
+def rng_step_base() -> int:
+    """seed of call k (1-based) of the step that starts now = rng_step_base() + k * B (mod 2^64): what a captured step keeps
+    in device memory (`rng_capture`), so that a replay draws exactly what the eager step would have drawn."""
+    return _i64(_RNG_STATE["seed"] * _RNG_A + _RNG_STATE["ctr"] * _RNG_B)
+
+
+class rng_capture:
+    """While active (a training step is being captured into a hipGraph), keep_mask / randn launch the *_dev generators: the
+    step's seed base is read from `base` (a 1-element int64 device tensor the host refreshes before every replay), the call's
+    position in the step is a constant of the captured launch.  `.calls` = generator calls per step afterwards."""
+
+    def __init__(self, base: torch.Tensor):
+        self.base, self.calls = base, 0
+
+    def __enter__(self):
+        _RNG_STATE["dev"] = self
+        return self
+
+    def __exit__(self, *a):
+        _RNG_STATE["dev"] = None
+
+
+def rng_advance(calls: int):
+    """account for the generator calls of one replayed step"""
+    _RNG_STATE["ctr"] += int(calls)
 
 
 def keep_mask(shape, device, p_drop=0.5) -> torch.Tensor:
     """Bernoulli(1-p) keep-mask from the counter-based device RNG (train-mode nn.Dropout, depth_decoder.py:13)."""
     m = torch.empty(tuple(shape), device=device, dtype=torch.float32)
-    call("jp_rng_keep_mask", m, m.numel(), _next_seed(), float(p_drop))
+    cap = _RNG_STATE["dev"]
+    if cap is not None:
+        cap.calls += 1
+        call("jp_rng_keep_mask_dev", m, m.numel(), cap.base, _i64(cap.calls * _RNG_B), float(p_drop))
+    else:
+        call("jp_rng_keep_mask", m, m.numel(), _next_seed(), float(p_drop))
     return m
 
 
 def randn(shape, device) -> torch.Tensor:
     """Standard-normal noise from the device RNG (automask tie-breaking noise, net.py:163)."""
     m = torch.empty(tuple(shape), device=device, dtype=torch.float32)
-    call("jp_rng_normal", m, m.numel(), _next_seed())
+    cap = _RNG_STATE["dev"]
+    if cap is not None:
+        cap.calls += 1
+        call("jp_rng_normal_dev", m, m.numel(), cap.base, _i64(cap.calls * _RNG_B))
+    else:
+        call("jp_rng_normal", m, m.numel(), _next_seed())
     return m

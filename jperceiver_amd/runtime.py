@@ -86,6 +86,7 @@ class FlatArena:
         self._partials = torch.zeros(64 * self._nblk, device=dev, dtype=torch.float64)   # grown on demand (small buckets)
         self._n_partials = 0
         self.step_count = 0
+        self.dev_state = None      # 3-float device tensor while a captured step owns the optimizer scalars
 
     def zero_grad(self):
         # memset node on the current stream; keeps p.grad views alive (no reallocation)
@@ -121,9 +122,21 @@ class FlatArena:
         if max_norm is not None and max_norm > 0:
             normsq = self.grad_norm_sq()
         self._n_partials = 0
+        if self.dev_state is not None:
+            # captured step (apis/trainer.py CapturedStep): lr and the bias corrections come from device memory, refreshed by
+            # the host before every replay (`step_state`) -- nothing step-dependent is a kernel argument
+            call("jp_adam_clip_step_dev", self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.live_numel, normsq,
+                 float(grad_scale), float(max_norm or 0.0), float(betas[0]), float(betas[1]), float(eps), self.dev_state)
+            return
         call("jp_adam_clip_step", self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.live_numel, normsq,
              float(grad_scale), float(max_norm or 0.0), float(lr), float(betas[0]), float(betas[1]), float(eps),
              self.step_count)
+
+    @staticmethod
+    def step_state(lr, betas, step):
+        """[lr, 1 - beta1^step, 1 - beta2^step] as fp32: the scalars jp_adam_clip_step derives on the host for step `step`"""
+        import numpy as np
+        return np.array([lr, 1.0 - betas[0] ** step, 1.0 - betas[1] ** step], dtype=np.float64).astype(np.float32)
 
     def layout(self):
         return [(n, o, k) for n, _, o, k in self.entries]

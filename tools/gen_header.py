@@ -55,7 +55,8 @@ GROUPS = [
     ("Optimizer over flat arenas + RNG — clip_grads(max_norm=35)+Adam mono/core/utils/dist_utils.py:58-60, "
      "config/cfg_kitti_baseline_odometry_boundary_ce_iou_1024_20.py:69-70; Dropout / randn " + R + "depth_decoder.py:13, "
      + R + "net.py:163.",
-     ["jp_sumsq_blocks", "jp_grad_sumsq_partials", "jp_sum_doubles", "jp_adam_clip_step", "jp_rng_keep_mask", "jp_rng_normal"]),
+     ["jp_sumsq_blocks", "jp_grad_sumsq_partials", "jp_sum_doubles", "jp_adam_clip_step", "jp_adam_clip_step_dev", "jp_rng_keep_mask",
+      "jp_rng_normal", "jp_rng_keep_mask_dev", "jp_rng_normal_dev"]),
     ("Evaluation metrics as GPU reductions — mean_IU / mean_precision mono/core/evaluation/pixel_error.py:59-118 (confusion counts "
      "of argmax(logits) vs label); depth compute_errors + median scaling + Garg crop mono/core/evaluation/pixel_error.py:27-40, "
      "mono/core/evaluation/eval_hooks.py:147-179.",
