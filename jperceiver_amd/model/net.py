@@ -62,6 +62,7 @@ class _StepFn(torch.autograd.Function):
         dvec = dvec.contiguous()
         call("jp_axpby", dvec, None, ctx.lv.grads, dvec.numel(), 1.0, 0.0)
         ops._WG_ACTIVE[0] = True
+        ops._WG_MAIN[0] = torch.cuda.current_stream(ctx.lv.vals.device).cuda_stream
         try:
             ctx.tape.backward()
         finally:
@@ -70,6 +71,7 @@ class _StepFn(torch.autograd.Function):
         side = getattr(ctx.tape, "side_stream", None)
         if side is not None:       # the pose branch's backward ran on its own stream: rejoin before the optimizer
             torch.cuda.current_stream(ctx.lv.vals.device).wait_stream(side)
+        ops.join_deferred_param_grad_streams()
         return None, None, None
 
 

@@ -106,6 +106,9 @@ import os as _os
 _WG_ON = _os.environ.get("JP_WGRAD_STREAM", "1") != "0"
 _WG_STREAMS = {}
 _WG_ACTIVE = [False]
+_WG_MAIN_ONLY = _os.environ.get("JP_WGRAD_SIDE", "1") == "0"     # companion stream for the main stream's backward only
+_WG_MAIN = [None]                                                  # cuda_stream handle the step's backward started on
+_WG_DEFERRED = []
 
 
 def _wgrad_stream():
@@ -113,6 +116,8 @@ def _wgrad_stream():
     if not _WG_ON or not _WG_ACTIVE[0]:
         return None
     base = torch.cuda.current_stream()
+    if _WG_MAIN_ONLY and _WG_MAIN[0] is not None and base.cuda_stream != _WG_MAIN[0]:
+        return None
     key = (base.device, base.cuda_stream)
     st = _WG_STREAMS.get(key)
     if st is None:
@@ -126,8 +131,24 @@ def join_param_grad_streams():
         return
     base = torch.cuda.current_stream()
     st = _WG_STREAMS.get((base.device, base.cuda_stream))
-    if st is not None:
-        base.wait_stream(st)
+    if st is None:
+        return
+    if _WG_MAIN[0] is not None and base.cuda_stream != _WG_MAIN[0] and torch.cuda.is_current_stream_capturing():
+        # hipGraph capture (apis.trainer.CapturedStep): a stream forked from a forked stream may only be joined into the ORIGIN
+        # stream -- hipStreamEndCapture dies on `side.wait_stream(companion of side)` (tools/debug/graph_streams_micro2.py:
+        # "mainfirst" / "twice" crash, "flatjoin" is fine).  Nothing on the side stream reads parameter gradients, so the
+        # companion is handed to the step's backward (model/net.py _StepFn), which joins it into the origin stream at its end.
+        if st not in _WG_DEFERRED:
+            _WG_DEFERRED.append(st)
+        return
+    base.wait_stream(st)
+
+
+def join_deferred_param_grad_streams():
+    """origin stream <- the side streams' companions whose join was deferred during a capture (see above)"""
+    base = torch.cuda.current_stream()
+    while _WG_DEFERRED:
+        base.wait_stream(_WG_DEFERRED.pop())
 
 
 def as_var(x) -> Var:

@@ -1,12 +1,12 @@
 """The captured training step (apis/trainer.py CapturedStep: one hipGraph per iteration for the B = 1 configs,
 config/cfg_kitti_baseline_argo_both_boundary_ce_iou_1024_20_B1.py:4-6) against the eager step it was captured from.
 
-Two runners start from identical weights and the same device-RNG seed and train the same 7 batches (three distinct ones,
-cycled; the learning rate halves before step 5): one issues every launch (eager), the other runs 2 eager warm-up
-iterations, captures, and replays.  Per-step losses, the parameters, Adam's moments and the BatchNorm counters must agree --
-bit for bit when the eager step itself is reproducible run to run (checked first), at fp32 rounding otherwise (a few kernels
-fold partial sums with atomics).  The Dropout masks and automask noise come from the device generator, so equality also
-proves that a replay draws what the eager step would have drawn."""
+An eager runner and a graph runner take the same 7 steps (three distinct batches, cycled; the learning rate halves before step
+5); before every step the eager runner's state -- parameters, Adam moments, BatchNorm buffers, device-RNG position -- is copied
+to the graph runner, so each replay is compared with the eager step FROM THE SAME STATE (Adam's early updates are ~lr * sign(g):
+comparing whole trajectories would measure how fast rounding noise of the few atomically-folded sums is amplified, not the
+capture).  The Dropout masks and automask noise come from the device generator, so agreement also proves that a replay draws
+what the eager step would have drawn."""
 import pytest
 import torch
 
@@ -22,55 +22,86 @@ from oracle import jp_oracle as J                                              #
 HW, B, FR, STEPS = 256, 1, [0, -1, 1], 7
 
 
-def _run(ty, graph):
-    opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type=ty,
-                        split="argo" if ty.startswith("Argo") else "odometry", loss_weightS=20, loss2_weightS=20)
+def _runner(ty, graph):
+    split = "argo" if ty.startswith("Argo") else "odometry"
+    opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type=ty, split=split,
+                        loss_weightS=20, loss2_weightS=20)
     model = MONO.module_dict["Baseline"](opt)
     model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
     model = model.cuda().train()
     optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
-    runner = Runner(model, batch_processor, optim, DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), step_graph=graph)
-    split = "argo" if ty.startswith("Argo") else "odometry"
-    batches = [syn.make_batch(B, HW, HW, FR, HW // 4, (129, 154) if split == "argo" else (94, 311), split, seed=80 + i)
-               for i in range(3)]
-    ops.manual_seed(11)
-    losses = []
-    for i in range(STEPS):
-        if i == 4:
-            optim.param_groups[0]["lr"] = 5e-5
-        out = runner.train_iter({k: v.clone() for k, v in batches[i % 3].items()})
-        losses.append(dict(out["log_vars"]))
-    torch.cuda.synchronize()
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    a = optim.arena
-    return dict(losses=losses, sd=sd, m=a.exp_avg.cpu().clone(), v=a.exp_avg_sq.cpu().clone(), step=a.step_count,
-                replays=runner.captured.replays if runner.captured else 0, ctr=ops._RNG_STATE["ctr"])
+    return Runner(model, batch_processor, optim, DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), step_graph=graph), split
+
+
+def _copy_state(src, dst):
+    """dst <- src: parameters, Adam moments + step, BatchNorm buffers and counters (both runners then start a step identically)"""
+    a, b = src.optimizer.arena, dst.optimizer.arena
+    b.params.copy_(a.params)
+    if a.exp_avg is not None:
+        if b.exp_avg is None:
+            b.exp_avg, b.exp_avg_sq = torch.zeros_like(b.params), torch.zeros_like(b.params)
+        b.exp_avg.copy_(a.exp_avg)
+        b.exp_avg_sq.copy_(a.exp_avg_sq)
+    b.step_count = a.step_count
+    ma, mb = src.model, dst.model
+    for (na, ba), (nb, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        assert na == nb
+        bb.copy_(ba)
+    for xa, xb in zip(ma.modules(), mb.modules()):
+        if hasattr(xa, "_pending"):
+            xb._pending = xa._pending
+    ops.weights_changed()
 
 
 @pytest.mark.parametrize("ty", ["static", "Argo_both"])
 def test_captured_step_equals_eager_step(ty):
-    e1, e2, g = _run(ty, False), _run(ty, False), _run(ty, True)
-    assert g["replays"] == STEPS - CapturedStep.WARMUP and g["step"] == e1["step"] == STEPS and g["ctr"] == e1["ctr"] > 0
-    reproducible = all(torch.equal(e1["sd"][k], e2["sd"][k]) for k in e1["sd"])
-    worst = 0.0
-    for k in e1["sd"]:
-        a, b = e1["sd"][k], g["sd"][k]
-        if k.endswith("num_batches_tracked"):
-            assert int(a) == int(b) > 0, k
-            continue
-        if reproducible:
-            assert torch.equal(a, b), f"{k}: replayed step differs from the eager step"
-        worst = max(worst, float((a.float() - b.float()).abs().max()))
-    for i, (le, lg) in enumerate(zip(e1["losses"], g["losses"])):
+    """Step by step from IDENTICAL state (the eager runner's parameters, Adam moments, BatchNorm buffers and RNG position are
+    copied over before every step): 2 eager warm-up iterations, the capture, then 5 replays, each against the eager step on the
+    same batch.  Forward quantities agree to fp32 rounding; one clip+Adam step moves a weight by at most ~lr, so parameters
+    agree within 2.2 lr everywhere (a sign flip of a ~0 gradient under the few atomically-folded sums) and bit for bit on all
+    but a sliver of the elements; Adam's step counter / bias corrections, the halved lr from step 5 on, the BatchNorm counters
+    and the device RNG position follow the eager run exactly."""
+    E, split = _runner(ty, False)
+    G, _ = _runner(ty, True)
+    batches = [syn.make_batch(B, HW, HW, FR, HW // 4, (129, 154) if split == "argo" else (94, 311), split, seed=80 + i)
+               for i in range(3)]
+    ops.manual_seed(11)
+    worst_p, worst_l, frac = 0.0, 0.0, 0.0
+    for i in range(STEPS):
+        lr = 1e-4 if i < 4 else 5e-5
+        E.optimizer.param_groups[0]["lr"] = G.optimizer.param_groups[0]["lr"] = lr
+        _copy_state(E, G)
+        c0 = ops._RNG_STATE["ctr"]
+        oe = E.train_iter({k: v.clone() for k, v in batches[i % 3].items()})
+        c1 = ops._RNG_STATE["ctr"]
+        ops._RNG_STATE["ctr"] = c0
+        og = G.train_iter({k: v.clone() for k, v in batches[i % 3].items()})
+        assert ops._RNG_STATE["ctr"] == c1 > c0, "the replay did not advance the device RNG like the eager step"
+        torch.cuda.synchronize()
+        le, lg = dict(oe["log_vars"]), dict(og["log_vars"])
         assert le.keys() == lg.keys()
         for k in le:
-            tol = 0.0 if reproducible else 1e-4 * max(1.0, abs(le[k]))
-            assert abs(le[k] - lg[k]) <= tol, (i, k, le[k], lg[k])
-    if reproducible:
-        assert torch.equal(e1["m"], g["m"]) and torch.equal(e1["v"], g["v"])
-    else:   # lr-sized moves: a sign flip of a ~0 gradient moves a weight by ~2 lr per step
-        assert worst <= 2.5e-4 * STEPS, worst
-    print(f"{ty}: eager step reproducible run to run: {reproducible}; max |param difference| graph vs eager {worst:.3e}")
+            d = abs(le[k] - lg[k]) / max(1.0, abs(le[k]))
+            worst_l = max(worst_l, d)
+            assert d <= 2e-5, (i, k, le[k], lg[k])
+        pe, pg = E.optimizer.arena.params, G.optimizer.arena.params
+        n = E.optimizer.arena.live_numel
+        d = (pe[:n] - pg[:n]).abs()
+        worst_p = max(worst_p, float(d.max()))
+        frac = max(frac, float((d > 1e-7).float().mean()))
+        assert float(d.max()) <= 2.2 * lr, (i, float(d.max()))
+        assert float((d > 1e-7).float().mean()) < 0.02, (i, float((d > 1e-7).float().mean()))
+        assert E.optimizer.arena.step_count == G.optimizer.arena.step_count == i + 1
+        for (na, ba), (nb, bb) in zip(E.model.named_buffers(), G.model.named_buffers()):
+            if ba.dtype.is_floating_point:
+                assert float((ba - bb).abs().max()) <= 1e-5 * max(1.0, float(ba.abs().max())), (i, na)
+    assert G.captured.replays == STEPS - CapturedStep.WARMUP
+    sd_e, sd_g = E.model.state_dict(), G.model.state_dict()
+    for k in sd_e:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_e[k]) == int(sd_g[k]) > 0, k
+    print(f"{ty}: worst loss-term difference {worst_l:.2e} (rel), worst parameter difference {worst_p:.2e}, "
+          f"largest share of elements that differ {frac:.2e}")
 
 
 def test_captured_step_recaptures_on_a_new_signature_and_refuses_foreign_setups():
