@@ -160,6 +160,14 @@ class CapturedStep:
     def _load(self, data):
         sig = self._signature(data)
         if sig != self.sig:            # new input signature: fresh static buffers, eager warm-up, new capture
+            if self.graph is not None:
+                # the old graph (and the tensors of its private pool) must be gone BEFORE the next capture starts: destroying a
+                # hipGraph while a stream is capturing is an error ("operation not permitted when stream is capturing")
+                import gc
+                torch.cuda.synchronize()
+                self.model_out = self.losses = self.loss = None
+                self.graph = None
+                gc.collect()
             self.sig, self.graph, self.eager_done = sig, None, 0
             self.static = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in data.items()}
             return
@@ -193,14 +201,22 @@ class CapturedStep:
         self.base_dev = torch.zeros(1, device=dev, dtype=torch.int64)
         bns = self._bn_modules()
         saved = (arena.step_count, ops._EPOCH[0], [b._pending for b in bns])
+        import gc
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         arena.dev_state = self.state_dev
+        gc.collect()                # (may drop dead models' pack entries -> the registry's job table is rebuilt next)
+        ops.PackRegistry.of(dev).ensure_table()
+        torch.cuda.synchronize(dev)
+        gc_was = gc.isenabled()
+        gc.disable()                # no collector run (it may destroy HIP objects) while the stream is capturing
         try:
             with ops.rng_capture(self.base_dev) as cap, torch.cuda.graph(self.graph):
                 self.model_out, self.losses, self.loss = self._body()
         finally:
             arena.dev_state = None
+            if gc_was:
+                gc.enable()
         self.rng_calls = cap.calls
         self.bn_delta = [(b, b._pending - p0) for b, p0 in zip(bns, saved[2])]
         # the capture executed nothing: take the host-side counters back

@@ -233,6 +233,22 @@ class PackRegistry:
             del self.entries[key]
             self.table = None
 
+    def ensure_table(self):
+        """Build the device job table of every live pack if it is missing (a host-to-device copy: CapturedStep calls this
+        BEFORE it starts capturing, refresh_all inside the capture then only launches).  -> False when there is nothing to replay."""
+        if self.table is None:
+            live = [e for e in self.entries.values()
+                    if e.jobs is not None and e.param is not None and e.ptr == e.param.data_ptr()]
+            jobs = np.concatenate([e.jobs for e in live]) if live else None
+            if jobs is None or len(jobs) == 0:
+                return False
+            # jp_pack_replay walks the concatenated range in groups of 4 elements: every job begins on a multiple of 4
+            padded = (jobs["total"] + 3) // 4 * 4
+            jobs["begin"] = np.concatenate([[0], np.cumsum(padded)[:-1]])
+            dev = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
+            self.table = (dev, len(jobs), int(padded.sum()), live)
+        return True
+
     def refresh_all(self):
         """One launch re-packs every registered layer if any weight changed since the last refresh."""
         if not self.entries:
@@ -250,17 +266,8 @@ class PackRegistry:
         stale = [e for e in self.entries.values() if e.epoch != ep and e.jobs is not None]
         if not stale:
             return
-        if self.table is None:
-            live = [e for e in self.entries.values()
-                    if e.jobs is not None and e.param is not None and e.ptr == e.param.data_ptr()]
-            jobs = np.concatenate([e.jobs for e in live]) if live else None
-            if jobs is None or len(jobs) == 0:
-                return
-            # jp_pack_replay walks the concatenated range in groups of 4 elements: every job begins on a multiple of 4
-            padded = (jobs["total"] + 3) // 4 * 4
-            jobs["begin"] = np.concatenate([[0], np.cumsum(padded)[:-1]])
-            dev = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
-            self.table = (dev, len(jobs), int(padded.sum()), live)
+        if not self.ensure_table():
+            return
         dev, n, total, live = self.table
         call("jp_pack_replay", dev, n, total)
         for e in live:
