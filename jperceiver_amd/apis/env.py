@@ -26,6 +26,17 @@ def get_dist_info():
     return 0, 1
 
 
+def get_root_logger(log_level="INFO"):
+    """mono/apis/env.py: the process-wide logger at `log_level` on rank 0, ERROR elsewhere (one line per event, not one per rank)."""
+    import logging
+    logger = logging.getLogger()
+    if not logger.hasHandlers():
+        logging.basicConfig(format="%(asctime)s - %(levelname)s - %(message)s", level=log_level)
+    rank, _ = get_dist_info()
+    logger.setLevel("ERROR" if rank != 0 else log_level)
+    return logger
+
+
 def set_random_seed(seed):
     random.seed(seed)
     np.random.seed(seed)

@@ -172,29 +172,37 @@ __device__ __forceinline__ WarpGeo warp_geo(const float* __restrict__ disp, int 
 }
 
 // grid (blocks over H*W, B).  pred (B,3,H,W)
+constexpr int CGT_FROWS = 4;
 __global__ __launch_bounds__(TPB) void cgt_warp_fwd_kernel(const float* __restrict__ disp, int hs, int ws,
                                                            const float* __restrict__ invK,
                                                            const float* __restrict__ Pm,
                                                            const float* __restrict__ color,
                                                            float* __restrict__ pred, int H, int W, float min_disp,
                                                            float max_disp) {
+    // 2-D tile (CGT_FROWS rows x 256 columns per workgroup, a thread walks one column down): consecutive rows share a source
+    // row of their bilinear corners in L1 (see cgt_warp_bwd_kernel)
     const int b = blockIdx.y;
-    const int p = blockIdx.x * TPB + threadIdx.x;
-    if (p >= H * W) return;
-    const int y = p / W, x = p - y * W;
-    const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pm + 12 * b, y, x, H, W, min_disp,
-                               max_disp, (float)hs / (float)H, (float)ws / (float)W);
-    const int x0 = (int)floorf(g.ix), y0 = (int)floorf(g.iy);
-    const float tx = g.ix - (float)x0, ty = g.iy - (float)y0;
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);   // weight of an OOB corner is 0
-    const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+    const int x = blockIdx.x * TPB + threadIdx.x;
+    if (x >= W) return;
     const size_t HW = (size_t)H * W;
     const float* c = color + (size_t)b * 3 * HW;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float* cc = c + ch * HW;
-        pred[((size_t)b * 3 + ch) * HW + p] =
-            cc[y0 * W + x0] * w00 + cc[y0 * W + x1] * w01 + cc[y1 * W + x0] * w10 + cc[y1 * W + x1] * w11;
+    for (int it = 0; it < CGT_FROWS; ++it) {
+        const int y = blockIdx.z * CGT_FROWS + it;
+        if (y >= H) break;
+        const int p = y * W + x;
+        const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pm + 12 * b, y, x, H, W, min_disp,
+                                   max_disp, (float)hs / (float)H, (float)ws / (float)W);
+        const int x0 = (int)floorf(g.ix), y0 = (int)floorf(g.iy);
+        const float tx = g.ix - (float)x0, ty = g.iy - (float)y0;
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);   // weight of an OOB corner is 0
+        const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* cc = c + ch * HW;
+            pred[((size_t)b * 3 + ch) * HW + p] =
+                cc[y0 * W + x0] * w00 + cc[y0 * W + x1] * w01 + cc[y1 * W + x0] * w10 + cc[y1 * W + x1] * w11;
+        }
     }
 }
 
@@ -213,11 +221,16 @@ __global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restri
     float dPl[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dPl[i] = 0.f;
-    // CGT_PPT pixels per thread: the 12 wave reductions + double atomics of dP are paid once per 2048 pixels
+    // 2-D tile: the workgroup owns CGT_PPT rows x 256 columns, a thread walks ONE column down the rows.  Row r + 1's bilinear
+    // corners share a source row with row r's, so that row is an L1 hit instead of a second L2 fetch (the 1-D mapping of
+    // rounds 1-3 -- 2048 consecutive pixels per workgroup -- fetched every source row twice, by workgroups on different XCDs:
+    // PMC FETCH_SIZE 6.3x the algorithmic bytes, profiles/r03_pmc_traffic_kernels.md); dpred / ddisp rows stay 1-KB
+    // contiguous per workgroup.  The 12 wave reductions + double atomics of dP are paid once per 2048 pixels, as before.
+    const int x = blockIdx.x * TPB + threadIdx.x;
     for (int it = 0; it < CGT_PPT; ++it) {
-        const int p = (blockIdx.x * CGT_PPT + it) * TPB + threadIdx.x;
-        if (p >= H * W) break;
-        const int y = p / W, x = p - y * W;
+        const int y = blockIdx.z * CGT_PPT + it;
+        if (y >= H || x >= W) break;
+        const int p = y * W + x;
         const float* Pb = Pm + 12 * b;
         const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pb, y, x, H, W, min_disp,
                                    max_disp, (float)hs / (float)H, (float)ws / (float)W);
@@ -597,7 +610,7 @@ extern "C" int jp_cgt_warp_fwd(const float* disp, int hs, int ws, const float* i
                                float max_depth, void* stream) {
     JP_CHECK_ARG(disp && invK && P && color && pred && B > 0 && H > 1 && W > 1, "cgt_warp_fwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(cgt_warp_fwd_kernel, dim3(jp_cdiv((long)H * W, TPB), B), dim3(TPB), 0, st, disp, hs, ws, invK, P,
+    hipLaunchKernelGGL(cgt_warp_fwd_kernel, dim3(jp_cdiv(W, TPB), B, jp_cdiv(H, CGT_FROWS)), dim3(TPB), 0, st, disp, hs, ws, invK, P,
                        color, pred, H, W, 1.f / max_depth, 1.f / min_depth);
     JP_LAUNCH_CHECK();
 }
@@ -607,7 +620,7 @@ extern "C" int jp_cgt_warp_bwd(const float* dpred, const float* disp, int hs, in
                                float min_depth, float max_depth, int accumulate, void* stream) {
     JP_CHECK_ARG(dpred && disp && invK && P && color && ddisp_up && dP && B > 0, "cgt_warp_bwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv((long)H * W, TPB * CGT_PPT), B), dim3(TPB), 0, st, dpred, disp, hs, ws,
+    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv(W, TPB), B, jp_cdiv(H, CGT_PPT)), dim3(TPB), 0, st, dpred, disp, hs, ws,
                        invK, P, color, ddisp_up, dP, H, W, 1.f / max_depth, 1.f / min_depth, accumulate);
     JP_LAUNCH_CHECK();
 }
