@@ -221,16 +221,14 @@ __global__ __launch_bounds__(TPB) void cgt_warp_bwd_kernel(const float* __restri
     float dPl[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dPl[i] = 0.f;
-    // 2-D tile: the workgroup owns CGT_PPT rows x 256 columns, a thread walks ONE column down the rows.  Row r + 1's bilinear
-    // corners share a source row with row r's, so that row is an L1 hit instead of a second L2 fetch (the 1-D mapping of
-    // rounds 1-3 -- 2048 consecutive pixels per workgroup -- fetched every source row twice, by workgroups on different XCDs:
-    // PMC FETCH_SIZE 6.3x the algorithmic bytes, profiles/r03_pmc_traffic_kernels.md); dpred / ddisp rows stay 1-KB
-    // contiguous per workgroup.  The 12 wave reductions + double atomics of dP are paid once per 2048 pixels, as before.
-    const int x = blockIdx.x * TPB + threadIdx.x;
+    // CGT_PPT pixels per thread: the 12 wave reductions + double atomics of dP are paid once per 2048 pixels.  (A 2-D tile --
+    // CGT_PPT rows x 256 columns, a thread walking one column down, as cgt_warp_fwd_kernel does -- cuts the source-row
+    // re-fetch of this 1-D order from 1.5x to 1.09x on a smooth flow (tools/ubench/fetch_calib.hip), but with the seven
+    // tensor streams of the backward it measured SLOWER on the step's data: 107 -> 123 us per call, profiles/r04_photo_ab.log.)
     for (int it = 0; it < CGT_PPT; ++it) {
-        const int y = blockIdx.z * CGT_PPT + it;
-        if (y >= H || x >= W) break;
-        const int p = y * W + x;
+        const int p = (blockIdx.x * CGT_PPT + it) * TPB + threadIdx.x;
+        if (p >= H * W) break;
+        const int y = p / W, x = p - y * W;
         const float* Pb = Pm + 12 * b;
         const WarpGeo g = warp_geo(disp + (size_t)b * hs * ws, hs, ws, invK + 16 * b, Pb, y, x, H, W, min_disp,
                                    max_disp, (float)hs / (float)H, (float)ws / (float)W);
@@ -620,7 +618,7 @@ extern "C" int jp_cgt_warp_bwd(const float* dpred, const float* disp, int hs, in
                                float min_depth, float max_depth, int accumulate, void* stream) {
     JP_CHECK_ARG(dpred && disp && invK && P && color && ddisp_up && dP && B > 0, "cgt_warp_bwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv(W, TPB), B, jp_cdiv(H, CGT_PPT)), dim3(TPB), 0, st, dpred, disp, hs, ws,
+    hipLaunchKernelGGL(cgt_warp_bwd_kernel, dim3(jp_cdiv((long)H * W, TPB * CGT_PPT), B), dim3(TPB), 0, st, dpred, disp, hs, ws,
                        invK, P, color, ddisp_up, dP, H, W, 1.f / max_depth, 1.f / min_depth, accumulate);
     JP_LAUNCH_CHECK();
 }

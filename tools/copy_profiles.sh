@@ -13,4 +13,5 @@ cp $S/pmc_traffic_kernels.md $D/${R}_pmc_traffic_kernels.md
 cp $S/pytest_gpu.log $D/${R}_pytest_gpu.log
 cp $S/smoke.log $D/${R}_smoke.log
 cp $S/bench_under_rocprof.log $D/${R}_bench_under_rocprof.log
+cp $S/bench_other_configs.jsonl $D/${R}_bench_other_configs.jsonl
 ls -la $D | grep ${R}_

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box aid: the round's measurement pass -> gpurun_out/rNN/ (copy the summaries into profiles/ afterwards).
 # usage: tools/measure_round.sh r02
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -9,6 +9,10 @@ cd $ROOT
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 JP_BENCH_TABLE=$OUT/bench_families.json timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+# the other BASELINE.json configs on one GPU (config 0 / 4 = one image per GPU: with and without the captured step)
+: > $OUT/bench_other_configs.jsonl
+for c in 0 4; do for g in off on; do timeout 300 python bench.py --config $c --graph $g --steps 20 --warmup 4 --no-cpu-baseline --no-secondary --no-roofline >> $OUT/bench_other_configs.jsonl 2>> $OUT/bench_other.err; done; done
+for c in 2 3; do timeout 600 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline >> $OUT/bench_other_configs.jsonl 2>> $OUT/bench_other.err; done
 cd /tmp && export TMPDIR=/tmp
 # (a) single-stream pass (no side / companion streams): per-kernel durations that are the kernels' own, comparable with
 #     bench.py's HIP-event roofline;  (b) the default overlapped step: timeline (kernels in flight, idle gaps)

@@ -38,3 +38,12 @@ for name, fn, byt in (
         ("cgt_warp_bwd", lambda: call("jp_cgt_warp_bwd", dpred, disp, H, W, invK, P, color, ddisp, dP, B, H, W, 0.1, 100.0, 0), px * 32)):
     ms = t(fn)
     print(f"{name:14s} {ms * 1e3:7.1f} us  {byt / 1e6:6.0f} MB  {byt / ms / 1e9:5.2f} TB/s", flush=True)
+# the same warp kernels on a SMOOTH disparity (a trained network's; the rows above use per-pixel random disparity = the
+# random-initialised network of bench.py: neighbouring pixels then sample source rows several lines apart)
+yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
+disp_s = (0.2 + 0.6 * yy + 0.05 * torch.sin(6.28 * xx)).expand(B, 1, H, W).contiguous()
+for name, fn, byt in (
+        ("cgt_warp_fwd smooth", lambda: call("jp_cgt_warp_fwd", disp_s, H, W, invK, P, color, warp, B, H, W, 0.1, 100.0), px * 28),
+        ("cgt_warp_bwd smooth", lambda: call("jp_cgt_warp_bwd", dpred, disp_s, H, W, invK, P, color, ddisp, dP, B, H, W, 0.1, 100.0, 0), px * 32)):
+    ms = t(fn)
+    print(f"{name:20s} {ms * 1e3:7.1f} us  {byt / 1e6:6.0f} MB  {byt / ms / 1e9:5.2f} TB/s", flush=True)
