@@ -9,12 +9,17 @@ public `forward(...)` on plain tensors (inference / standalone use).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import ops, ops_loss
 from ..ops import Var, param as P, ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID, PAD_ZERO, PAD_REFLECT
+
+
+_STEM_FUSE = os.environ.get("JP_STEM_FUSE", "1") != "0"      # bn1 -> relu -> maxpool of the ResNet stems in one pass each way
 
 
 def _t(v):
@@ -242,16 +247,25 @@ class ResNet(nn.Module):
             layers.append(BasicBlock(planes, planes))
         return nn.Sequential(*layers)
 
-    def features(self, img: Var, n_updates=1, ready_tag=None, groups=1):
+    def features(self, img: Var, n_updates=1, ready_tag=None, groups=1, need_f0=True):
         """(x-0.45)/0.225 -> stem -> 4 stages; returns the 5-level pyramid (depth_encoder.py:35-44).
         `ready_tag`: report gradient completion in two steps (layer4, then the rest) to the data-parallel hook.
-        `groups`: the batch stacks that many independent passes (BatchNorm statistics per group, ops.batchnorm_train)."""
+        `groups`: the batch stacks that many independent passes (BatchNorm statistics per group, ops.batchnorm_train).
+        `need_f0=False` (the train step: neither DepthDecoder, PoseDecoder nor the layout Encoder reads level 0): the stem tail
+        bn1 -> relu -> maxpool runs fused (ops.bn_relu_maxpool_train) and level 0 of the returned list is None."""
         if ready_tag:
             ops.grad_ready(ready_tag + ".lo")
         x = ops.affine(img, 1.0 / 0.225, -0.45 / 0.225)
-        f0 = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates, groups=groups)
-        feats = [f0]
-        x = ops.maxpool(f0, 3, 2, 1)
+        c0 = conv_apply(self.conv1, x)
+        if not need_f0 and self.bn1.training and _STEM_FUSE and c0.t.shape[2] % 4 == 0 and c0.t.shape[3] % 4 == 0:
+            self.bn1._pending += n_updates * groups
+            feats = [None]
+            x = ops.bn_relu_maxpool_train(c0, P(self.bn1.weight), P(self.bn1.bias), self.bn1.running_mean, self.bn1.running_var,
+                                          self.bn1.momentum, self.bn1.eps, n_updates, groups)
+        else:
+            f0 = bn_apply(self.bn1, c0, relu=True, n_updates=n_updates, groups=groups)
+            feats = [f0]
+            x = ops.maxpool(f0, 3, 2, 1)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             if ready_tag and layer is self.layer4:
                 ops.grad_ready(ready_tag + ".l4")
@@ -273,11 +287,11 @@ class DepthEncoder(nn.Module):
         if pretrained_path is not None:
             self.encoder.load_state_dict(torch.load(pretrained_path))
 
-    def _fwd(self, img, n_updates=1):
-        return self.encoder.features(img, n_updates, ready_tag="DepthEncoder")
+    def _fwd(self, img, n_updates=1, need_f0=False):
+        return self.encoder.features(img, n_updates, ready_tag="DepthEncoder", need_f0=need_f0)
 
     def forward(self, input_image):
-        return [f.t for f in self._fwd(Var(input_image))]
+        return [f.t for f in self._fwd(Var(input_image), need_f0=True)]
 
 
 class PoseEncoder(nn.Module):
@@ -294,11 +308,11 @@ class PoseEncoder(nn.Module):
             loaded["conv1.weight"] = torch.cat([loaded["conv1.weight"]] * num_input_images, 1) / num_input_images
             self.encoder.load_state_dict(loaded)
 
-    def _fwd(self, img, n_updates=1, groups=1):
-        return self.encoder.features(img, n_updates, groups=groups)
+    def _fwd(self, img, n_updates=1, groups=1, need_f0=False):
+        return self.encoder.features(img, n_updates, groups=groups, need_f0=need_f0)
 
     def forward(self, input_image):
-        return [f.t for f in self._fwd(Var(input_image))]
+        return [f.t for f in self._fwd(Var(input_image), need_f0=True)]
 
 
 def find_imagenet_resnet18():
@@ -342,11 +356,11 @@ class ResnetEncoder(nn.Module):
                 self.encoder.load_state_dict(loaded)
                 self.pretrained_loaded = True
 
-    def _fwd(self, img, n_updates=1):
-        return self.encoder.features(img, n_updates)
+    def _fwd(self, img, n_updates=1, need_f0=False):
+        return self.encoder.features(img, n_updates, need_f0=need_f0)
 
     def forward(self, input_image):
-        return [f.t for f in self._fwd(Var(input_image))]
+        return [f.t for f in self._fwd(Var(input_image), need_f0=True)]
 
 
 # ------------------------------------------------------------------------------------------- depth_decoder.py

@@ -523,6 +523,43 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
     return out
 
 
+def bn_relu_maxpool_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, momentum=0.1, eps=1e-5, n_updates=1,
+                          groups=1) -> Var:
+    """ResNet stem tail, train mode: MaxPool2d(3, 2, 1)(relu(BatchNorm2d(x))) without the normalised map (resnet.py:92-94) --
+    forward pools straight off the convolution output, backward gathers the pooled gradient through the argmax bytes inside
+    the BatchNorm reduce / apply kernels (csrc/bn.hip).  `groups` as in batchnorm_train.  H and W must be multiples of 4."""
+    N, C, H, W = x.t.shape
+    assert N % groups == 0 and H % 4 == 0 and W % 4 == 0
+    Ng = N // groups
+    y = _new((N, C, H // 2, W // 2), x.t)
+    idx = _new((N, C, H // 2, W // 2), x.t, torch.uint8)
+    mean, invstd = _new((groups, C), x.t), _new((groups, C), x.t)
+    nbw = int(_jplib().fn["jp_bn_ws_doubles"](Ng, C, H * W))
+    for g in range(groups):
+        sl = slice(g * Ng, (g + 1) * Ng)
+        ws = _new((nbw,), x.t, torch.float64)
+        call("jp_bn_relu_pool_fwd", x.t[sl], gamma.t, beta.t, y[sl], idx[sl], running_mean, running_var, mean[g], invstd[g], ws,
+             Ng, C, H, W, momentum, eps, n_updates)
+    out = Var(y, x.rg or gamma.rg)
+
+    def bwd():
+        if out.g is None:
+            return
+        dx = torch.empty_like(x.t)
+        nb2 = int(_jplib().fn["jp_bn_relu_pool_bwd_ws_doubles"](Ng, C, H, W))
+        for g in range(groups):
+            sl = slice(g * Ng, (g + 1) * Ng)
+            ws2 = _new((nb2,), x.t, torch.float64)
+            call("jp_bn_relu_pool_bwd", out.g[sl], idx[sl], x.t[sl], gamma.t, beta.t, mean[g], invstd[g], dx[sl], gamma.g, beta.g,
+                 ws2, Ng, C, H, W, 1)
+        if x.rg:
+            x.add_grad(dx)
+        out.g = None
+
+    _rec(out.rg, bwd)
+    return out
+
+
 def split_rows(v: Var, n: int):
     """(k*n, ...) -> k Vars of n rows each (views of v's storage); their gradients are gathered back into v's."""
     k = v.t.shape[0] // n

@@ -346,7 +346,7 @@ def test_train_mono_two_epochs_single_rank(tmp_path):
     runner = train_mono(model, _SynthSet(HW, FR), None, cfg, None, distributed=False, validate=False)
     assert runner.epoch == 2 and runner.iter == 4 and runner.current_lr()[0] == pytest.approx(5e-5)
     lv = runner.outputs["log_vars"]
-    assert all(v == v and abs(v) < 1e6 for v in lv.values()) and lv["loss"] > 0
+    assert all(v == v and abs(v) < 1e6 for v in lv.values()) and "loss" in lv        # (the boundary term makes the total negative)
     w1 = runner.model.module.DepthDecoder.iconv3.conv.weight.detach().cpu()
     moved = (w1 - w0).abs().max()
     assert 1e-5 < float(moved) < 1e-3                          # 2 steps at 1e-4 + 2 at 5e-5: |dw| <= 3e-4 per weight

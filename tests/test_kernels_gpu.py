@@ -231,6 +231,52 @@ def test_batchnorm_train(relu, res, nup, shape):
         close(rvv.g, rr.grad, msg="dres")
 
 
+@pytest.mark.parametrize("shape,groups,nup", [((2, 8, 12, 20), 1, 1), ((4, 16, 64, 128), 2, 2), ((3, 5, 300, 64), 1, 1),
+                                              ((8, 64, 512, 512), 1, 1), ((16, 64, 96, 320), 2, 1)],
+                         ids=["small", "two-groups-double-update", "ragged-bands", "depth-stem-bench-shape", "pose-stem-bench-shape"])
+def test_bn_relu_maxpool_fused_stem_tail(shape, groups, nup):
+    """ops.bn_relu_maxpool_train (ResNet stem tail in one pass each way, csrc/bn.hip) against the two ops it replaces --
+    batchnorm_train(relu) + maxpool(3, 2, 1): the pooled map, the argmax decisions (through the gradient) and the running
+    statistics bit for bit, the gradients to fp32 rounding (the fused backward sums the same terms in another order) -- and,
+    on the small shape, against ATen on the CPU.  Many exact ties: relu zeroes half the map."""
+    N, C, H, W = shape
+    x = rnd(N, C, H, W, seed=1) * 2 + 0.3
+    g, b = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.1
+    g[0] = -0.7                                                 # a negative scale: max and affine do not commute
+    res = {}
+    for fused in (True, False):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        xv, gv, bv = Var(x, True), pvar(g.clone()), pvar(b.clone())
+        tape = Tape()
+        with recording(tape):
+            if fused:
+                y = ops.bn_relu_maxpool_train(xv, gv, bv, rm, rv, 0.1, 1e-5, nup, groups)
+            else:
+                y = ops.maxpool(ops.batchnorm_train(xv, gv, bv, rm, rv, None, True, 0.1, 1e-5, nup, groups), 3, 2, 1)
+        gy = rnd(*y.t.shape, seed=5)
+        y.g = gy.clone()
+        tape.backward()
+        res[fused] = dict(y=y.t.clone(), rm=rm, rv=rv, dx=xv.g.clone(), dg=gv.g.clone(), db=bv.g.clone())
+    a, r = res[True], res[False]
+    assert torch.equal(a["y"], r["y"]) and torch.equal(a["rm"], r["rm"]) and torch.equal(a["rv"], r["rv"])
+    close(a["dx"], r["dx"], rtol=2e-5, atol=1e-6, msg="dx vs unfused")
+    close(a["dg"], r["dg"], rtol=2e-5, atol=1e-6, msg="dgamma vs unfused")
+    close(a["db"], r["db"], rtol=2e-5, atol=1e-6, msg="dbeta vs unfused")
+    # identical argmax decisions: the gradient reaches exactly the same input positions before the BatchNorm terms spread it
+    if N * C * H * W <= 1 << 16 and groups == 1:
+        xr, gr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, g, b))
+        rm2, rv2 = torch.zeros(C), torch.ones(C)
+        for _ in range(nup):
+            yr = F.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5)
+        yr = F.max_pool2d(F.relu(yr), 3, 2, 1)
+        close(a["y"], yr, msg="fwd vs ATen")
+        close(a["rm"], rm2, msg="running_mean")
+        yr.backward(gy.cpu())
+        close(a["dx"], xr.grad, rtol=3e-4, msg="dx vs ATen")
+        close(a["dg"], gr.grad, rtol=3e-4, msg="dgamma vs ATen")
+        close(a["db"], br.grad, rtol=3e-4, msg="dbeta vs ATen")
+
+
 # ------------------------------------------------------------------------------------------- pooling & co
 @pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 20, 28), (5, 1, 2, 9, 13), (2, 2, 0, 8, 8), (3, 2, 1, 21, 27),
                                        (5, 1, 2, 40, 150), (3, 2, 1, 70, 262), (2, 2, 0, 36, 132), (3, 1, 1, 19, 70),

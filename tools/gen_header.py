@@ -28,8 +28,11 @@ GROUPS = [
      ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
     ("Train-mode BatchNorm2d (+fused residual add / ReLU) — " + R + "resnet.py:21-24,41-45,92; " + R + "layout_model.py:146,152. "
      "ws = jp_bn_ws_doubles(N, C, HW) doubles of caller scratch.  n_updates = number of momentum updates of the running stats (2 for the layout "
-     "branch the reference evaluates twice, " + R + "net.py:73-74).",
-     ["jp_bn_ws_doubles", "jp_bn_train_fwd", "jp_bn_train_bwd", "jp_bn_eval_fwd"]),
+     "branch the reference evaluates twice, " + R + "net.py:73-74).  jp_bn_relu_pool_*: the ResNet stem tail bn1 -> relu -> MaxPool2d(3, 2, 1) ("
+     + R + "resnet.py:92-94) in one pass each way, for callers that do not read the normalised map itself (the decoders never do): "
+     "pooled output + argmax byte in forward, the convolution-output gradient straight from the pooled gradient in backward.",
+     ["jp_bn_ws_doubles", "jp_bn_train_fwd", "jp_bn_train_bwd", "jp_bn_eval_fwd", "jp_bn_relu_pool_fwd",
+      "jp_bn_relu_pool_bwd_ws_doubles", "jp_bn_relu_pool_bwd"]),
     ("Pooling / resampling / elementwise — MaxPool2d " + R + "resnet.py:94, " + R + "layers.py:191, " + R + "layout_model.py:84; "
      "nearest upsample " + R + "layers.py:110; torch.cat; Dropout multiply " + R + "depth_decoder.py:52-53; F.interpolate bilinear "
      + R + "net.py:196,632,692 and area " + R + "net.py:762.",
