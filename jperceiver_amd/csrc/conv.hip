@@ -2114,9 +2114,18 @@ inline bool p9_m256() {
 // `ptiles` = N * (H/4) * (W/32) pixel tiles of the launch (the conv entry points know it when they pack: a layer's pack is
 // keyed by its shape on the host side); the 8-wave variant needs >= 256 workgroups or it leaves CUs empty
 // (512->512 @32x32: 141 -> 92 TF), where it has them it is 2-4 % faster (256->256 @128x128: 141 -> 146 TF)
+// JP_P1_TILE (1x1 layers with 256-row banks): 0 = 256 rows x 4x32 pixels on 8 waves (rounds 2-3); 1 = 256 rows x 8x32 pixels
+// (jp_igemm_p9s_wide_kernel<4, 2>: NJ = 4 pixel rows per wave, one workgroup per CU); 2 = 128 rows x 8x32 pixels on 4 waves
+// (jp_igemm_p9s_wide_kernel<2, 2>, two workgroups per CU; 128-row pack)
+inline int p1_tile() {
+    static const int m = [] { const char* e = getenv("JP_P1_TILE"); return e ? atoi(e) : 0; }();
+    return m;
+}
+inline bool p9_wide256(int rows, long ptiles) { return p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256; }
 inline int p9_bmt(int rows, int khw = 9, long ptiles = 0) {
     if (rows <= 64) return 64;
-    return (p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256) ? 256 : 128;
+    if (khw == 1 && p1_tile() == 2) return 128;
+    return p9_wide256(rows, ptiles) ? 256 : 128;
 }
 inline long p9_ptiles(int N, int H, int W) { return (long)N * (H / 4) * (W / 32); }
 inline long dgrad_tap_floats(int Cin, int Cout, int KH) { return ((long)(KH * KH + 16) * Cin + 512 + 64) * ((Cout + 31) / 32 * 32); }
@@ -2151,7 +2160,7 @@ inline int p1_mode() {
 }
 inline bool p9_ok(int rows, int red, int N, int H, int W, int khw = 9) {
     const int tr = rows <= 64 ? 8 : 4;
-    const bool p1 = p1_mode() == 1 || (p1_mode() == 2 && p9_bmt(rows, 1, p9_ptiles(N, H, W)) == 256);
+    const bool p1 = p1_mode() == 1 || (p1_mode() == 2 && p9_wide256(rows, p9_ptiles(N, H, W)));
     return p9_enabled() && (khw == 9 || p1) && rows >= 32 && red >= 32 && red % (khw == 1 ? 64 : 32) == 0 && W % 32 == 0 && H % tr == 0 &&
            (long)jp_cdiv(rows, p9_bmt(rows)) * N * (H / tr) * (W / 32) >= 192;
 }
@@ -2159,11 +2168,24 @@ template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9_tag() { return __PRETTY_FUNCTION__; }       // profiler tag naming the instantiation
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9s_tag() { return __PRETTY_FUNCTION__; }
+template <int WM, int WN, class E>
+const char* p9sw_tag() { return __PRETTY_FUNCTION__; }
 template <bool REFLECT, bool REV, class E, int TAPS>
 void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
+    if constexpr (TAPS == 1 && !REFLECT && !REV) {
+        // wide 1x1 tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy
+        if (p1_tile() && H % 8 == 0 && bmt >= 128 && p9_wide256(rows, p9_ptiles(N, H, W)) && (long)N * (H / 8) * (W / 32) * (rows / bmt) >= 256) {
+            jp_prof_before(bmt == 256 ? p9sw_tag<4, 2, E>() : p9sw_tag<2, 2, E>(), 6.0 * 2.0 * rows * (double)N * H * W * red, st);
+            dim3 grid(N * (H / 8) * (W / 32), jp_cdiv(rows, bmt), 1);
+            if (bmt == 256) hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<4, 2, E>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+            else hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<2, 2, E>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+            jp_prof_after(st);
+            return;
+        }
+    }
     // executed FLOPs: 6 bf16 MFMA products per fp32 product
     jp_prof_before(bmt == 64 ? p9s_tag<1, 4, REFLECT, REV, E, TAPS>() : (bmt == 256 ? p9s_tag<4, 2, REFLECT, REV, E, TAPS>() : p9s_tag<2, 2, REFLECT, REV, E, TAPS>()),
                    6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);

@@ -61,7 +61,11 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 // MASK (small maps, igemm_p9sm kernels below): H / W need not be multiples of the tile -- partial tiles stage zeros outside
 // the map and store only pixels inside it -- and the workgroup runs the stage range [s_begin, s_end) of the reduction only
 // (split-K over grid.z for launches whose tile grid cannot fill the chip; partial sums through a slice epilogue).
-template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS, int XS, bool MASK = false>
+// ROWB: B fragments are re-read row by row just in time (12*NJ registers) instead of double-buffered per step (24*NJ): what
+// lets a wave hold NJ = 4 pixel rows (8 accumulators) in 230-250 registers -- the 1x1 "wide" tiles of round 4, which halve the
+// L2 weight-stream traffic per MFMA (a wave's A fragments serve 4 pixel rows instead of 2).
+template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS, int XS, bool MASK = false,
+          bool ROWB = (P9S_OCC >= 3)>
 __device__ __forceinline__ void jp_igemm_p9s_body(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
     int s_begin = 0, int s_end = -1) {
@@ -186,96 +190,103 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     for (int d = 0; d < P9S_AHEAD; ++d) aload(d, (s_begin * STEPS + d) * SBYTES);
     const jp_u32x4* bp = patch + (lhi * PR + wn * NJ) * COLS + l31;
 
-#if P9S_OCC >= 3
-    // B fragments of pixel row j, [split]: each row is re-read just in time -- row j of the next use is requested while the
-    // MFMAs of the other rows run (12*NJ registers instead of a double buffer of 24*NJ)
-    jp_u32x4 rb[NJ][3];
-    auto bload = [&](int j, int u) {
-        const int tap = u / KGS, kg = u % KGS;
-        const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
+    if constexpr (ROWB) {
+        // B fragments of pixel row j, [split]: each row is re-read just in time -- row j of the next use is requested while the
+        // MFMAs of the other rows run (12*NJ registers instead of a double buffer of 24*NJ)
+        jp_u32x4 rb[NJ][3];
+        auto bload = [&](int j, int u) {
+            const int tap = u / KGS, kg = u % KGS;
+            const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) rb[j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
-    };
-#define JP_P9S_MFMA(J_, SA_, SB_)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
-        acc[i][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
-                                                             __builtin_bit_cast(jp_bf16x8, rb[J_][SB_]), acc[i][J_], 0, 0, 0)
-    auto run_stage = [&](auto par_tag, int stage) {
-        constexpr int PAR = decltype(par_tag)::value;
-        lstore();
-        __syncthreads();
-        if (stage + 1 < s_end) gload(stage + 1);
-        const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
-        bload(0, 0);
+            for (int s = 0; s < 3; ++s) rb[j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+        };
+#define JP_P9S_MFMA_ROW(J_, SA_, SB_)                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
+            acc[i][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
+                                                                 __builtin_bit_cast(jp_bf16x8, rb[J_][SB_]), acc[i][J_], 0, 0, 0)
+        auto run_stage = [&](auto par_tag, int stage) {
+            constexpr int PAR = decltype(par_tag)::value;
+            lstore();
+            __syncthreads();
+            if (stage + 1 < s_end) gload(stage + 1);
+            const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
+            bload(0, 0);
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) {
-            aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+            for (int u = 0; u < STEPS; ++u) {
+                aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) bload(j + 1, u);
-                else if (u + 1 < STEPS) { /* row 0 of the next step: requested after this row's MFMAs were issued (below) */ }
-                __builtin_amdgcn_sched_barrier(0);
-                JP_P9S_MFMA(j, 2, 0); JP_P9S_MFMA(j, 1, 1); JP_P9S_MFMA(j, 0, 2);
-                JP_P9S_MFMA(j, 1, 0); JP_P9S_MFMA(j, 0, 1); JP_P9S_MFMA(j, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j == 0 && NJ > 1) { /* rb[0] is free again */ }
-                if (j + 1 == NJ && u + 1 < STEPS) bload(0, u + 1);
+                for (int j = 0; j < NJ; ++j) {
+                    if (j + 1 < NJ) bload(j + 1, u);
+                    else if (u + 1 < STEPS) { /* row 0 of the next step: requested after this row's MFMAs were issued (below) */ }
+                    __builtin_amdgcn_sched_barrier(0);
+                    JP_P9S_MFMA_ROW(j, 2, 0); JP_P9S_MFMA_ROW(j, 1, 1); JP_P9S_MFMA_ROW(j, 0, 2);
+                    JP_P9S_MFMA_ROW(j, 1, 0); JP_P9S_MFMA_ROW(j, 0, 1); JP_P9S_MFMA_ROW(j, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j == 0 && NJ > 1) { /* rb[0] is free again */ }
+                    if (j + 1 == NJ && u + 1 < STEPS) bload(0, u + 1);
+                }
             }
+            __syncthreads();
+        };
+        static_assert(RING == 2, "two stage parities <-> two ring phases");
+        gload(s_begin);
+        for (int stage = s_begin; stage < s_end; stage += 2) {
+            run_stage(std::integral_constant<int, 0>{}, stage);
+            if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
         }
-        __syncthreads();
-    };
-#else
-    // B fragments of step u: [j][split], compile-time LDS offsets (the step loop is fully unrolled)
-    jp_u32x4 rb[2][NJ][3];
-    auto bload = [&](int slot, int u) {
-        const int tap = u / KGS, kg = u % KGS;
-        const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
+    } else {
+        // B fragments of step u: [j][split], compile-time LDS offsets (the step loop is fully unrolled)
+        jp_u32x4 rb[2][NJ][3];
+        auto bload = [&](int slot, int u) {
+            const int tap = u / KGS, kg = u % KGS;
+            const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) rb[slot][j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
-    };
+                for (int s = 0; s < 3; ++s) rb[slot][j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+        };
 #define JP_P9S_MFMA(SA_, SB_)                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
-                                                            __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
+                                                                __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
 
-    // one stage; PAR = stage parity (compile-time): the weight ring slot of step u is (global step) % RING and STEPS may be odd
-    auto run_stage = [&](auto par_tag, int stage) {
-        constexpr int PAR = decltype(par_tag)::value;
-        lstore();
-        __syncthreads();
-        if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
-        const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
-        bload(0, 0);
+        // one stage; PAR = stage parity (compile-time): the weight ring slot of step u is (global step) % RING and STEPS may be odd
+        auto run_stage = [&](auto par_tag, int stage) {
+            constexpr int PAR = decltype(par_tag)::value;
+            lstore();
+            __syncthreads();
+            if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
+            const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
+            bload(0, 0);
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) {
-            // operands of step u + 1 are requested before the MFMAs of step u issue: weights of step u + AHEAD (the stream
-            // continues into the next stage; the pack carries AHEAD steps of slack), B fragments of step u + 1
-            aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
-            if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
-            // (the issue order does not matter to the matrix pipe: tools/ubench/mfma_bf16_chain.hip measures 86-90 % of 2.5 PF for
-            // dependent chains, round robin and six-in-a-row alike -- and the compiler's scheduler interleaves them anyway)
-            JP_P9S_MFMA(2, 0);
-            JP_P9S_MFMA(1, 1);
-            JP_P9S_MFMA(0, 2);
-            JP_P9S_MFMA(1, 0);
-            JP_P9S_MFMA(0, 1);
-            JP_P9S_MFMA(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < STEPS; ++u) {
+                // operands of step u + 1 are requested before the MFMAs of step u issue: weights of step u + AHEAD (the stream
+                // continues into the next stage; the pack carries AHEAD steps of slack), B fragments of step u + 1
+                aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+                if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
+                // (the issue order does not matter to the matrix pipe: tools/ubench/mfma_bf16_chain.hip measures 86-90 % of 2.5 PF for
+                // dependent chains, round robin and six-in-a-row alike -- and the compiler's scheduler interleaves them anyway)
+                JP_P9S_MFMA(2, 0);
+                JP_P9S_MFMA(1, 1);
+                JP_P9S_MFMA(0, 2);
+                JP_P9S_MFMA(1, 0);
+                JP_P9S_MFMA(0, 1);
+                JP_P9S_MFMA(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        static_assert(RING == 2, "two stage parities <-> two ring phases");
+        gload(s_begin);
+        for (int stage = s_begin; stage < s_end; stage += 2) {
+            run_stage(std::integral_constant<int, 0>{}, stage);
+            if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
         }
-        __syncthreads();
-    };
-#endif
-    static_assert(RING == 2, "two stage parities <-> two ring phases");
-    gload(s_begin);
-    for (int stage = s_begin; stage < s_end; stage += 2) {
-        run_stage(std::integral_constant<int, 0>{}, stage);
-        if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
     }
 #undef JP_P9S_MFMA
+#undef JP_P9S_MFMA_ROW
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -302,6 +313,13 @@ template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, i
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off);
+}
+// 1x1 "wide" tiles (round 4): NJ = 4 pixel rows per wave (8 rows x 32 columns per workgroup with WN = 2), B fragments re-read row
+// by row (ROWB): a wave's weight fragments serve twice the pixels, i.e. half the L2 -> CU weight-stream bytes per MFMA
+template <int WM, int WN, class Epi>
+__global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9s_wide_kernel(
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
+    jp_igemm_p9s_body<WM, WN, 4, false, false, Epi, 1, 2, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
 // small maps (pose encoder 24x80 .. 6x20, BEV 32x32 .. 8x8): masked partial tiles + split-K over grid.z; the epilogue's
 // `slice` member receives blockIdx.z (conv_p9sm.hip)
