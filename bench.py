@@ -424,7 +424,8 @@ def _kernel_name(tag):
     kv = dict(p.split(" = ", 1) for p in parts if " = " in p)
     kv = {k: v.replace("(anonymous namespace)::", "") for k, v in kv.items()}
     if "p9sw_tag" in tag:
-        return f"jp_igemm_p9s_wide_kernel<{kv['WM']}, {kv['WN']}, {kv['E']}>"
+        taps = kv.get("TAPS", "1")
+        return f"jp_igemm_p9s_wide_kernel<{kv['WM']}, {kv['WN']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {taps}, {1 if taps == '9' else 2}>"
     if "p9sm_tag" in tag:
         return f"jp_igemm_p9sm_kernel<{kv['WM']}, {kv['WN']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {kv['TAPS']}>"
     if "p9s_tag" in tag:

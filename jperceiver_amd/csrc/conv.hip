@@ -2114,11 +2114,13 @@ inline bool p9_m256() {
 // `ptiles` = N * (H/4) * (W/32) pixel tiles of the launch (the conv entry points know it when they pack: a layer's pack is
 // keyed by its shape on the host side); the 8-wave variant needs >= 256 workgroups or it leaves CUs empty
 // (512->512 @32x32: 141 -> 92 TF), where it has them it is 2-4 % faster (256->256 @128x128: 141 -> 146 TF)
-// JP_P1_TILE (1x1 layers with 256-row banks): 0 = 256 rows x 4x32 pixels on 8 waves (rounds 2-3); 1 = 256 rows x 8x32 pixels
-// (jp_igemm_p9s_wide_kernel<4, 2>: NJ = 4 pixel rows per wave, one workgroup per CU); 2 = 128 rows x 8x32 pixels on 4 waves
-// (jp_igemm_p9s_wide_kernel<2, 2>, two workgroups per CU; 128-row pack)
+// JP_P1_TILE (1x1 layers with 256-row banks): 0 = 256 rows x 4x32 pixels on 8 waves (rounds 2-3); 1 (default) = 256 rows x 8x32
+// pixels (jp_igemm_p9s_wide_kernel<4, 2>: NJ = 4 pixel rows per wave, one workgroup per CU: half the weight-stream bytes per MFMA);
+// 2 = 128 rows x 8x32 pixels on 4 waves (jp_igemm_p9s_wide_kernel<2, 2>, two workgroups per CU; 128-row pack).  Same box, CRP
+// 256->256 @256^2 forward / dgrad: 0.545 / 0.488 ms (0), 0.522 / 0.461 (1), 0.556 / 0.500 (2); @128^2 0.128 / 0.120, 0.121 / 0.110,
+// 0.134 / 0.118 (profiles/r04_p1_tile_ab.log).
 inline int p1_tile() {
-    static const int m = [] { const char* e = getenv("JP_P1_TILE"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char* e = getenv("JP_P1_TILE"); return e ? atoi(e) : 1; }();
     return m;
 }
 inline bool p9_wide256(int rows, long ptiles) { return p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256; }
@@ -2168,20 +2170,40 @@ template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9_tag() { return __PRETTY_FUNCTION__; }       // profiler tag naming the instantiation
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9s_tag() { return __PRETTY_FUNCTION__; }
-template <int WM, int WN, class E>
+template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS>
 const char* p9sw_tag() { return __PRETTY_FUNCTION__; }
+// JP_P9_TILE (3x3 layers): 0 = 4x32-pixel tiles (rounds 2-3), 1 = 8x32-pixel wide tiles for 256-row banks, 2 (default) = also for
+// 128-row tiles (jp_igemm_p9s_wide_kernel<2, 2, ...>, 4 waves), 3 = also 16x32-pixel tiles for 64-row banks (<1, 4, ...>).
+// Same box (profiles/r04_p9_tile_ab.log): 256->256 reflect @256^2 forward / dgrad 2.652 / 2.631 -> 2.513 / 2.496 ms (1 477-1 487 TF
+// executed = 0.59 of 2.5 PF), @128^2 0.717 / 0.677 -> 0.678 / 0.640; 128->128 @128^2 0.197 / 0.193 -> 0.189 / 0.183.
+inline int p9_tile() {
+    static const int m = [] { const char* e = getenv("JP_P9_TILE"); return e ? atoi(e) : 2; }();
+    return m;
+}
 template <bool REFLECT, bool REV, class E, int TAPS>
 void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
-    if constexpr (TAPS == 1 && !REFLECT && !REV) {
-        // wide 1x1 tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy
-        if (p1_tile() && H % 8 == 0 && bmt >= 128 && p9_wide256(rows, p9_ptiles(N, H, W)) && (long)N * (H / 8) * (W / 32) * (rows / bmt) >= 256) {
-            jp_prof_before(bmt == 256 ? p9sw_tag<4, 2, E>() : p9sw_tag<2, 2, E>(), 6.0 * 2.0 * rows * (double)N * H * W * red, st);
+    {
+        // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy
+        const int mode = TAPS == 1 ? (p1_tile() ? (bmt == 256 ? 1 : (p1_tile() == 2 ? 2 : 0)) : 0) : p9_tile();
+        if (TAPS == 9 && mode >= 3 && bmt == 64 && H % 16 == 0 && (long)N * (H / 16) * (W / 32) >= 256) {
+            jp_prof_before(p9sw_tag<1, 4, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+            hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<1, 4, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 16) * (W / 32), 1, 1), dim3(256), 0,
+                               st, wq, x, e, rows, red, NST, H, W, mt_off);
+            jp_prof_after(st);
+            return;
+        }
+        const bool want = (mode >= 1 && bmt == 256) || (mode >= 2 && bmt == 128);
+        if (want && H % 8 == 0 && (long)N * (H / 8) * (W / 32) * jp_cdiv(rows, bmt) >= 256) {
+            jp_prof_before(bmt == 256 ? p9sw_tag<4, 2, REFLECT, REV, E, TAPS>() : p9sw_tag<2, 2, REFLECT, REV, E, TAPS>(),
+                           6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
             dim3 grid(N * (H / 8) * (W / 32), jp_cdiv(rows, bmt), 1);
-            if (bmt == 256) hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<4, 2, E>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
-            else hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<2, 2, E>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+            if (bmt == 256)
+                hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+            else
+                hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
             jp_prof_after(st);
             return;
         }

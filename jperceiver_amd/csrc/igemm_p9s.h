@@ -314,12 +314,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC :
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
-// 1x1 "wide" tiles (round 4): NJ = 4 pixel rows per wave (8 rows x 32 columns per workgroup with WN = 2), B fragments re-read row
-// by row (ROWB): a wave's weight fragments serve twice the pixels, i.e. half the L2 -> CU weight-stream bytes per MFMA
-template <int WM, int WN, class Epi>
+// "wide" tiles (round 4): NJ = 4 pixel rows per wave (8 rows x 32 columns per workgroup with WN = 2), B fragments re-read row
+// by row (ROWB): a wave's weight fragments serve twice the pixels, i.e. half the L2 -> CU weight-stream bytes per MFMA, and a 3x3
+// patch carries 10 rows for 8 instead of 6 for 4
+template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9s_wide_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
-    jp_igemm_p9s_body<WM, WN, 4, false, false, Epi, 1, 2, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
+    jp_igemm_p9s_body<WM, WN, 4, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
 // small maps (pose encoder 24x80 .. 6x20, BEV 32x32 .. 8x8): masked partial tiles + split-K over grid.z; the epilogue's
 // `slice` member receives blockIdx.z (conv_p9sm.hip)
