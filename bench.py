@@ -453,7 +453,7 @@ def _kernel_name(tag):
     if "p9sd_tag" in tag:
         return f"jp_igemm_p9sd_kernel<{kv['E']}>"
     if "p9us_tag" in tag:
-        return f"jp_igemm_p9us_kernel<{kv['E']}>"
+        return f"jp_igemm_p9us_kernel<{kv['E']}, {kv.get('NJ', '2')}>"
     if "p9u_tag" in tag:
         return f"jp_igemm_p9u_kernel<{kv['E']}>"
     if "w9s_tag" in tag:

@@ -2082,7 +2082,7 @@ inline bool p9us_enabled() {
     static const int on = [] { const char* e = getenv("JP_P9US"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
-template <class E>
+template <class E, int NJ>
 const char* p9us_tag() { return __PRETTY_FUNCTION__; }
 // P9SD (igemm_p9sd.h): dgrad of the upsampled iconv segment at half resolution on the bf16 pipe; JP_P9SD=0 keeps DgradUPB
 inline bool p9sd_enabled() {
@@ -2114,13 +2114,14 @@ inline bool p9_m256() {
 // `ptiles` = N * (H/4) * (W/32) pixel tiles of the launch (the conv entry points know it when they pack: a layer's pack is
 // keyed by its shape on the host side); the 8-wave variant needs >= 256 workgroups or it leaves CUs empty
 // (512->512 @32x32: 141 -> 92 TF), where it has them it is 2-4 % faster (256->256 @128x128: 141 -> 146 TF)
-// JP_P1_TILE (1x1 layers with 256-row banks): 0 = 256 rows x 4x32 pixels on 8 waves (rounds 2-3); 1 (default) = 256 rows x 8x32
-// pixels (jp_igemm_p9s_wide_kernel<4, 2>: NJ = 4 pixel rows per wave, one workgroup per CU: half the weight-stream bytes per MFMA);
-// 2 = 128 rows x 8x32 pixels on 4 waves (jp_igemm_p9s_wide_kernel<2, 2>, two workgroups per CU; 128-row pack).  Same box, CRP
-// 256->256 @256^2 forward / dgrad: 0.545 / 0.488 ms (0), 0.522 / 0.461 (1), 0.556 / 0.500 (2); @128^2 0.128 / 0.120, 0.121 / 0.110,
-// 0.134 / 0.118 (profiles/r04_p1_tile_ab.log).
+// JP_P1_TILE (1x1 layers with 256-row banks): 0 (default) = 256 rows x 4x32 pixels on 8 waves (rounds 2-3); 1 = 256 rows x 8x32
+// pixels (jp_igemm_p9s_wide_kernel<4, 2, ..., 1, 2>: NJ = 4 pixel rows per wave, one workgroup per CU: half the weight-stream bytes
+// per MFMA); 2 = 128 rows x 8x32 pixels on 4 waves (two workgroups per CU; 128-row pack).  Same box, CRP 256->256 @256^2 forward /
+// dgrad alone: 0.545 / 0.488 ms (0), 0.522 / 0.461 (1), 0.556 / 0.500 (2); @128^2 0.128 / 0.120, 0.121 / 0.110, 0.134 / 0.118
+// (profiles/r04_p1_tile_ab.log) -- but in the overlapped step mode 1 LOSES 0.3 ms (84.69 -> 84.99 ms, r04_tile_step_ab.log: the wide
+// kernel takes a CU's whole register file, nothing of the side streams fits beside it), so it stays opt-in.
 inline int p1_tile() {
-    static const int m = [] { const char* e = getenv("JP_P1_TILE"); return e ? atoi(e) : 1; }();
+    static const int m = [] { const char* e = getenv("JP_P1_TILE"); return e ? atoi(e) : 0; }();
     return m;
 }
 inline bool p9_wide256(int rows, long ptiles) { return p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256; }
@@ -2172,12 +2173,14 @@ template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS = 9>
 const char* p9s_tag() { return __PRETTY_FUNCTION__; }
 template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS>
 const char* p9sw_tag() { return __PRETTY_FUNCTION__; }
-// JP_P9_TILE (3x3 layers): 0 = 4x32-pixel tiles (rounds 2-3), 1 = 8x32-pixel wide tiles for 256-row banks, 2 (default) = also for
-// 128-row tiles (jp_igemm_p9s_wide_kernel<2, 2, ...>, 4 waves), 3 = also 16x32-pixel tiles for 64-row banks (<1, 4, ...>).
+// JP_P9_TILE (3x3 layers): 0 = 4x32-pixel tiles (rounds 2-3), 1 = 8x32-pixel wide tiles for 256-row banks, 2 = also for
+// 128-row tiles (jp_igemm_p9s_wide_kernel<2, 2, ...>, 4 waves), 3 (default) = also 16x32-pixel tiles for 64-row banks (<1, 4, ...>:
+// 64->64 @256^2 forward / dgrad 0.229 / 0.233 -> 0.220 / 0.209 ms).  Whole step, same box, three runs each (r04_tile_step_ab.log):
+// 85.61 ms (0), 84.77 (2), 84.69 (3).
 // Same box (profiles/r04_p9_tile_ab.log): 256->256 reflect @256^2 forward / dgrad 2.652 / 2.631 -> 2.513 / 2.496 ms (1 477-1 487 TF
 // executed = 0.59 of 2.5 PF), @128^2 0.717 / 0.677 -> 0.678 / 0.640; 128->128 @128^2 0.197 / 0.193 -> 0.189 / 0.183.
 inline int p9_tile() {
-    static const int m = [] { const char* e = getenv("JP_P9_TILE"); return e ? atoi(e) : 2; }();
+    static const int m = [] { const char* e = getenv("JP_P9_TILE"); return e ? atoi(e) : 3; }();
     return m;
 }
 template <bool REFLECT, bool REV, class E, int TAPS>
@@ -2590,10 +2593,20 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                 if (c2) do_pack(PACK_SPLITSEG, w, ws + fS + fU, fD, Cout, Cin, c0 + c1, c2, 0, 0, st);
                 // (the kernel's last weight prefetch reads one step past the streams: inside the scratch, never used)
             }
-            jp_prof_before(p9us_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
-            dim3 grid(N * (H / 4) * (W / 64), MT, 1);
-            hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi>), grid, dim3(512), 0, st, reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e,
-                               Cout, c0, c1, c2, H, W);
+            // JP_P9US_TILE=1: 8 x 64-pixel tiles (4 rows per parity class and wave) where they still give >= 256 workgroups.  OFF by
+            // default: the kernel alone gains 6 % (6.03 -> 5.65 ms per step, profiles/r04_p9us_tile_ab.log) but it then holds a CU's
+            // whole register file and 65 KB of LDS (256 VGPRs, 39 of them spilled), the side streams' kernels no longer fit beside
+            // it, and the overlapped step LOSES 0.2-0.9 ms (same-box pairs 86.10 / 85.52 -> 86.32 / 86.39 ms).
+            static const bool wide_on = [] { const char* e_ = getenv("JP_P9US_TILE"); return e_ && e_[0] == '1'; }();
+            const bool wide = wide_on && H % 8 == 0 && (long)MT * N * (H / 8) * (W / 64) >= 256;
+            jp_prof_before(wide ? p9us_tag<FwdEpi, 4>() : p9us_tag<FwdEpi, 2>(),
+                           6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
+            if (wide)
+                hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 4>), dim3(N * (H / 8) * (W / 64), MT, 1), dim3(512), 0, st,
+                                   reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+            else
+                hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
+                                   reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }

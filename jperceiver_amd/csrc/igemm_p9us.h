@@ -16,16 +16,20 @@
 #pragma once
 #include "igemm_p9s.h"
 
-template <class Epi>
+// NJ = pixel rows per parity class and wave: 2 (tile 4 rows x 64 columns, rounds 3) or 4 (8 rows x 64 columns, round 4: a wave's
+// weight fragments serve twice the pixels and the patches carry 10 / 6 rows for 8 / 4 instead of 6 / 4 for 4 / 2)
+template <class Epi, int NJ = 2>
 __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* __restrict__ wp, const float* __restrict__ x0,
                                                                const float* __restrict__ x1, const float* __restrict__ x2,
                                                                Epi epi, int M, int C0, int C1, int C2, int H, int W) {
     constexpr int NT = 512;
-    constexpr int PRS = 6, PHALF = 34, PITS = 2 * PHALF, COLS_S = 66;      // S / D patch rows x [33 even | pad | 33 odd | pad]
-    constexpr int PRU = 4, PITU = 34;                                      // U patch: 4 rows x [halo | 32 | halo]
+    constexpr int TR = 2 * NJ;                                             // output rows per tile
+    constexpr int PRS = TR + 2, PHALF = 34, PITS = 2 * PHALF, COLS_S = 66; // S / D patch rows x [33 even | pad | 33 odd | pad]
+    constexpr int PRU = NJ + 2, PITU = 34;                                 // U patch: NJ + 2 rows x [halo | 32 | halo]
     constexpr int PLS = PRS * PITS, PLU = PRU * PITU;                      // 16-byte words per (split, k-half) plane
     constexpr int ITS = 2 * PRS * COLS_S, NQS = (ITS + NT - 1) / NT;       // 792 items -> 2 rounds
-    constexpr int ITU = 2 * PRU * PITU;                                    // 272 items -> 1 round
+    constexpr int ITU = 2 * PRU * PITU;                                    // 272 / 408 items -> 1 round
+    static_assert(ITU <= NT, "one staging round for the low-resolution patch");
     constexpr int SBYTES = 3 * 2 * 128 * 16;                               // bytes per weight step
     __shared__ jp_u32x4 patch[3 * 2 * PLS];
 
@@ -47,9 +51,9 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             nt = G + i / gy;
         }
     }
-    const int tiles_x = W / 64, tiles_y = H / 4;
+    const int tiles_x = W / 64, tiles_y = H / TR;
     const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
-    const int y0 = (tr_ / tiles_x) * 4, x0c = (tr_ % tiles_x) * 64;
+    const int y0 = (tr_ / tiles_x) * TR, x0c = (tr_ % tiles_x) * 64;
     const int MT = M / 128;
     const long HW = (long)H * W;
     const int h2 = H / 2, w2 = W / 2;
@@ -145,11 +149,11 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         if (lU >= 0) store_item(0, lU, PLU);
     };
 
-    jp_f32x16 acc[2][2];
+    jp_f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     const jp_u32x4* bu = patch + (lhi * PRU + py) * PITU + l31 + px;
     // B fragments of pixel row j, [split]: each half (j = 0, 1) is re-read just in time -- row j of the NEXT use is requested
     // while the 12 MFMAs of the other row run (24 registers instead of a 48-register double buffer)
-    jp_u32x4 rb[2][3];
+    jp_u32x4 rb[NJ][3];
     auto breadS = [&](int j, int tap) {
         const int ty = tap / 3, tx = tap % 3;
 #pragma unroll
@@ -191,14 +195,16 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
 #pragma unroll
         for (int u = 0; u < T; ++u) {
             aload((PAR + u + 1) & 1, u + 1 < T ? cur + (u + 1) * SBYTES : nxt);
-            if (UP) breadU(1, u); else breadS(1, u);
-            __builtin_amdgcn_sched_barrier(0);
-            JP_P9US_ROW(0);                              // the six products with split index sum <= 2, smallest terms first
-            __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < T) { if (UP) breadU(0, u + 1); else breadS(0, u + 1); }
-            __builtin_amdgcn_sched_barrier(0);
-            JP_P9US_ROW(1);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // the fragments of the row after this one are requested before this row's 12 MFMAs issue; the last row of a
+                // step requests row 0 of the next step (rb[0] is free again by then)
+                if (j + 1 < NJ) { if (UP) breadU(j + 1, u); else breadS(j + 1, u); }
+                else if (u + 1 < T) { if (UP) breadU(0, u + 1); else breadS(0, u + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                JP_P9US_ROW(j);                          // the six products with split index sum <= 2, smallest terms first
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     using P0 = std::integral_constant<int, 0>;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int m0 = mt * 128;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int p = img * (int)HW + (y0 + py + 2 * j) * W + x0c + 2 * l31 + px;
         const typename Epi::St se = epi.col(p);
 #pragma unroll

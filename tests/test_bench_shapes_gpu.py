@@ -81,15 +81,15 @@ def _split_name(w):
     if w == "WgradAP, WgradBP" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w4s_kernel<2>"                               # parity-class wgrad of the upsampled segment (igemm_w4s.h)
     if w == "jp_igemm_p9u_kernel<FwdEpi>" and os.environ.get("JP_P9US", "1") != "0":
-        return "jp_igemm_p9us_kernel<FwdEpi>"
+        return "jp_igemm_p9us_kernel<FwdEpi, "            # NJ = 2 (4 x 64-pixel tiles) or 4 (8 x 64, round 4)
     m = re.fullmatch(r"jp_igemm_p9_kernel<(\d), (\d), (\w+), (\w+), (\w+), (\d), \d>", w)
     if m is None or os.environ.get("JP_P9S", "1") == "0":
         return w
     taps = m.group(6)
-    if taps == "1" and m.group(1) == "4" and os.environ.get("JP_P1_TILE", "1") == "1":
+    if taps == "1" and m.group(1) == "4" and os.environ.get("JP_P1_TILE", "0") == "1":
         return f"jp_igemm_p9s_wide_kernel<4, 2, false, false, {m.group(5)}, 1, 2>"        # 8x32-pixel 1x1 tiles (NJ = 4), round 4
-    tile = int(os.environ.get("JP_P9_TILE", "2"))
-    if taps == "9" and ((m.group(1) == "4" and tile >= 1) or (m.group(1) == "2" and tile >= 2)):
+    tile = int(os.environ.get("JP_P9_TILE", "3"))
+    if taps == "9" and ((m.group(1) == "4" and tile >= 1) or (m.group(1) == "2" and tile >= 2) or (m.group(1) == "1" and tile >= 3)):
         # round 4: 8x32-pixel "wide" tiles where H % 8 == 0 and they still give >= 256 workgroups, the 4x32 ones elsewhere
         return (f"jp_igemm_p9s_wide_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}, 9, 1>",
                 f"jp_igemm_p9s_kernel<{m.group(1)}, {m.group(2)}, 2, {m.group(3)}, {m.group(4)}, {m.group(5)}, 9, 1>")
