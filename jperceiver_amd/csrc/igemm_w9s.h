@@ -153,9 +153,14 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         aload(0, tb, kg * KGW);
         gload(T0);
         for (int T = T0; T < T1; ++T) {
+#ifdef W9S_PROBE_NOSTAGE   // timing probe (wrong results): the X patch is staged for the first tile only
+            if (T == T0) lstore();
+            __syncthreads();
+#else
             lstore();
             __syncthreads();
             gload(T + 1);                                           // next tile's patch: in flight during the MFMAs below
+#endif
             tile_org(T + 1, img, y0, x0);
             const int tbn = (img * Cout) * (int)HW + y0 * W + x0;
 #pragma unroll
@@ -169,6 +174,9 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
                 jp_u32x4 sa[3];
                 {
                     const jp_u32x4 lo = araw[gi & 1][0], hi = araw[gi & 1][1];
+#ifdef W9S_PROBE_NOSPLIT   // timing probe (wrong results): dY is not split (raw bits as operands): the 44 VALU per K group are gone
+                    sa[0] = lo; sa[1] = hi; sa[2] = lo ^ hi;
+#else
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         unsigned s0, s1, s2;
@@ -177,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
                         jp_split3(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), s0, s1, s2);
                         sa[0][2 + k] = s0; sa[1][2 + k] = s1; sa[2][2 + k] = s2;
                     }
+#endif
                 }
                 // B fragments are read one tap ahead of the MFMAs that use them (compile-time offsets: everything is unrolled);
                 // the scheduling barriers keep the compiler from hoisting a whole K group's reads (register pressure)

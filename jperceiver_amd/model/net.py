@@ -157,7 +157,8 @@ class Baseline(nn.Module):
     def _pose_stream(self, dev):
         st = getattr(self, "_side_stream", None)
         if st is None or st.device != dev:
-            st = self._side_stream = torch.cuda.Stream(device=dev)      # on the MODEL's device, not the current one
+            # on the MODEL's device, not the current one.  JP_SIDE_PRIO = -1 gives the side stream the high hardware priority
+            st = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("JP_SIDE_PRIO", "0")))
         return st
 
     def _layout_head(self, sfx, F, f4, n_updates):
