@@ -457,7 +457,7 @@ def _kernel_name(tag):
     if "p9u_tag" in tag:
         return f"jp_igemm_p9u_kernel<{kv['E']}>"
     if "w9s_tag" in tag:
-        return f"jp_wgrad_w9s_kernel<{kv['TR']}, {kv['REFLECT']}, {kv.get('KG', '1')}>"
+        return f"jp_wgrad_w9s_kernel<{kv['TR']}, {kv['REFLECT']}, {kv.get('KG', '1')}, {kv.get('NCB', '2')}>"
     if "w9_tag" in tag:
         return f"jp_wgrad_w9_kernel<{kv['MW']}, 2, {kv['KG']}, {kv['REFLECT']}>"
     if "launch_r3" in tag:

@@ -2305,7 +2305,13 @@ static bool w9s_enabled() {
     static const bool on = [] { const char* e = getenv("JP_W9S"); return !(e && e[0] == '0'); }();
     return on;
 }
-struct W9Plan { int splits, tps, ntiles, slices, narrow, split_mfma; long need; };
+struct W9Plan { int splits, tps, ntiles, slices, narrow, split_mfma, ncb1; long need; };
+// W9S with 256 output x 32 input channels per workgroup (igemm_w9s.h NCB = 1) for layers whose output channels fill 256-row tiles;
+// JP_W9S_NCB=2 keeps the 128 x 64 tiles of round 3
+static inline bool w9s_ncb1(int Cout, int narrow) {
+    static const bool on = [] { const char* e = getenv("JP_W9S_NCB"); return !(e && e[0] == '2'); }();
+    return on && !narrow && Cout % 256 == 0;
+}
 static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W9Plan* p) {
     if (!w9_enabled() || KH != 3 || stride != 1 || pad != 1 || W % 32 || H % W9_TR || Cm < 64 || Cm % 64 || Cout < 48 ||
         (long)N * Cout * H * W * 4 >= (1L << 31))
@@ -2313,7 +2319,9 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
     p->split_mfma = w9s_enabled();
     const int ntiles = N * (H / (p->split_mfma ? (narrow ? W9S_TRN : W9S_TR) : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
-    const long out_tiles = (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128), per = (long)Cout * 9 * Cm;
+    p->ncb1 = p->split_mfma && w9s_ncb1(Cout, narrow);
+    const long out_tiles = p->ncb1 ? (long)(Cm / 32) * (Cout / 256) : (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128);
+    const long per = (long)Cout * 9 * Cm;
     static const long wgs = [] { const char* e = getenv("JP_W9_WGS"); return e ? atol(e) : 256L; }();
     long sp = std::max<long>(1, std::min<long>(wgs / std::max<long>(1, out_tiles), ntiles / 2));
     sp = std::min<long>(sp, ws_floats / (per * kg));
@@ -2329,7 +2337,7 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
 }
 template <int MW, int KG, bool REFLECT>
 const char* w9_tag() { return __PRETTY_FUNCTION__; }
-template <int TR, bool REFLECT, int KG>
+template <int TR, bool REFLECT, int KG, int NCB = 2>
 const char* w9s_tag() { return __PRETTY_FUNCTION__; }
 template <bool REFLECT>
 static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
@@ -2337,16 +2345,22 @@ static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx,
     if (p.split_mfma) {
         // executed FLOPs: 6 bf16 MFMA products per fp32 product
         const int dyb = (int)((long)N * Cout * H * W * 4);
+        const int xb = (int)std::min<long>((long)N * Cx * H * W * 4, 0x7fffffffL);       // (w9_plan: the X tensor is < 2 GiB too)
         if (p.narrow) {
             jp_prof_before(w9s_tag<W9S_TRN, REFLECT, 2>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
             dim3 grid(Cm / 64, jp_cdiv(Cout, 64), p.splits);
             hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TRN, REFLECT, 2>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                               p.ntiles, p.tps, dyb);
+                               p.ntiles, p.tps, dyb, xb);
+        } else if (p.ncb1) {
+            jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+            dim3 grid(Cm / 32, Cout / 256, p.splits);
+            hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                               p.ntiles, p.tps, dyb, xb);
         } else {
             jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
             dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
             hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                               p.ntiles, p.tps, dyb);
+                               p.ntiles, p.tps, dyb, xb);
         }
         jp_prof_after(st);
         return;
@@ -3214,7 +3228,7 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     // W9 patch kernel on the 64-aligned channels (+ a table pass for a short channel tail, e.g. 513 = 512 + 1): input patch
     // staged once per pixel tile for all 9 taps, dY fragments straight from global memory
     const int c9 = Cin / 64 * 64, tail9 = Cin - c9;
-    if (single && ws && (tail9 == 0 || (tail9 <= 32 && c9 >= 128)) &&
+    if (single && ws && (tail9 == 0 || (tail9 <= 32 && c9 >= 128)) && (long)N * Cin * H * W * 4 < (1L << 31) &&
         w9_plan(N, c9, H, W, Cout, KH, stride, pad, ws_floats, &w9)) {
         if (pad_mode == JP_PAD_REFLECT) launch_w9<true>(dy, x0, ws, N, Cin, c9, H, W, Cout, w9, st);
         else launch_w9<false>(dy, x0, ws, N, Cin, c9, H, W, Cout, w9, st);

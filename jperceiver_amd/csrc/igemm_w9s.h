@@ -25,25 +25,39 @@ typedef short jp_s16x8 __attribute__((ext_vector_type(8)));
 
 // KG = 1: M tile = 128 output channels (4 blocks).  KG = 2 (layers with <= 64 output channels): M tile = 64 channels and the
 // two wave groups take different pixel rows of the tile (K groups), writing their own partial slice 2*split + kg.
-template <int TR, bool REFLECT, int KG = 1>
+// W9S_DB (round 4): the patch is double-buffered in LDS.  The split + LDS store of tile T + 1's patch used to sit between two
+// barriers with no MFMA in flight (timing probe: staging = 12.6 % of the kernel, profiles/r04_w9s_probes.log); now it is issued
+// item by item between the taps of tile T's LAST K group, underneath its MFMAs, and a tile needs ONE barrier.
+#ifndef W9S_DB
+#define W9S_DB 1
+#endif
+// NCB = 32-channel INPUT blocks per workgroup: 2 (128 output x 64 input channels, rounds 3) or 1 (256 output x 32 input channels,
+// round 4).  The kernel is VALU-issue-sensitive (timing probes, profiles/r04_w9s_probes.log: dropping the 44-VALU dY split per K
+// group is worth 8 %, dropping the patch staging 12.6 %) and the patch staging -- address arithmetic + split of every staged X
+// value -- is its largest VALU item; with one input block per workgroup a staged value serves 256 output channels instead of 128,
+// i.e. half the staging instructions per MFMA, and no dY row is split twice.
+template <int TR, bool REFLECT, int KG = 1, int NCB = 2>
 __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
-                                                             int ntiles, int tiles_per_split, int dy_bytes) {
+                                                             int ntiles, int tiles_per_split, int dy_bytes, int x_bytes) {
     constexpr int NT = 512, PR = TR + 2, PC = 34;
     constexpr int SLOTS = PR * PC;                 // patch pixels
     constexpr int CBP = SLOTS * 64;                // bytes per (split, channel block) plane
-    constexpr int SPL = 2 * CBP;                   // bytes per split
-    constexpr int ITEMS = SLOTS * 16, NQ = (ITEMS + NT - 1) / NT;      // (pixel, channel quad) items, rounds per thread
+    constexpr int SPL = NCB * CBP;                 // bytes per split
+    constexpr int ITEMS = SLOTS * 8 * NCB, NQ = (ITEMS + NT - 1) / NT;  // (pixel, channel quad) items, rounds per thread
     constexpr int KGR = TR * 2;                    // K groups (16 pixels) per tile
-    constexpr int MB = 4 / KG, KGW = KGR / KG;     // 32-channel output blocks per M tile; K groups per wave and tile
+    constexpr int MB = 8 / (KG * NCB), KGW = KGR / KG;  // 32-channel output blocks per M tile; K groups per wave and tile
     static_assert(KG == 1 || KG == 2, "one or two K groups");
+    static_assert(NCB == 1 || NCB == 2, "one or two input-channel blocks");
     static_assert(2 * SPL + ((TR + 1) * PC + 18) * 64 + 256 < 65536, "transpose-read immediates must fit 16 bits");
     static_assert(KGW % 2 == 0 || KG == 1, "a wave group's K groups must be whole pixel rows");
-    __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
+    constexpr bool DB = W9S_DB != 0;
+    constexpr int BUFB = 3 * SPL;                  // bytes per patch buffer
+    __shared__ __attribute__((aligned(16))) unsigned char patch[(DB ? 2 : 1) * BUFB];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int ab = wave % MB, cb = (wave / MB) & 1, kg = wave / (2 * MB);
+    const int ab = wave % MB, cb = (wave / MB) % NCB, kg = wave / (NCB * MB);
     const int l31 = lane & 31, lhi = lane >> 5;
     int mt, nt, zs;
     {   // every XCD owns whole K slices, see jp_wgrad_w9_kernel
@@ -62,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         mt = tile % gy;
         nt = tile / gy;
     }
-    const int m0 = mt * 32 * MB, c0 = nt * 64;
+    const int m0 = mt * 32 * MB, c0 = nt * 32 * NCB;
     const int T0 = zs * tiles_per_split, T1 = min(ntiles, T0 + tiles_per_split);
     const int tiles_x = W / 32, tiles_img = tiles_x * (H / TR);
     const long HW = (long)H * W;
@@ -94,50 +108,67 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
             bbase[tx][rd] = cb * CBP + (kg * (KGW / 2) * PC + 8 * lhi + rr) * 64 + ((Qq ^ ((tx + 4 * rd + rr) & 7)) * 8);
+    int rbuf = 0;                                  // byte offset of the buffer the MFMAs read (0 | BUFB), toggled per tile
     auto bread = [&](int ty, int tx, int g, int s) -> jp_bf16x8 {
         const int imm = s * SPL + ((g / 2 + ty) * PC + 16 * (g % 2) + tx) * 64;
         const jp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx][0] + imm));
+            (jp_s16x4 __attribute__((address_space(3)))*)(patch + (bbase[tx][0] + rbuf) + imm));
         const jp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx][1] + imm + 256));
+            (jp_s16x4 __attribute__((address_space(3)))*)(patch + (bbase[tx][1] + rbuf) + imm + 256));
         const jp_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(jp_bf16x8, v);
     };
 
     // ---- staging: item e = t + NT*q -> (patch column, patch row, channel quad Qd of the 64 channels); lanes run along
     // the patch columns (coalesced loads), each item = 4 channels of one pixel -> three 8-byte LDS words
+    // Everything about an item that does not depend on the tile is decoded ONCE (round 4): its patch position (packed), its LDS
+    // byte offset and its channel-quad offset; a tile then costs an item two adds, the border handling and one multiply-add,
+    // and its four channel loads are buffer loads (SGPR resource of the whole X tensor + one per-lane 32-bit offset + a
+    // wave-uniform byte offset per channel: no 64-bit address arithmetic in vector registers).
     float rv[NQ][4];
+    int ipos[NQ], ilds[NQ];              // (patch column - 1) | (patch row - 1) << 16;  LDS byte offset, -1: no item
+    unsigned iq[NQ];                     // byte offset of the item's first channel inside the (image, channel block) slab
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = t + NT * q;
+        const int pcol = e % PC, rest = e / PC, prow = rest % PR, Qd = rest / PR;
+        ipos[q] = ((pcol - 1) & 0xffff) | ((prow - 1) << 16);
+        ilds[q] = e < ITEMS ? (Qd >> 3) * CBP + (prow * PC + pcol) * 64 + (((Qd & 7) ^ (pcol & 7)) * 8) : -1;
+        iq[q] = (unsigned)(4 * Qd) * (unsigned)HW * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
     auto gload = [&](int T) {
         int img, y0, x0;
         tile_org(T, img, y0, x0);
-        const float* xc = x + ((long)img * Cx + c0) * HW;
+        const long slab = ((long)img * Cx + c0) * HW * 4;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int e = t + NT * q;
-            const int pcol = e % PC, rest = e / PC, prow = rest % PR, Qd = rest / PR;
-            int yy = y0 - 1 + prow, xx = x0 - 1 + pcol;
+            int yy = y0 + (ipos[q] >> 16), xx = x0 + (int)(short)(ipos[q] & 0xffff);
             if (REFLECT) { yy = jp_reflect(yy, H); xx = jp_reflect(xx, W); }
-            const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float* p = xc + (long)(4 * Qd) * HW + (ok ? (long)yy * W + xx : 0);
+            const bool ok = ilds[q] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const unsigned lo = ok ? iq[q] + (unsigned)(yy * W + xx) * 4u : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rv[q][k] = ok ? p[(long)k * HW] : 0.f;
+            for (int k = 0; k < 4; ++k) {
+                const int ub = __builtin_amdgcn_readfirstlane((int)(slab + (long)k * HW * 4));
+                const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, lo, ub, 0));
+                rv[q][k] = ok ? v : 0.f;
+            }
         }
     };
-    auto lstore = [&]() {
+    auto lstore1 = [&](int q, int wbuf) {           // item q of the staged patch -> buffer at byte offset wbuf
+        if (ilds[q] < 0) return;
+        const int off = wbuf + ilds[q];
+        unsigned a0, a1, a2, b0, b1, b2;
+        jp_split3(rv[q][0], rv[q][1], a0, a1, a2);
+        jp_split3(rv[q][2], rv[q][3], b0, b1, b2);
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u2*>(patch + off) = u2{a0, b0};
+        *reinterpret_cast<u2*>(patch + SPL + off) = u2{a1, b1};
+        *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a2, b2};
+    };
+    auto lstore = [&](int wbuf) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = t + NT * q;
-            if (e >= ITEMS) continue;
-            const int pcol = e % PC, rest = e / PC, prow = rest % PR, Qd = rest / PR;
-            const int off = (Qd >> 3) * CBP + (prow * PC + pcol) * 64 + (((Qd & 7) ^ (pcol & 7)) * 8);
-            unsigned a0, a1, a2, b0, b1, b2;
-            jp_split3(rv[q][0], rv[q][1], a0, a1, a2);
-            jp_split3(rv[q][2], rv[q][3], b0, b1, b2);
-            typedef unsigned u2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u2*>(patch + off) = u2{a0, b0};
-            *reinterpret_cast<u2*>(patch + SPL + off) = u2{a1, b1};
-            *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a2, b2};
-        }
+        for (int q = 0; q < NQ; ++q) lstore1(q, wbuf);
     };
 
     jp_f32x16 acc[9];
@@ -152,14 +183,18 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         int tb = (img * Cout) * (int)HW + y0 * W + x0;
         aload(0, tb, kg * KGW);
         gload(T0);
+        if (DB) lstore(0);
         for (int T = T0; T < T1; ++T) {
 #ifdef W9S_PROBE_NOSTAGE   // timing probe (wrong results): the X patch is staged for the first tile only
-            if (T == T0) lstore();
+            if (!DB && T == T0) lstore(0);
             __syncthreads();
 #else
-            lstore();
-            __syncthreads();
-            gload(T + 1);                                           // next tile's patch: in flight during the MFMAs below
+            if (!DB) lstore(0);
+            __syncthreads();                                        // DB: buffer rbuf is complete, the other one is free
+            // next tile's patch: in flight during the MFMAs below.  (Issuing these loads BEHIND the dY loads of K group 1 -- vector
+            // loads return in order, a later dY wait is a wait for the patch too -- measured no gain on the wide variants and
+            // 0.233 -> 0.31 ms on the narrow one, profiles/r04_w9s_ab.log.)
+            gload(T + 1);
 #endif
             tile_org(T + 1, img, y0, x0);
             const int tbn = (img * Cout) * (int)HW + y0 * W + x0;
@@ -210,10 +245,17 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tap], 0, 0, 0);
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tap], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    // DB: one item of the NEXT tile's patch is split and stored into the other buffer behind each of the first
+                    // NQ taps of the tile's last K group -- VALU + LDS writes underneath the six MFMAs just issued
+                    if (DB && gi == KGW - 1 && tap < NQ) {
+                        lstore1(tap, rbuf ^ BUFB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             tb = tbn;
-            __syncthreads();
+            if (DB) rbuf ^= BUFB;
+            else __syncthreads();
         }
     }
 

@@ -61,10 +61,10 @@ def _split_name(w):
     import re
     mw = re.fullmatch(r"jp_wgrad_w9_kernel<2, 2, 1, (\w+)>", w)
     if mw is not None and os.environ.get("JP_W9S", "1") != "0":
-        return f"jp_wgrad_w9s_kernel<2, {mw.group(1)}, 1>"
+        return f"jp_wgrad_w9s_kernel<2, {mw.group(1)}, 1, "            # NCB = 2 (128 x 64 channel tiles) or 1 (256 x 32, round 4)
     mn = re.fullmatch(r"jp_wgrad_w9_kernel<1, 2, 2, (\w+)>", w)
     if mn is not None and os.environ.get("JP_W9S", "1") != "0":
-        return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2>"            # narrow twin: two K groups per workgroup
+        return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2, 2>"         # narrow twin: two K groups per workgroup
     if w == "jp_wgrad_w1_kernel" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w1s_kernel"
     if w.startswith("SM<"):                                          # small-map split-bf16 patch kernel (conv_p9sm.hip); JP_P9SM=0 / JP_P9S=0: generic engine
