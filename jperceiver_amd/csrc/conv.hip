@@ -2301,6 +2301,11 @@ static bool w9_enabled() {
 // keeps the exact-fp32 W9 kernel.  Its pixel tiles are W9S_TR rows high.
 constexpr int W9S_TR = 2;
 constexpr int W9S_TRN = 4;     // narrow variant (<= 64 output channels): two K groups of 2 rows each
+// pixel-tile height of the 256x32-channel variant (NCB = 1): JP_W9S_TR1 = 2 | 4
+static inline int w9s_tr1() {
+    static const int v = [] { const char* e = getenv("JP_W9S_TR1"); return e ? atoi(e) : 4; }();
+    return v == 2 ? 2 : 4;      // 4 (default): 1.5x instead of 2x patch re-staging, half the barriers: 2.738 -> 2.649 ms @256^2 (r04_w9s_ab.log)
+}
 static bool w9s_enabled() {
     static const bool on = [] { const char* e = getenv("JP_W9S"); return !(e && e[0] == '0'); }();
     return on;
@@ -2318,8 +2323,8 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
         return false;
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
     p->split_mfma = w9s_enabled();
-    const int ntiles = N * (H / (p->split_mfma ? (narrow ? W9S_TRN : W9S_TR) : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
     p->ncb1 = p->split_mfma && w9s_ncb1(Cout, narrow);
+    const int ntiles = N * (H / (p->split_mfma ? (narrow ? W9S_TRN : (p->ncb1 ? w9s_tr1() : W9S_TR)) : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
     const long out_tiles = p->ncb1 ? (long)(Cm / 32) * (Cout / 256) : (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128);
     const long per = (long)Cout * 9 * Cm;
     static const long wgs = [] { const char* e = getenv("JP_W9_WGS"); return e ? atol(e) : 256L; }();
@@ -2352,10 +2357,16 @@ static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx,
             hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TRN, REFLECT, 2>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
                                p.ntiles, p.tps, dyb, xb);
         } else if (p.ncb1) {
-            jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
             dim3 grid(Cm / 32, Cout / 256, p.splits);
-            hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                               p.ntiles, p.tps, dyb, xb);
+            if (w9s_tr1() == 4) {
+                jp_prof_before(w9s_tag<4, REFLECT, 1, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+                hipLaunchKernelGGL((jp_wgrad_w9s_kernel<4, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                                   p.ntiles, p.tps, dyb, xb);
+            } else {
+                jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+                hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                                   p.ntiles, p.tps, dyb, xb);
+            }
         } else {
             jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
             dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);

@@ -61,7 +61,8 @@ def _split_name(w):
     import re
     mw = re.fullmatch(r"jp_wgrad_w9_kernel<2, 2, 1, (\w+)>", w)
     if mw is not None and os.environ.get("JP_W9S", "1") != "0":
-        return f"jp_wgrad_w9s_kernel<2, {mw.group(1)}, 1, "            # NCB = 2 (128 x 64 channel tiles) or 1 (256 x 32, round 4)
+        # NCB = 2 (128 x 64-channel tiles, 2-row pixel tiles) or, round 4, 1 (256 x 32 channels, 4-row pixel tiles unless JP_W9S_TR1=2)
+        return (f"jp_wgrad_w9s_kernel<2, {mw.group(1)}, 1, ", f"jp_wgrad_w9s_kernel<4, {mw.group(1)}, 1, 1>")
     mn = re.fullmatch(r"jp_wgrad_w9_kernel<1, 2, 2, (\w+)>", w)
     if mn is not None and os.environ.get("JP_W9S", "1") != "0":
         return f"jp_wgrad_w9s_kernel<4, {mn.group(1)}, 2, 2>"         # narrow twin: two K groups per workgroup
