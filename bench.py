@@ -136,7 +136,7 @@ def build_runner(optd, dev, world, rank, batch_kw, step_graph=False):
     return runner, batch
 
 
-def timed_steps(runner, batch, steps, warmup, world, dev, log):
+def timed_steps(runner, batch, steps, warmup, world, dev, log, calibrate=None):
     def sync():
         if world > 1:
             dist.barrier()
@@ -147,6 +147,21 @@ def timed_steps(runner, batch, steps, warmup, world, dev, log):
         runner.train_iter(batch)
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms")
+    if calibrate is not None:
+        # --graph auto: the captured replay wins on a slow host and loses on a fast one; time a few
+        # un-timed steps each way and keep the faster issue mode for the timed region
+        for mode in (True, False):
+            runner.step_graph = mode
+            runner.train_iter(batch)
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            for _ in range(5):
+                runner.train_iter(batch)
+            torch.cuda.synchronize()
+            calibrate["graph_ms" if mode else "eager_ms"] = round((time.perf_counter() - t_c) / 5 * 1e3, 3)
+        runner.step_graph = calibrate["graph_ms"] < calibrate["eager_ms"]
+        calibrate["chosen"] = "graph" if runner.step_graph else "eager"
+        log(f"--graph auto: {calibrate}")
     sync()
     if world > 1:
         runner.hook.exposed_events = []
@@ -208,8 +223,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's, BASELINE.json)")
     ap.add_argument("--hw", type=int, default=1024)
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the whole iteration from one captured hipGraph (apis.trainer.CapturedStep); auto = on for "
-                         "single-process runs with <= 2 images per GPU (the B = 1 configs, host-bound when issued launch by launch)")
+                    help="replay the whole iteration from one captured hipGraph (apis.trainer.CapturedStep); auto = for "
+                         "single-process runs with <= 2 images per GPU, time both issue modes in the warm-up and keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -250,7 +265,9 @@ def main():
                                       split=cfg["split"], seed=1), step_graph=use_graph)
     if use_graph and args.warmup < 3:
         log("note: the captured step needs 2 eager iterations + the capture itself: --warmup < 3 puts them inside the timed region")
-    dt, out, multi = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log)
+    calib = {} if (use_graph and args.graph == "auto") else None
+    dt, out, multi = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log, calibrate=calib)
+    use_graph = bool(runner.step_graph)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     log(f"{args.steps} timed steps: {ms:.1f} ms/step, {value:.2f} images/s")
@@ -291,7 +308,7 @@ def main():
                                    f"loss_sum {cfg['loss_sum']}, occ {HW // 4}, full-res frame {cfg['full_hw'][0]}x{cfg['full_hw'][1]}",
                        "config_index": args.config, "global_batch": B * world,
                        "parallelism": f"dp{world}", "loss": float(out["log_vars"]["loss"]),
-                       "step_graph": bool(use_graph)},
+                       "step_graph": bool(use_graph), "step_graph_calibration": calib},
             "roofline": roof, "cpu_baseline": cpu, "families": fam, "secondary": sec,
         }
         if multi is not None:
