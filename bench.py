@@ -451,6 +451,8 @@ def _kernel_name(tag):
     if "p9_tag" in tag:
         taps = kv.get("TAPS", "9")          # rocprofv3 prints the defaulted TAPS / CPB arguments too: 9, 1 (3x3) or 1, 2 (1x1)
         return f"jp_igemm_p9_kernel<{kv['WM']}, {kv['WN']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {taps}, {2 if taps == '1' else 1}>"
+    if "w9s2_tag" in tag:
+        return f"jp_wgrad_w9s2_kernel<{kv['KG']}>"
     if "w1s_tag" in tag:
         return "jp_wgrad_w1s_kernel"
     if "w1_tag" in tag:

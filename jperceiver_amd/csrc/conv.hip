@@ -26,6 +26,7 @@
 #include "igemm_p9s.h"
 #include "conv_p9sm.h"
 #include "igemm_w9s.h"
+#include "igemm_w9s2.h"
 #include "igemm_p9us.h"
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
@@ -2340,6 +2341,48 @@ static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int st
     p->need = (long)p->slices * per;
     return true;
 }
+// W9S2 (igemm_w9s2.h): the 3x3 stride-2 zero-pad weight gradient of the ResNet stage transitions on the bf16 pipe; JP_W9S2=0 (or
+// JP_W9S=0) keeps the exact-fp32 generic engine.
+struct W9S2Plan { int splits, tps, ntiles, slices, kg; long need; };
+static inline bool w9s2_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, int pad_mode, long ws_floats,
+                             W9S2Plan* p) {
+    static const bool on = [] { const char* e = getenv("JP_W9S2"); return !(e && e[0] == '0'); }();
+    if (!on || !w9s_enabled() || KH != 3 || stride != 2 || pad != 1 || pad_mode == JP_PAD_REFLECT || (H & 1) || (W & 1) ||
+        (W / 2) % 32 || (H / 2) % 2 || Cm < 32 || Cm % 32 || !(Cout == 128 || Cout % 256 == 0) ||
+        (long)N * Cout * (H / 2) * (W / 2) * 4 >= (1L << 31) || (long)N * Cm * H * W * 4 >= (1L << 31))
+        return false;
+    const int kg = Cout == 128 ? 2 : 1;
+    const int ntiles = N * (H / 4) * (W / 64);
+    const long out_tiles = (long)(Cm / 32) * (kg == 2 ? 1 : Cout / 256);
+    const long per = (long)Cout * 9 * Cm;
+    long sp = std::max<long>(1, std::min<long>(256 / std::max<long>(1, out_tiles), ntiles / 4));
+    sp = std::min<long>(sp, std::min<long>(ws_floats, 16L << 20) / (per * kg));     // partial slices: at most 64 MB written + folded
+    if (sp < 1 || ntiles < 8) return false;
+    p->tps = (int)jp_cdiv(ntiles, sp);
+    p->splits = jp_cdiv(ntiles, p->tps);
+    p->ntiles = ntiles;
+    p->kg = kg;
+    p->slices = p->splits * kg;
+    p->need = (long)p->slices * per;
+    return true;
+}
+template <int KG>
+const char* w9s2_tag() { return __PRETTY_FUNCTION__; }
+static void launch_w9s2(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
+                        const W9S2Plan& p, hipStream_t st) {
+    const int dyb = (int)((long)N * Cout * (H / 2) * (W / 2) * 4), xb = (int)((long)N * Cx * H * W * 4);
+    const double fl = 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * (H / 2) * (W / 2);
+    if (p.kg == 2) {
+        jp_prof_before(w9s2_tag<2>(), fl, st);
+        hipLaunchKernelGGL((jp_wgrad_w9s2_kernel<2>), dim3(Cm / 32, 1, p.splits), dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
+                           p.ntiles, p.tps, dyb, xb);
+    } else {
+        jp_prof_before(w9s2_tag<1>(), fl, st);
+        hipLaunchKernelGGL((jp_wgrad_w9s2_kernel<1>), dim3(Cm / 32, Cout / 256, p.splits), dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm,
+                           H, W, p.ntiles, p.tps, dyb, xb);
+    }
+    jp_prof_after(st);
+}
 template <int MW, int KG, bool REFLECT>
 const char* w9_tag() { return __PRETTY_FUNCTION__; }
 template <int TR, bool REFLECT, int KG, int NCB = 2>
@@ -3235,6 +3278,19 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         else launch_w7<6>(dy, x0, dw, ws, N, H, W, w7, st);
         JP_LAUNCH_CHECK();
     }
+    W9S2Plan w92;
+    if (single && whole && ws && w9s2_plan(N, Cin, H, W, Cout, KH, stride, pad, pad_mode, ws_floats, &w92)) {
+        launch_w9s2(dy, x0, ws, N, Cin, Cin, H, W, Cout, w92, st);
+        const long total = (long)Cout * 9 * Cin;
+        const int nblk = (int)((total / 4 + 63) / 64);
+        if (w92.slices >= 64 && nblk < 2048)
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<8>, dim3(nblk), dim3(512), 0, st, ws, dw, Cout, 9 * Cin, w92.slices, Cin, 9,
+                               dw_coff, dw_ctot);
+        else
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3(nblk), dim3(64), 0, st, ws, dw, Cout, 9 * Cin, w92.slices, Cin, 9,
+                               dw_coff, dw_ctot);
+        JP_LAUNCH_CHECK();
+    }
     W9Plan w9;
     // W9 patch kernel on the 64-aligned channels (+ a table pass for a short channel tail, e.g. 513 = 512 + 1): input patch
     // staged once per pixel tile for all 9 taps, dY fragments straight from global memory
@@ -3482,7 +3538,9 @@ extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout
     const WgradPlan p = wgrad_plan(Cout, Np, (long)N * pad32(OH * OW), narrow ? 64 : 128, narrow ? 256 : 128, 3, cap);
     W9Plan w9;
     const long need9 = w9_plan(N, Cin / 64 * 64, H, W, Cout, KH, stride, pad, cap, &w9) ? w9.need : 0;
-    return std::max(std::max(p.use_ws ? p.ws_need : 0, need9), need1);
+    W9S2Plan w92;
+    const long need92 = w9s2_plan(N, Cin, H, W, Cout, KH, stride, pad, 0, cap, &w92) ? w92.need : 0;
+    return std::max(std::max(std::max(p.use_ws ? p.ws_need : 0, need9), need1), need92);
 }
 
 // ---- weight-pack recording / replay (see do_pack).  `host_jobs`: caller-owned HOST buffer of max_jobs 64-byte records.

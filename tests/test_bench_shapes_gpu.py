@@ -74,6 +74,9 @@ def _split_name(w):
     if w.startswith("STEM<"):                                        # 7x7 stem forward: P7S (igemm_p7s.h) or the generic engine's FwdBC
         on = os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0"
         return f"jp_igemm_p7s_kernel<{w[5]}" if on else ("FwdBC<7, 4>" if w[5] == "3" else "FwdBC<7, 8>")
+    if w.startswith("W9S2<"):                                        # stride-2 3x3 weight gradient: igemm_w9s2.h (round 4) or the generic engine
+        on = os.environ.get("JP_W9S2", "1") != "0" and os.environ.get("JP_W9S", "1") != "0"
+        return f"jp_wgrad_w9s2_kernel<{w[5]}>" if on else "jp_igemm_kernel"
     if w == "S2F":                                                   # stride-2 forward: patch kernel (igemm_p9s2f.h) or the generic engine
         on = os.environ.get("JP_P9S2", "1") != "0" and os.environ.get("JP_P9S", "1") != "0"
         return "jp_igemm_p9s2f_kernel" if on else "jp_igemm_kernel"
@@ -134,9 +137,11 @@ BENCH_CONV = [
      ["jp_igemm_p9_kernel<2, 2, false, true, DgradEpi, 9, 1>"],
      ["jp_wgrad_w9_kernel<2, 2, 1, false>"]),
     ("ResNet layer2.0 64->128 3x3 stride 2 @256^2", (8, 64, 256, 256, 128, 3, 2, 1, 0, 0, False),
-     ["S2F"], ["DgradS2B"], ["jp_igemm_kernel"]),
+     ["S2F"], ["DgradS2B"], ["W9S2<2>"]),
     ("ResNet layer3.0 128->256 3x3 stride 2 @128^2", (8, 128, 128, 128, 256, 3, 2, 1, 0, 0, False),
-     ["S2F"], ["DgradS2B"], ["jp_igemm_kernel"]),
+     ["S2F"], ["DgradS2B"], ["W9S2<1>"]),
+    ("ResNet layer4.0 256->512 3x3 stride 2 @64^2", (8, 256, 64, 64, 512, 3, 2, 1, 0, 0, False),
+     ["jp_igemm"], ["jp_igemm"], ["W9S2<1>"]),
     ("downsample 64->128 1x1 stride 2 @256^2", (8, 64, 256, 256, 128, 1, 2, 0, 0, 0, False), ["jp_igemm"], ["jp_igemm"], ["jp_igemm"]),
     ("stem 3->64 7x7 stride 2 @1024^2", (8, 3, 1024, 1024, 64, 7, 2, 3, 0, 0, False),
      ["STEM<3>"], [], ["jp_wgrad_w7_kernel<3>"]),

@@ -32,6 +32,8 @@ CASES = [
     ("layer4 512->512 3x3 @32^2", 8, 512, 32, 32, 512, 3, 1, 1, 0),
     ("pose layer1 64->64 3x3 @48x160 (N = 16)", 16, 64, 48, 160, 64, 3, 1, 1, 0),
     ("layer2.0 64->128 3x3 stride 2 @256^2", 8, 64, 256, 256, 128, 3, 2, 1, 0),
+    ("layer3.0 128->256 3x3 stride 2 @128^2", 8, 128, 128, 128, 256, 3, 2, 1, 0),
+    ("layer4.0 256->512 3x3 stride 2 @64^2", 8, 256, 64, 64, 512, 3, 2, 1, 0),
     ("stem 3->64 7x7 stride 2 @1024^2", 8, 3, 1024, 1024, 64, 7, 2, 3, 0),
     # small maps of the step (conv_p9sm.hip; A/B with JP_P9SM=0 / 1 / 2)
     ("small: pose layer2 128->128 3x3 @24x80 N16", 16, 128, 24, 80, 128, 3, 1, 1, 0),
