@@ -540,6 +540,12 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
         if (bias) v += bias[m];
         y[base + (size_t)m * OHW] = jp_act(v, act);
     }
+    // four consecutive pixels of channel m (16-byte aligned: the patch kernels' tiles start at multiples of 32 pixels)
+    __device__ __forceinline__ void put4(St base, int m, float4 v) const {
+        const float b = bias ? bias[m] : 0.f;
+        *reinterpret_cast<float4*>(y + base + (size_t)m * OHW) =
+            make_float4(jp_act(v.x + b, act), jp_act(v.y + b, act), jp_act(v.z + b, act), jp_act(v.w + b, act));
+    }
 };
 
 struct AtomicEpi {  // out[img][m][pix] += acc : split-K forward / dgrad on grids too small to fill the chip
@@ -687,6 +693,11 @@ struct DgradEpi {  // dx[img][ci][pix] (= or +=) acc
     __device__ __forceinline__ void put(St base, int m, float v) const {
         float* q = dx + base + (size_t)m * HW;
         *q = accumulate ? (*q + v) : v;
+    }
+    __device__ __forceinline__ void put4(St base, int m, float4 v) const {
+        float4* q = reinterpret_cast<float4*>(dx + base + (size_t)m * HW);
+        if (accumulate) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *q = v;
     }
 };
 
@@ -2220,6 +2231,20 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
         hipLaunchKernelGGL((jp_igemm_p9s_kernel<1, 4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
     } else if (bmt == 256) {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1);
+        if constexpr (TAPS == 1) {
+            // 1x1: more 16-channel groups per stage = fewer barrier pairs per MFMA (the pack's step order does not depend on KGS)
+            static const int kgs1 = [] { const char* e_ = getenv("JP_P1_KGS"); return e_ ? atoi(e_) : 2; }();
+            if (kgs1 == 4 && red % 64 == 0) {
+                hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, 4>), grid, dim3(512), 0, st, wq, x, e, rows, red, red / 64, H, W, mt_off);
+                jp_prof_after(st);
+                return;
+            }
+            if (kgs1 == 8 && red % 128 == 0) {
+                hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, 8>), grid, dim3(512), 0, st, wq, x, e, rows, red, red / 128, H, W, mt_off);
+                jp_prof_after(st);
+                return;
+            }
+        }
         hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
@@ -3572,3 +3597,9 @@ extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, voi
                            std::min(2048, njobs - off));
     JP_LAUNCH_CHECK();
 }
+
+#ifdef P9S_TRACE   // debug build only (not part of the ABI): cycle stamps of one 1x1 workgroup, tools/debug/p1_trace.py
+extern "C" int jp_debug_p9s_trace(unsigned long long* host40) {
+    return (int)hipMemcpyFromSymbol(host40, HIP_SYMBOL(jp_p9s_trace), 40 * sizeof(unsigned long long));
+}
+#endif

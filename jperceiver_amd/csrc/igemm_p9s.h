@@ -50,6 +50,29 @@ __device__ __forceinline__ float jp_gather(const __amdgpu_buffer_rsrc_t& r, unsi
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uniform_bytes, 0));
 }
 
+#ifdef P9S_TRACE    // debug build only: cycle stamps of wave 0 of one workgroup (tools/debug/p1_trace.py)
+__device__ unsigned long long jp_p9s_trace[64];
+#define JP_TR(i_) do { if (TAPS == 1 && tr_on) trc_[(i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define JP_TR(i_) do { } while (0)
+#endif
+// Epilogues that offer put4(St first_pixel, int m, float4 v) -- four CONSECUTIVE pixels of output channel m -- get the
+// TRANSPOSED accumulator tile (round 4): the MFMA operands are swapped (pixels as rows, channels as columns; the products and
+// the k order are the same, so the sums are bit-identical), a lane then holds 4 consecutive pixels of ONE channel per register
+// quad and the tile leaves as 16-byte stores -- a quarter of the store instructions of the scalar epilogue, which cost a
+// 256 x 128 tile 11 300 cycles of nothing but store issue (profiles/r04_p1_trace.log).
+template <class E, class = void>
+struct jp_has_put4 : std::false_type {};
+template <class E>
+struct jp_has_put4<E, std::void_t<decltype(&E::put4)>> : std::true_type {};
+template <bool SWAP>
+__device__ __forceinline__ jp_f32x16 jp_mfma_bf16_sw(jp_u32x4 a, jp_u32x4 b, jp_f32x16 c) {
+    if constexpr (SWAP)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, b), __builtin_bit_cast(jp_bf16x8, a), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, a), __builtin_bit_cast(jp_bf16x8, b), c, 0, 0, 0);
+}
+
 constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring of P9S_AHEAD + 1 slots)
 
 // WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
@@ -81,6 +104,15 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     constexpr int ITEMS = KH * PLANE, NQ = (ITEMS + NT - 1) / NT;
     constexpr int STEPS = TAPS * KGS;                         // (tap, group) steps per stage
     constexpr int BMT = 64 * WM;
+#ifdef P9S_NO_VEC4
+    constexpr bool VEC = false;
+#else
+    // transposed accumulators + 16-byte stores: the 4-wave 3x3 kernels only.  Same box, alone (profiles/r04_vec4_ab.log): <1,4> wide
+    // 64->64 @256^2 0.225 / 0.216 -> 0.208 / 0.204 ms, <2,2> wide 128->128 @128^2 0.176 / 0.172 -> 0.166 / 0.167; the 8-wave 3x3
+    // kernels do not care (2.469 -> 2.480) and the 1x1 kernels, whose tile is mostly stores, LOSE 2-6 % (a 16-byte store per lane
+    // covers an eighth of a 128-byte line; the scalar stores of 32 adjacent lanes cover it whole).
+    constexpr bool VEC = jp_has_put4<Epi>::value && !MASK && TAPS == 9 && WM * WN <= 4;
+#endif
     __shared__ jp_u32x4 patch[3 * KH * PLANE];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -101,6 +133,12 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             nt = G + i / gy;
         }
     }
+#ifdef P9S_TRACE
+    unsigned long long trc_[40];
+    const bool tr_on = nt == 2000 && mt == 0 && t == 0;
+    for (int i = 0; i < 40; ++i) trc_[i] = 0;
+#endif
+    JP_TR(0);
     const int tiles_x = MASK ? (W + 31) / 32 : W / 32, tiles_y = MASK ? (H + TR - 1) / TR : H / TR;
     const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
     const int y0 = (tr_ / tiles_x) * TR, x0 = (tr_ % tiles_x) * 32;
@@ -202,8 +240,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         };
 #define JP_P9S_MFMA_ROW(J_, SA_, SB_)                                                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
-            acc[i][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
-                                                                 __builtin_bit_cast(jp_bf16x8, rb[J_][SB_]), acc[i][J_], 0, 0, 0)
+            acc[i][J_] = jp_mfma_bf16_sw<VEC>(ra[(PAR * STEPS + u) % RING][i][SA_], rb[J_][SB_], acc[i][J_])
         auto run_stage = [&](auto par_tag, int stage) {
             constexpr int PAR = decltype(par_tag)::value;
             lstore();
@@ -247,14 +284,16 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         };
 #define JP_P9S_MFMA(SA_, SB_)                                                                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[(PAR * STEPS + u) % RING][i][SA_]), \
-                                                                __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
+            acc[i][j] = jp_mfma_bf16_sw<VEC>(ra[(PAR * STEPS + u) % RING][i][SA_], rb[u & 1][j][SB_], acc[i][j])
 
         // one stage; PAR = stage parity (compile-time): the weight ring slot of step u is (global step) % RING and STEPS may be odd
         auto run_stage = [&](auto par_tag, int stage) {
             constexpr int PAR = decltype(par_tag)::value;
+            JP_TR(2 + 4 * (stage & 7));
             lstore();
+            JP_TR(3 + 4 * (stage & 7));
             __syncthreads();
+            JP_TR(4 + 4 * (stage & 7));
             if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
             const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
             bload(0, 0);
@@ -276,19 +315,39 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 JP_P9S_MFMA(0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            JP_TR(5 + 4 * (stage & 7));
             __syncthreads();
         };
         static_assert(RING == 2, "two stage parities <-> two ring phases");
         gload(s_begin);
+        JP_TR(1);
         for (int stage = s_begin; stage < s_end; stage += 2) {
             run_stage(std::integral_constant<int, 0>{}, stage);
             if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
         }
     }
+    JP_TR(34);
 #undef JP_P9S_MFMA
 #undef JP_P9S_MFMA_ROW
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if constexpr (VEC) {
+        // transposed tile: col = output channel, row = pixel -> register quad k holds pixels 8k + 4*lhi + {0..3} of the row
+        static_assert(std::is_integral<typename Epi::St>::value, "put4: the column state is an element offset");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int p = img * (int)HW + (y0 + wn * NJ + j) * W + x0 + 4 * lhi;
+            const typename Epi::St se = epi.col(p);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = m0 + wm * 64 + i * 32 + l31;
+                if (m >= M) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    epi.put4(se + 8 * k, m, make_float4(acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]));
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (MASK && (y0 + wn * NJ + j >= H || x0 + l31 >= W)) continue;
@@ -307,6 +366,12 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             }
         }
     }
+    }
+#ifdef P9S_TRACE
+    JP_TR(35);
+    if (TAPS == 1 && tr_on)
+        for (int i = 0; i < 40; ++i) jp_p9s_trace[i] = trc_[i];
+#endif
 }
 
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
