@@ -2139,7 +2139,7 @@ inline int p1_tile() {
 inline bool p9_wide256(int rows, long ptiles) { return p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256; }
 inline int p9_bmt(int rows, int khw = 9, long ptiles = 0) {
     if (rows <= 64) return 64;
-    if (khw == 1 && p1_tile() == 2) return 128;
+    if (khw == 1 && p1_tile() >= 2) return 128;      // 3: the plain 4-wave <2, 2, 2> kernel on 128-row tiles (two workgroups per CU)
     return p9_wide256(rows, ptiles) ? 256 : 128;
 }
 inline long p9_ptiles(int N, int H, int W) { return (long)N * (H / 4) * (W / 32); }
@@ -2236,11 +2236,6 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
             static const int kgs1 = [] { const char* e_ = getenv("JP_P1_KGS"); return e_ ? atoi(e_) : 2; }();
             if (kgs1 == 4 && red % 64 == 0) {
                 hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, 4>), grid, dim3(512), 0, st, wq, x, e, rows, red, red / 64, H, W, mt_off);
-                jp_prof_after(st);
-                return;
-            }
-            if (kgs1 == 8 && red % 128 == 0) {
-                hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, 8>), grid, dim3(512), 0, st, wq, x, e, rows, red, red / 128, H, W, mt_off);
                 jp_prof_after(st);
                 return;
             }

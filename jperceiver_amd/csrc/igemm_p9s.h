@@ -77,6 +77,9 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 
 // WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
 // TAPS = 9 (3x3, one-pixel halo) or 1 (1x1).  KGS = 16-channel groups per stage.
+#ifndef P9S_DB
+#define P9S_DB 1           // double-buffered patch, one barrier per stage (round 4); 0: the two-barrier stage of round 3
+#endif
 #ifndef P9S_OCC
 #define P9S_OCC 2          // waves per SIMD the 4-wave variants are compiled for (3: <= 168 VGPRs, B fragments re-read per row)
 #endif
@@ -104,6 +107,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     constexpr int ITEMS = KH * PLANE, NQ = (ITEMS + NT - 1) / NT;
     constexpr int STEPS = TAPS * KGS;                         // (tap, group) steps per stage
     constexpr int BMT = 64 * WM;
+    constexpr int LSU = STEPS >= 3 ? STEPS - 3 : 0;           // P9S_DB: the step behind whose MFMAs the next stage's patch is stored
 #ifdef P9S_NO_VEC4
     constexpr bool VEC = false;
 #else
@@ -113,7 +117,14 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     // covers an eighth of a 128-byte line; the scalar stores of 32 adjacent lanes cover it whole).
     constexpr bool VEC = jp_has_put4<Epi>::value && !MASK && TAPS == 9 && WM * WN <= 4;
 #endif
-    __shared__ jp_u32x4 patch[3 * KH * PLANE];
+    // P9S_DB (round 4): the patch is double-buffered.  A stage used to be [split + LDS store, barrier, MFMAs, barrier]: the cycle
+    // stamps of a 1x1 tile (profiles/r04_p1_trace.log) show ~2 300 cycles per stage with no MFMA in flight (drain, barrier, store,
+    // barrier) next to 3 100 (1x1) / 13 800 (3x3) cycles of MFMA issue.  Now stage s + 1's patch is split and stored into the other
+    // buffer underneath the MFMAs of stage s (its loads were requested a whole stage earlier) and a stage ends in ONE barrier.
+    constexpr int BUFW = 3 * KH * PLANE;                      // 16-byte words per patch buffer
+    // (not where two buffers would cost the 4-wave kernels their second workgroup per CU: the 16x32-pixel tiles of <1, 4> wide)
+    constexpr bool DB = P9S_DB != 0 && (WM * WN == 8 || 2 * BUFW * 16 <= 80 * 1024);
+    __shared__ jp_u32x4 patch[(DB ? 2 : 1) * BUFW];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -179,7 +190,8 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
+        jp_u32x4* patch_ = patch + buf * BUFW;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (loff[q] < 0) continue;
@@ -190,9 +202,9 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
                 w0[k] = a; w1[k] = b; w2[k] = c;
             }
-            patch[loff[q]] = w0;
-            patch[KH * PLANE + loff[q]] = w1;
-            patch[2 * KH * PLANE + loff[q]] = w2;
+            patch_[loff[q]] = w0;
+            patch_[KH * PLANE + loff[q]] = w1;
+            patch_[2 * KH * PLANE + loff[q]] = w2;
         }
     };
 
@@ -232,77 +244,89 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         // B fragments of pixel row j, [split]: each row is re-read just in time -- row j of the next use is requested while the
         // MFMAs of the other rows run (12*NJ registers instead of a double buffer of 24*NJ)
         jp_u32x4 rb[NJ][3];
-        auto bload = [&](int j, int u) {
+        auto bload = [&](int buf, int j, int u) {
             const int tap = u / KGS, kg = u % KGS;
             const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) rb[j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+            for (int s = 0; s < 3; ++s) rb[j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
         };
 #define JP_P9S_MFMA_ROW(J_, SA_, SB_)                                                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
             acc[i][J_] = jp_mfma_bf16_sw<VEC>(ra[(PAR * STEPS + u) % RING][i][SA_], rb[J_][SB_], acc[i][J_])
-        auto run_stage = [&](auto par_tag, int stage) {
-            constexpr int PAR = decltype(par_tag)::value;
-            lstore();
-            __syncthreads();
-            if (stage + 1 < s_end) gload(stage + 1);
+        auto run_stage = [&](auto par_tag, auto buf_tag, int stage) {
+            constexpr int PAR = decltype(par_tag)::value, BUF = DB ? decltype(buf_tag)::value : 0;
+            if (!DB) {
+                lstore(0);
+                __syncthreads();
+                if (stage + 1 < s_end) gload(stage + 1);
+            }
             const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
-            bload(0, 0);
+            bload(BUF, 0, 0);
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) {
                 aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if (j + 1 < NJ) bload(j + 1, u);
-                    else if (u + 1 < STEPS) { /* row 0 of the next step: requested after this row's MFMAs were issued (below) */ }
+                    if (j + 1 < NJ) bload(BUF, j + 1, u);
                     __builtin_amdgcn_sched_barrier(0);
                     JP_P9S_MFMA_ROW(j, 2, 0); JP_P9S_MFMA_ROW(j, 1, 1); JP_P9S_MFMA_ROW(j, 0, 2);
                     JP_P9S_MFMA_ROW(j, 1, 0); JP_P9S_MFMA_ROW(j, 0, 1); JP_P9S_MFMA_ROW(j, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j == 0 && NJ > 1) { /* rb[0] is free again */ }
-                    if (j + 1 == NJ && u + 1 < STEPS) bload(0, u + 1);
+                    if (j + 1 == NJ && u + 1 < STEPS) bload(BUF, 0, u + 1);
+                }
+                if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
+                    lstore(BUF ^ 1);
+                    if (stage + 2 < s_end) gload(stage + 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
         };
         static_assert(RING == 2, "two stage parities <-> two ring phases");
         gload(s_begin);
+        if (DB) {
+            lstore(0);
+            if (s_begin + 1 < s_end) gload(s_begin + 1);
+            __syncthreads();
+        }
         for (int stage = s_begin; stage < s_end; stage += 2) {
-            run_stage(std::integral_constant<int, 0>{}, stage);
-            if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
+            run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, stage);
+            if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, std::integral_constant<int, 1>{}, stage + 1);
         }
     } else {
         // B fragments of step u: [j][split], compile-time LDS offsets (the step loop is fully unrolled)
         jp_u32x4 rb[2][NJ][3];
-        auto bload = [&](int slot, int u) {
+        auto bload = [&](int buf, int slot, int u) {
             const int tap = u / KGS, kg = u % KGS;
             const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) rb[slot][j][s] = bp[s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+                for (int s = 0; s < 3; ++s) rb[slot][j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
         };
 #define JP_P9S_MFMA(SA_, SB_)                                                                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
             acc[i][j] = jp_mfma_bf16_sw<VEC>(ra[(PAR * STEPS + u) % RING][i][SA_], rb[u & 1][j][SB_], acc[i][j])
 
         // one stage; PAR = stage parity (compile-time): the weight ring slot of step u is (global step) % RING and STEPS may be odd
-        auto run_stage = [&](auto par_tag, int stage) {
-            constexpr int PAR = decltype(par_tag)::value;
+        auto run_stage = [&](auto par_tag, auto buf_tag, int stage) {
+            constexpr int PAR = decltype(par_tag)::value, BUF = DB ? decltype(buf_tag)::value : 0;
             JP_TR(2 + 4 * (stage & 7));
-            lstore();
-            JP_TR(3 + 4 * (stage & 7));
-            __syncthreads();
-            JP_TR(4 + 4 * (stage & 7));
-            if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
+            if (!DB) {
+                lstore(0);
+                JP_TR(3 + 4 * (stage & 7));
+                __syncthreads();
+                JP_TR(4 + 4 * (stage & 7));
+                if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
+            }
             const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
-            bload(0, 0);
+            bload(BUF, 0, 0);
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) {
                 // operands of step u + 1 are requested before the MFMAs of step u issue: weights of step u + AHEAD (the stream
                 // continues into the next stage; the pack carries AHEAD steps of slack), B fragments of step u + 1
                 aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
-                if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
+                if (u + 1 < STEPS) bload(BUF, (u + 1) & 1, u + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
                 // (the issue order does not matter to the matrix pipe: tools/ubench/mfma_bf16_chain.hip measures 86-90 % of 2.5 PF for
@@ -314,6 +338,13 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 JP_P9S_MFMA(0, 1);
                 JP_P9S_MFMA(0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
+                    JP_TR(3 + 4 * (stage & 7));
+                    lstore(BUF ^ 1);
+                    if (stage + 2 < s_end) gload(stage + 2);
+                    JP_TR(4 + 4 * (stage & 7));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             JP_TR(5 + 4 * (stage & 7));
             __syncthreads();
@@ -321,9 +352,14 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         static_assert(RING == 2, "two stage parities <-> two ring phases");
         gload(s_begin);
         JP_TR(1);
+        if (DB) {
+            lstore(0);
+            if (s_begin + 1 < s_end) gload(s_begin + 1);
+            __syncthreads();
+        }
         for (int stage = s_begin; stage < s_end; stage += 2) {
-            run_stage(std::integral_constant<int, 0>{}, stage);
-            if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, stage + 1);
+            run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, stage);
+            if (stage + 1 < s_end) run_stage(std::integral_constant<int, (STEPS & 1)>{}, std::integral_constant<int, 1>{}, stage + 1);
         }
     }
     JP_TR(34);
