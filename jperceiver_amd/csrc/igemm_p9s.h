@@ -80,6 +80,10 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 #ifndef P9S_DB
 #define P9S_DB 1           // double-buffered patch, one barrier per stage (round 4); 0: the two-barrier stage of round 3
 #endif
+#ifndef P9S_PF1
+#define P9S_PF1 1          // stages of the 1x1 kernels' input in flight.  2 was measured (profiles/r04_p9s_pf_ab.log): no change --
+                           // the 1 900-2 500 cycles a 1x1 stage spends in its split + store are not a wait for data
+#endif
 #ifndef P9S_OCC
 #define P9S_OCC 2          // waves per SIMD the 4-wave variants are compiled for (3: <= 168 VGPRs, B fragments re-read per row)
 #endif
@@ -174,8 +178,12 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         loff[q] = e < ITEMS ? (kh * PR + pr) * COLS + col : -1;
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)((long)C * HWI * 4), 0x00020000);
-    float rv[NQ][8];
-    auto gload = [&](int stage) {
+    // PF = stages of the input in flight (P9S_DB; the 1x1 kernels may take 2, see P9S_PF1)
+    constexpr int PF = (DB && TAPS == 1) ? P9S_PF1 : 1;
+    static_assert(PF == 1 || PF == 2, "one or two stages in flight");
+    float rv_[PF][NQ][8];
+    auto gload = [&](int slot, int stage) {
+        float (&rv)[NQ][8] = rv_[slot];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #ifdef P9S_PROBE_X      // timing probe (wrong results): every stage re-reads channel k of the first one -- input traffic from L2 only
@@ -190,7 +198,8 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int slot) {
+        float (&rv)[NQ][8] = rv_[slot];
         jp_u32x4* patch_ = patch + buf * BUFW;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -256,9 +265,9 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         auto run_stage = [&](auto par_tag, auto buf_tag, int stage) {
             constexpr int PAR = decltype(par_tag)::value, BUF = DB ? decltype(buf_tag)::value : 0;
             if (!DB) {
-                lstore(0);
+                lstore(0, 0);
                 __syncthreads();
-                if (stage + 1 < s_end) gload(stage + 1);
+                if (stage + 1 < s_end) gload(0, stage + 1);
             }
             const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
             bload(BUF, 0, 0);
@@ -275,18 +284,20 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                     if (j + 1 == NJ && u + 1 < STEPS) bload(BUF, 0, u + 1);
                 }
                 if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
-                    lstore(BUF ^ 1);
-                    if (stage + 2 < s_end) gload(stage + 2);
+                    lstore(BUF ^ 1, (BUF + 1) % PF);
+                    if (stage + 1 + PF < s_end) gload((BUF + 1) % PF, stage + 1 + PF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
         };
         static_assert(RING == 2, "two stage parities <-> two ring phases");
-        gload(s_begin);
+        gload(0, s_begin);
         if (DB) {
-            lstore(0);
-            if (s_begin + 1 < s_end) gload(s_begin + 1);
+            lstore(0, 0);
+#pragma unroll
+            for (int d = 1; d <= PF; ++d)
+                if (s_begin + d < s_end) gload(d % PF, s_begin + d);
             __syncthreads();
         }
         for (int stage = s_begin; stage < s_end; stage += 2) {
@@ -313,11 +324,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             constexpr int PAR = decltype(par_tag)::value, BUF = DB ? decltype(buf_tag)::value : 0;
             JP_TR(2 + 4 * (stage & 7));
             if (!DB) {
-                lstore(0);
+                lstore(0, 0);
                 JP_TR(3 + 4 * (stage & 7));
                 __syncthreads();
                 JP_TR(4 + 4 * (stage & 7));
-                if (stage + 1 < s_end) gload(stage + 1);            // next stage's patch: in flight during the MFMAs below
+                if (stage + 1 < s_end) gload(0, stage + 1);         // next stage's patch: in flight during the MFMAs below
             }
             const int ab = __builtin_amdgcn_readfirstlane(stage * STEPS * SBYTES);
             bload(BUF, 0, 0);
@@ -340,8 +351,8 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 __builtin_amdgcn_sched_barrier(0);
                 if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
                     JP_TR(3 + 4 * (stage & 7));
-                    lstore(BUF ^ 1);
-                    if (stage + 2 < s_end) gload(stage + 2);
+                    lstore(BUF ^ 1, (BUF + 1) % PF);
+                    if (stage + 1 + PF < s_end) gload((BUF + 1) % PF, stage + 1 + PF);
                     JP_TR(4 + 4 * (stage & 7));
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -350,11 +361,13 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             __syncthreads();
         };
         static_assert(RING == 2, "two stage parities <-> two ring phases");
-        gload(s_begin);
+        gload(0, s_begin);
         JP_TR(1);
         if (DB) {
-            lstore(0);
-            if (s_begin + 1 < s_end) gload(s_begin + 1);
+            lstore(0, 0);
+#pragma unroll
+            for (int d = 1; d <= PF; ++d)
+                if (s_begin + d < s_end) gload(d % PF, s_begin + d);
             __syncthreads();
         }
         for (int stage = s_begin; stage < s_end; stage += 2) {
