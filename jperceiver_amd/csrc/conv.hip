@@ -2692,9 +2692,16 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             if (wide)
                 hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 4>), dim3(N * (H / 8) * (W / 64), MT, 1), dim3(512), 0, st,
                                    reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
-            else
-                hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
-                                   reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+            else {
+                // double-buffered patch (igemm_p9us.h P9US_DB) where the stage counts of both segments are even; JP_P9US_DB=0: off
+                static const bool db_on = [] { const char* e_ = getenv("JP_P9US_DB"); return !(e_ && e_[0] == '0'); }();
+                if (db_on && c0 % 32 == 0 && c1 % 32 == 0)
+                    hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2, true>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
+                                       reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+                else
+                    hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
+                                       reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+            }
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }

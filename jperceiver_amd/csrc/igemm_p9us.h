@@ -18,7 +18,7 @@
 
 // NJ = pixel rows per parity class and wave: 2 (tile 4 rows x 64 columns, rounds 3) or 4 (8 rows x 64 columns, round 4: a wave's
 // weight fragments serve twice the pixels and the patches carry 10 / 6 rows for 8 / 4 instead of 6 / 4 for 4 / 2)
-template <class Epi, int NJ = 2>
+template <class Epi, int NJ = 2, bool DB = false>
 __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* __restrict__ wp, const float* __restrict__ x0,
                                                                const float* __restrict__ x1, const float* __restrict__ x2,
                                                                Epi epi, int M, int C0, int C1, int C2, int H, int W) {
@@ -31,7 +31,11 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     constexpr int ITU = 2 * PRU * PITU;                                    // 272 / 408 items -> 1 round
     static_assert(ITU <= NT, "one staging round for the low-resolution patch");
     constexpr int SBYTES = 3 * 2 * 128 * 16;                               // bytes per weight step
-    __shared__ jp_u32x4 patch[3 * 2 * PLS];
+    // P9US_DB (round 4, as P9S_DB in igemm_p9s.h): two patch buffers; the NEXT stage's patch (whatever its kind) is split and stored
+    // into the other one underneath this stage's MFMAs and a stage ends in one barrier.  Needs C0 % 32 == 0 and C1 % 32 == 0 (the
+    // buffer of a stage is a compile-time parity); the host launches the single-buffer instantiation otherwise.
+    constexpr int BUFW = 3 * 2 * PLS;
+    __shared__ jp_u32x4 patch[(DB ? 2 : 1) * BUFW];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             rv[0][k] = lU >= 0 ? v : 0.f;
         }
     };
-    auto store_item = [&](int q, int loff, int plane) {
+    auto store_item = [&](jp_u32x4* patch, int q, int loff, int plane) {
         jp_u32x4 w0, w1, w2_;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -140,13 +144,23 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         patch[2 * plane + loff] = w1;
         patch[4 * plane + loff] = w2_;
     };
-    auto lstoreS = [&]() {
+    auto lstoreS = [&](int buf = 0) {
 #pragma unroll
         for (int q = 0; q < NQS; ++q)
-            if (lS[q] >= 0) store_item(q, lS[q], PLS);
+            if (lS[q] >= 0) store_item(patch + buf * BUFW, q, lS[q], PLS);
     };
-    auto lstoreU = [&]() {
-        if (lU >= 0) store_item(0, lU, PLU);
+    auto lstoreU = [&](int buf = 0) {
+        if (lU >= 0) store_item(patch + buf * BUFW, 0, lU, PLU);
+    };
+    // stage k of the whole sequence [S x NS0][U x NS1][D x (C2 ? 1 : 0)]
+    const int NSTG = NS0 + NS1 + (C2 ? 1 : 0);
+    auto gload_stage = [&](int k) {
+        if (k < NS0) gloadS(rsS, k * 16, 16);
+        else if (k < NS0 + NS1) gloadU((k - NS0) * 16);
+        else gloadS(rsD, 0, C2);
+    };
+    auto lstore_stage = [&](int k, int buf) {
+        if (k >= NS0 && k < NS0 + NS1) lstoreU(buf); else lstoreS(buf);
     };
 
     jp_f32x16 acc[2][NJ];
@@ -165,18 +179,18 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     // B fragments of pixel row j, [split]: each half (j = 0, 1) is re-read just in time -- row j of the NEXT use is requested
     // while the 12 MFMAs of the other row run (24 registers instead of a 48-register double buffer)
     jp_u32x4 rb[NJ][3];
-    auto breadS = [&](int j, int tap) {
+    auto breadS = [&](int buf, int j, int tap) {
         const int ty = tap / 3, tx = tap % 3;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const int o = s * 2 * PLS + (2 * j + ty) * PITS;
+            const int o = buf * BUFW + s * 2 * PLS + (2 * j + ty) * PITS;
             rb[j][s] = tx == 1 ? bsB[o] : bsA[o + (tx == 2 ? 1 : 0)];
         }
     };
-    auto breadU = [&](int j, int sl) {
+    auto breadU = [&](int buf, int j, int sl) {
         const int r = sl >> 1, sx = sl & 1;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) rb[j][s] = bu[s * 2 * PLU + (j + r) * PITU + sx];
+        for (int s = 0; s < 3; ++s) rb[j][s] = bu[buf * BUFW + s * 2 * PLU + (j + r) * PITU + sx];
     };
 #define JP_P9US_MFMA(J_, SA_, SB_)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                          \
@@ -187,11 +201,14 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     JP_P9US_MFMA(J_, 1, 0); JP_P9US_MFMA(J_, 0, 1); JP_P9US_MFMA(J_, 0, 0)
     // one stage of T steps (9 taps or 4 slots); weights of step u live in ring slot (PAR + u) & 1; `cur` = byte offset of the
     // stage's first step, `nxt` = first step of the stage that follows (prefetched by the last step)
-    auto run_stage = [&](auto par_tag, auto up_tag, int cur, int nxt) {
+    // (DB: `k` = the stage's index in the whole sequence, BUF = its patch buffer = k & 1)
+    auto run_stage = [&](auto par_tag, auto up_tag, int cur, int nxt, auto buf_tag, int k) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool UP = decltype(up_tag)::value;
         constexpr int T = UP ? 4 : 9;
-        if (UP) breadU(0, 0); else breadS(0, 0);
+        constexpr int BUF = DB ? decltype(buf_tag)::value : 0;
+        constexpr int LSU = T - 3;                       // the step behind whose MFMAs the next stage's patch is stored
+        if (UP) breadU(BUF, 0, 0); else breadS(BUF, 0, 0);
 #pragma unroll
         for (int u = 0; u < T; ++u) {
             aload((PAR + u + 1) & 1, u + 1 < T ? cur + (u + 1) * SBYTES : nxt);
@@ -199,10 +216,15 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             for (int j = 0; j < NJ; ++j) {
                 // the fragments of the row after this one are requested before this row's 12 MFMAs issue; the last row of a
                 // step requests row 0 of the next step (rb[0] is free again by then)
-                if (j + 1 < NJ) { if (UP) breadU(j + 1, u); else breadS(j + 1, u); }
-                else if (u + 1 < T) { if (UP) breadU(0, u + 1); else breadS(0, u + 1); }
+                if (j + 1 < NJ) { if (UP) breadU(BUF, j + 1, u); else breadS(BUF, j + 1, u); }
+                else if (u + 1 < T) { if (UP) breadU(BUF, 0, u + 1); else breadS(BUF, 0, u + 1); }
                 __builtin_amdgcn_sched_barrier(0);
                 JP_P9US_ROW(j);                          // the six products with split index sum <= 2, smallest terms first
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DB && u == LSU && k + 1 < NSTG) {
+                lstore_stage(k + 1, BUF ^ 1);
+                if (k + 2 < NSTG) gload_stage(k + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -215,34 +237,53 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     // ---- stage sequence: S x NS0 (NS0 even: the ring parity is 0 again after every pair), U x NS1, D x (C2 ? 1 : 0)
     aload(0, NS0 ? offS : offU);
     if (NS0) gloadS(rsS, 0, 16); else gloadU(0);
-    auto s_stage = [&](auto par_tag, int st) {
-        lstoreS();
+    if (DB) {
+        lstore_stage(0, 0);
+        if (1 < NSTG) gload_stage(1);
         __syncthreads();
-        if (st + 1 < NS0) gloadS(rsS, (st + 1) * 16, 16);
-        else if (NS1) gloadU(0);
-        else if (C2) gloadS(rsD, 0, C2);
+    }
+    auto s_stage = [&](auto par_tag, int st) {
+        if (!DB) {
+            lstoreS();
+            __syncthreads();
+            if (st + 1 < NS0) gloadS(rsS, (st + 1) * 16, 16);
+            else if (NS1) gloadU(0);
+            else if (C2) gloadS(rsD, 0, C2);
+        }
         const int cur = offS + st * 9 * SBYTES;
         const int nxt = st + 1 < NS0 ? cur + 9 * SBYTES : (NS1 ? offU : offD);
-        run_stage(par_tag, UPF{}, cur, nxt);
+        run_stage(par_tag, UPF{}, cur, nxt, par_tag, st);          // NS0 even: stage st's buffer = st & 1 = its ring parity tag
         __syncthreads();
     };
     for (int st = 0; st < NS0; st += 2) {         // 9 steps per stage: the ring parity alternates, a stage pair restores it
         s_stage(P0{}, st);
         s_stage(P1{}, st + 1);
     }
-    for (int st = 0; st < NS1; ++st) {
-        lstoreU();
-        __syncthreads();
-        if (st + 1 < NS1) gloadU((st + 1) * 16);
-        else if (C2) gloadS(rsD, 0, C2);
+    auto u_stage = [&](auto buf_tag, int st) {
+        if (!DB) {
+            lstoreU();
+            __syncthreads();
+            if (st + 1 < NS1) gloadU((st + 1) * 16);
+            else if (C2) gloadS(rsD, 0, C2);
+        }
         const int cur = offU + st * 4 * SBYTES;
-        run_stage(P0{}, UPT{}, cur, st + 1 < NS1 ? cur + 4 * SBYTES : offD);
+        run_stage(P0{}, UPT{}, cur, st + 1 < NS1 ? cur + 4 * SBYTES : offD, buf_tag, NS0 + st);
         __syncthreads();
+    };
+    if (DB) {                                     // NS0, NS1 even (host-checked): U stage st sits in buffer st & 1
+        for (int st = 0; st < NS1; st += 2) {
+            u_stage(P0{}, st);
+            u_stage(P1{}, st + 1);
+        }
+    } else {
+        for (int st = 0; st < NS1; ++st) u_stage(P0{}, st);
     }
     if (C2) {
-        lstoreS();
-        __syncthreads();
-        run_stage(P0{}, UPF{}, offD, offD + 9 * SBYTES);
+        if (!DB) {
+            lstoreS();
+            __syncthreads();
+        }
+        run_stage(P0{}, UPF{}, offD, offD + 9 * SBYTES, P0{}, NS0 + NS1);
     }
 #undef JP_P9US_MFMA
 #undef JP_P9US_ROW
