@@ -2693,8 +2693,10 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                 hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 4>), dim3(N * (H / 8) * (W / 64), MT, 1), dim3(512), 0, st,
                                    reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
             else {
-                // double-buffered patch (igemm_p9us.h P9US_DB) where the stage counts of both segments are even; JP_P9US_DB=0: off
-                static const bool db_on = [] { const char* e_ = getenv("JP_P9US_DB"); return !(e_ && e_[0] == '0'); }();
+                // JP_P9US_DB=1: double-buffered patch (igemm_p9us.h, DB = true) where the stage counts of both segments are even.  OFF by
+                // default: unlike the P9S kernels this one does not gain from it (same box, three pairs: 5.83 / 5.70 / 5.58 ms per step
+                // with, 5.75 / 5.69 / 5.66 without; profiles/r04_p9us_db_ab.log)
+                static const bool db_on = [] { const char* e_ = getenv("JP_P9US_DB"); return e_ && e_[0] == '1'; }();
                 if (db_on && c0 % 32 == 0 && c1 % 32 == 0)
                     hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2, true>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
                                        reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
