@@ -3603,7 +3603,7 @@ extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, voi
 }
 
 #ifdef P9S_TRACE   // debug build only (not part of the ABI): cycle stamps of one 1x1 workgroup, tools/debug/p1_trace.py
-extern "C" int jp_debug_p9s_trace(unsigned long long* host40) {
+extern "C" int dbg_p9s_trace(unsigned long long* host40) {
     return (int)hipMemcpyFromSymbol(host40, HIP_SYMBOL(jp_p9s_trace), 40 * sizeof(unsigned long long));
 }
 #endif

@@ -16,7 +16,7 @@ for it in range(3):
         y = ops.conv2d(Var(x), wv, None, 1, 0, 0, 0)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 40)()
-f = _lib.lib().cdll.jp_debug_p9s_trace
+f = _lib.lib().cdll.dbg_p9s_trace
 f.argtypes = [ctypes.c_void_p]
 assert f(ctypes.cast(buf, ctypes.c_void_p)) == 0
 t = list(buf)
