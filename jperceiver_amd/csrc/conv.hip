@@ -538,7 +538,11 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
         if (bias) v += bias[m];
+#ifdef JP_EPI_NT     // experiment: non-temporal output stores (profiles/r04_epi_nt_ab.log)
+        __builtin_nontemporal_store(jp_act(v, act), y + base + (size_t)m * OHW);
+#else
         y[base + (size_t)m * OHW] = jp_act(v, act);
+#endif
     }
     // four consecutive pixels of channel m (16-byte aligned: the patch kernels' tiles start at multiples of 32 pixels)
     __device__ __forceinline__ void put4(St base, int m, float4 v) const {
@@ -692,6 +696,9 @@ struct DgradEpi {  // dx[img][ci][pix] (= or +=) acc
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
         float* q = dx + base + (size_t)m * HW;
+#ifdef JP_EPI_NT
+        if (!accumulate) { __builtin_nontemporal_store(v, q); return; }
+#endif
         *q = accumulate ? (*q + v) : v;
     }
     __device__ __forceinline__ void put4(St base, int m, float4 v) const {
