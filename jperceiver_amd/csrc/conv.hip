@@ -3611,6 +3611,6 @@ extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, voi
 
 #ifdef P9S_TRACE   // debug build only (not part of the ABI): cycle stamps of one 1x1 workgroup, tools/debug/p1_trace.py
 extern "C" int dbg_p9s_trace(unsigned long long* host40) {
-    return (int)hipMemcpyFromSymbol(host40, HIP_SYMBOL(jp_p9s_trace), 40 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(host40, HIP_SYMBOL(jp_p9s_trace), 64 * sizeof(unsigned long long));   // host buffer: 64 entries
 }
 #endif

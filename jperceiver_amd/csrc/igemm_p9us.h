@@ -55,6 +55,20 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             nt = G + i / gy;
         }
     }
+#ifdef P9S_TRACE   // debug build: cycle stamps of wave 0 of one workgroup (tools/debug/p9us_trace.py), see igemm_p9s.h
+    unsigned long long trc_[40];
+#ifdef P9US_TRACE_WAVES   // every wave's lane 0 stamps S stages 1 and 2: [wave*8 + {start, stored, after barrier 1, issued}] x 2
+    const bool tr_on = nt == 1000 && mt == 0 && lane == 0;
+#else
+    const bool tr_on = nt == 1000 && mt == 0 && t == 0;
+#endif
+    int tr_n = 0;
+    for (int i = 0; i < 40; ++i) trc_[i] = 0;
+#define JP_UTR() do { if (tr_on && tr_n < 40) trc_[tr_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define JP_UTR() do { } while (0)
+#endif
+    JP_UTR();
     const int tiles_x = W / 64, tiles_y = H / TR;
     const int img = nt / (tiles_x * tiles_y), tr_ = nt - img * (tiles_x * tiles_y);
     const int y0 = (tr_ / tiles_x) * TR, x0c = (tr_ % tiles_x) * 64;
@@ -71,7 +85,11 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     const int avo = (lhi * 128 + wm * 64 + l31) * 16;
     jp_u32x4 ra[2][2][3];
     auto aload = [&](int slot, int byte_off) {
+#ifdef P9US_PROBE_W   // timing probe (wrong results): every step re-reads the stream's first bytes -- weight latency / bandwidth out of the picture
+        const int so = __builtin_amdgcn_readfirstlane(byte_off & 0);
+#else
         const int so = __builtin_amdgcn_readfirstlane(byte_off);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -243,9 +261,21 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         __syncthreads();
     }
     auto s_stage = [&](auto par_tag, int st) {
+#ifdef P9US_TRACE_WAVES
+        if (st == 1 || st == 2) JP_UTR();
+#else
+        if (st < 4 || st + 2 >= NS0) JP_UTR();                    // S stages 0..3 and the last two: start
+#endif
         if (!DB) {
             lstoreS();
+#ifdef P9US_TRACE_WAVES
+            if (st == 1 || st == 2) JP_UTR();
             __syncthreads();
+            if (st == 1 || st == 2) JP_UTR();
+#else
+            if (st < 4) JP_UTR();                                 // ... input arrived, split and stored
+            __syncthreads();
+#endif
             if (st + 1 < NS0) gloadS(rsS, (st + 1) * 16, 16);
             else if (NS1) gloadU(0);
             else if (C2) gloadS(rsD, 0, C2);
@@ -253,6 +283,11 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         const int cur = offS + st * 9 * SBYTES;
         const int nxt = st + 1 < NS0 ? cur + 9 * SBYTES : (NS1 ? offU : offD);
         run_stage(par_tag, UPF{}, cur, nxt, par_tag, st);          // NS0 even: stage st's buffer = st & 1 = its ring parity tag
+#ifdef P9US_TRACE_WAVES
+        if (st == 1 || st == 2) JP_UTR();
+#else
+        if (st < 4) JP_UTR();                                     // ... step loop issued
+#endif
         __syncthreads();
     };
     for (int st = 0; st < NS0; st += 2) {         // 9 steps per stage: the ring parity alternates, a stage pair restores it
@@ -260,14 +295,23 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         s_stage(P1{}, st + 1);
     }
     auto u_stage = [&](auto buf_tag, int st) {
+#ifndef P9US_TRACE_WAVES
+        if (st < 4) JP_UTR();                                     // U stages 0..3: start
+#endif
         if (!DB) {
             lstoreU();
+#ifndef P9US_TRACE_WAVES
+            if (st < 4) JP_UTR();
+#endif
             __syncthreads();
             if (st + 1 < NS1) gloadU((st + 1) * 16);
             else if (C2) gloadS(rsD, 0, C2);
         }
         const int cur = offU + st * 4 * SBYTES;
         run_stage(P0{}, UPT{}, cur, st + 1 < NS1 ? cur + 4 * SBYTES : offD, buf_tag, NS0 + st);
+#ifndef P9US_TRACE_WAVES
+        if (st < 4) JP_UTR();
+#endif
         __syncthreads();
     };
     if (DB) {                                     // NS0, NS1 even (host-checked): U stage st sits in buffer st & 1
@@ -287,6 +331,9 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     }
 #undef JP_P9US_MFMA
 #undef JP_P9US_ROW
+#ifndef P9US_TRACE_WAVES
+    JP_UTR();                                                     // K loop done
+#endif
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int m0 = mt * 128;
@@ -303,4 +350,17 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             }
         }
     }
+#ifndef P9US_TRACE_WAVES
+    JP_UTR();                                                     // epilogue done
+#endif
+#ifdef P9S_TRACE
+#ifdef P9US_TRACE_WAVES
+    if (tr_on)
+        for (int i = 0; i < 8; ++i) jp_p9s_trace[wave * 8 + i] = trc_[1 + i];
+#else
+    if (tr_on)
+        for (int i = 0; i < 40; ++i) jp_p9s_trace[i] = trc_[i];
+#endif
+#endif
+#undef JP_UTR
 }

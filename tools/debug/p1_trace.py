@@ -15,7 +15,7 @@ for it in range(3):
     with recording(Tape()):
         y = ops.conv2d(Var(x), wv, None, 1, 0, 0, 0)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 40)()
+buf = (ctypes.c_ulonglong * 64)()
 f = _lib.lib().cdll.dbg_p9s_trace
 f.argtypes = [ctypes.c_void_p]
 assert f(ctypes.cast(buf, ctypes.c_void_p)) == 0
