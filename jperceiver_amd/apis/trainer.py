@@ -138,7 +138,17 @@ class CapturedStep:
             raise RuntimeError("CapturedStep replays the stock batch_processor")
         self.m = getattr(runner.model, "module", runner.model)
         self.sig, self.static, self.graph, self.eager_done = None, None, None, 0
-        self.replays = 0
+        self.replays, self.recaptures = 0, 0
+        self._table, self._h2d_done = None, None
+
+    def _table_current(self, dev):
+        """the pack registry still serves the job table (and, through its `live` list, the scratch tensors) the graph was
+        captured with"""
+        from .. import ops
+        t = ops.PackRegistry.of(dev).table
+        if t is None or self._table is None or t is not self._table:
+            return False
+        return all(e.param is not None and e.ptr == e.param.data_ptr() for e in t[3])
 
     # ---- inputs
     def _prepare(self, data):
@@ -217,6 +227,10 @@ class CapturedStep:
             arena.dev_state = None
             if gc_was:
                 gc.enable()
+        # the graph holds RAW pointers into the pack registry's job table and every pack entry's scratch: keep them alive here (the
+        # registry drops its table whenever a conv of a new signature is recorded -- an eval / validation forward at another batch
+        # or resolution, a second model on the device) and re-capture when the registry has moved on (step()).
+        self._table = ops.PackRegistry.of(dev).table
         self.rng_calls = cap.calls
         self.bn_delta = [(b, b._pending - p0) for b, p0 in zip(bns, saved[2])]
         # the capture executed nothing: take the host-side counters back
@@ -233,15 +247,30 @@ class CapturedStep:
             self.eager_done += 1
             model_out, losses, loss = self._body()
             return self._finish(losses, loss, model_out)
+        opt, arena = r.optimizer, r.optimizer.arena
+        if self.graph is not None and not self._table_current(arena.params.device):
+            # packs were recorded / dropped since the capture (a forward with a new conv signature in between): the captured
+            # jp_pack_replay would refresh a stale job table.  The old table and scratch stay alive (self._table) until the
+            # old graph is gone; then capture again against the registry's current table.
+            import gc
+            torch.cuda.synchronize()
+            self.model_out = self.losses = self.loss = None
+            self.graph = None
+            gc.collect()
+            self.recaptures += 1
         if self.graph is None:
             self._capture()
-        opt, arena = r.optimizer, r.optimizer.arena
         g = opt.param_groups[0]
         arena.step_count += 1
+        if self._h2d_done is not None:
+            self._h2d_done.synchronize()      # the previous replay's H2D copies have read the pinned words (no-op after a resolve)
         self.state_host.copy_(torch.from_numpy(FlatArena.step_state(g["lr"], g["betas"], arena.step_count)))
         self.base_host[0] = ops.rng_step_base()
         self.state_dev.copy_(self.state_host, non_blocking=True)
         self.base_dev.copy_(self.base_host, non_blocking=True)
+        if self._h2d_done is None:
+            self._h2d_done = torch.cuda.Event()
+        self._h2d_done.record()
         self.graph.replay()
         ops.rng_advance(self.rng_calls)
         for b, d in self.bn_delta:
@@ -449,6 +478,19 @@ class Runner(object):
         live = dist.is_available() and dist.is_initialized()
         if not live or dist.get_rank() == 0:    # mmcv's CheckpointHook.after_train_epoch is @master_only
             save_checkpoint(self.model, path, optimizer=self.optimizer if save_optimizer else None, meta=meta)
+            # mmcv.Runner.save_checkpoint also points `latest.pth` at the new file (several reference configs resume from it:
+            # cfg_kitti_baseline_kitti_odom_4pugsB12_lr1e-4_ce_eigen.py:61)
+            latest = os.path.join(os.path.dirname(path) or ".", "latest.pth")
+            tmp = latest + ".tmp"
+            try:
+                if os.path.lexists(tmp):
+                    os.remove(tmp)
+                os.symlink(os.path.basename(path), tmp)
+                os.replace(tmp, latest)
+            except OSError:                     # no symlinks on this file system: a copy
+                import shutil
+                shutil.copyfile(path, tmp)
+                os.replace(tmp, latest)
         if live and dist.get_world_size() > 1:
             dist.barrier()                      # nobody resumes from / trains past a file that is still being written
         return path
@@ -488,31 +530,64 @@ class _LogHook(object):
                              lv["loss"])
 
 
+_VAL_KEYS = ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3", "scale")
+
+
+def _class1(lst):
+    """eval_hooks.py:186-199: `np.array([0., 0.]) += mean_IU(...)` then `[1]` -- class 1's entry; a one-entry list (only one class
+    in the union) broadcasts into both slots there."""
+    return float(lst[1] if len(lst) == 2 else (lst[0] if len(lst) == 1 else 0.0))
+
+
 def _validate_hook(dataset_val, cfg, logger):
-    """DistEvalMonoHook / NonDistEvalHook (mono/core/evaluation/eval_hooks.py:27-100) reduced to their numbers: after every
-    `validate_interval` epochs the eval-mode forward over `dataset_val` and the seven depth metrics with median scaling
-    (items without `gt_depth` are skipped); the training mode is restored afterwards."""
-    from .inference import evaluate_depth
+    """DistEvalMonoHook (mono/core/evaluation/eval_hooks.py:120-262, 268-327) reduced to its numbers.  After every
+    `validate_interval` epochs: the eval-mode forward over THIS rank's slice `range(rank, len(dataset), world_size)` (:128); per
+    item the seven depth metrics + `scale` with median scaling (`cfg.data['stereo_scale']` -> x36; zeros for items without
+    `gt_depth`, :203-224) and `iou_road / mAP_road` (`topview` vs `("bothS", 0, 0)`), `iou_vehicle / mAP_vehicle` (`topviewB` vs
+    `("bothD", 0, 0)`) (:181-199, 225-228); the per-item dicts are gathered on rank 0 (the reference goes through pickle files in
+    work_dir, here `all_gather_object`), averaged over the whole set (:296-326) and left in `runner.eval_result` on every rank."""
+    from ..core import evaluation as ev
     interval = int(_cfg(cfg, "validate_interval", 1))
+    data_cfg = _cfg(cfg, "data", {}) or {}
+    stereo = bool(data_cfg.get("stereo_scale", False)) if isinstance(data_cfg, dict) else bool(getattr(data_cfg, "stereo_scale", False))
 
     def hook(runner):
         if (runner.epoch + 1) % interval or dataset_val is None:
             return
+        live = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if live else (0, 1)
         m = getattr(runner.model, "module", runner.model)
         was = m.training
         m.eval()
-        batches, gts = [], []
-        for i in range(len(dataset_val)):
-            item = dataset_val[i]
-            if "gt_depth" not in item:
-                continue
-            gts.append(item["gt_depth"])
-            batches.append({k: torch.as_tensor(v).float().unsqueeze(0).cuda() for k, v in item.items()
-                            if k != "gt_depth" and not isinstance(v, str)})
-        if batches:
-            runner.eval_result = evaluate_depth(m, batches, gts)
-            if logger is not None:
-                logger.info("validation after epoch %d: %s", runner.epoch + 1, runner.eval_result[0])
+        mine = []
+        with torch.no_grad():
+            for idx in range(rank, len(dataset_val), world):
+                item = dataset_val[idx]
+                inputs = {k: torch.as_tensor(v).float().unsqueeze(0).cuda() for k, v in item.items()
+                          if k != "gt_depth" and not isinstance(v, str)}
+                out = m(inputs)
+                res = dict.fromkeys(_VAL_KEYS, 0.0)
+                if "gt_depth" in item:
+                    gt = torch.as_tensor(item["gt_depth"]).float().cuda()
+                    r = ev.eval_depth(out[("disp", 0, 0)], gt, stereo_scale=stereo)
+                    res.update({k: r[k] for k in _VAL_KEYS})
+                for name, key, tag in (("topview", ("bothS", 0, 0), "road"), ("topviewB", ("bothD", 0, 0), "vehicle")):
+                    if name in out and key in inputs:
+                        iu, prec = ev.eval_layout(out[name], inputs[key])[0]
+                        res["iou_" + tag], res["mAP_" + tag] = _class1(iu), _class1(prec)
+                mine.append((idx, res))
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+            mine = [p for part in parts for p in part]
+        mine.sort(key=lambda p: p[0])
+        if mine:
+            keys = sorted({k for _, r in mine for k in r})
+            avg = {k: float(sum(r.get(k, 0.0) for _, r in mine) / len(mine)) for k in keys}
+            avg["scale mean"] = avg.pop("scale")
+            runner.eval_result = (avg, len(mine))
+            if logger is not None and rank == 0:
+                logger.info("validation after epoch %d over %d items: %s", runner.epoch + 1, len(mine), avg)
         m.train(was)
     return hook
 
@@ -568,11 +643,9 @@ def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False, logg
 def train_mono(model, dataset_train, dataset_val, cfg, args=None, distributed=False, validate=False, logger=None):
     """trainer.py:59-73, same signature: `train.py:89-96` runs unchanged with `from jperceiver_amd.apis import train_mono`.
     Returns the runner (the reference returns None)."""
-    if logger is None:
-        import logging
-        logger = logging.getLogger("jperceiver_amd")
-        lvl = _cfg(cfg, "log_level", "INFO")
-        logger.setLevel(getattr(logging, lvl) if isinstance(lvl, str) else lvl)
+    if logger is None:          # what train.py:78 passes: handler attached, INFO on rank 0, ERROR elsewhere
+        from .env import get_root_logger
+        logger = get_root_logger(_cfg(cfg, "log_level", "INFO"))
     if distributed:
         return _dist_train(model, dataset_train, dataset_val, cfg, args, validate=validate, logger=logger)
     return _non_dist_train(model, dataset_train, dataset_val, cfg, validate=validate, logger=logger)

@@ -2202,11 +2202,37 @@ inline int p9_tile() {
     static const int m = [] { const char* e = getenv("JP_P9_TILE"); return e ? atoi(e) : 3; }();
     return m;
 }
+template <int NJ, bool REFLECT, bool REV, class E, int TAPS>
+const char* p9sx_tag() { return __PRETTY_FUNCTION__; }
+// JP_P9_X (round 5): 256-row banks on 4-wave workgroups -- 1: <NJ = 4>, two workgroups per CU; 2: <NJ = 8>, one wave per SIMD.
+// JP_P1_X: the same for the 1x1 layers.
+inline int p9_x(int taps) {
+    static const int m9 = [] { const char* e = getenv("JP_P9_X"); return e ? atoi(e) : 0; }();
+    static const int m1 = [] { const char* e = getenv("JP_P1_X"); return e ? atoi(e) : 0; }();
+    return taps == 9 ? m9 : m1;
+}
 template <bool REFLECT, bool REV, class E, int TAPS>
 void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
+    if (bmt == 256 && p9_x(TAPS)) {
+        const int xm = p9_x(TAPS);
+        if (xm == 1 && (long)N * (H / 4) * (W / 32) * jp_cdiv(rows, 256) >= 512) {
+            jp_prof_before(p9sx_tag<4, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+            hipLaunchKernelGGL((jp_igemm_p9s_x_kernel<4, 2, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1),
+                               dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+            jp_prof_after(st);
+            return;
+        }
+        if (xm == 2 && H % 8 == 0 && (long)N * (H / 8) * (W / 32) * jp_cdiv(rows, 256) >= 256) {
+            jp_prof_before(p9sx_tag<8, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+            hipLaunchKernelGGL((jp_igemm_p9s_x_kernel<8, 1, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 8) * (W / 32), jp_cdiv(rows, 256), 1),
+                               dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+            jp_prof_after(st);
+            return;
+        }
+    }
     {
         // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy
         const int mode = TAPS == 1 ? (p1_tile() ? (bmt == 256 ? 1 : (p1_tile() == 2 ? 2 : 0)) : 0) : p9_tile();

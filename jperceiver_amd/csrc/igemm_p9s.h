@@ -134,6 +134,9 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
+#ifdef P9S_PRIO      // guide, "Two waves per SIMD" item 4: the second-dispatched half of an 8-wave workgroup loses every arbitration
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int mt, nt;
     {   // XCD band order, see jp_igemm_kernel
         const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
@@ -241,6 +244,8 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             for (int s = 0; s < 3; ++s)
 #ifdef P9S_PROBE_W      // timing probe (wrong results): every step re-reads the first one -- weight stream latency / bandwidth out of the picture
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), 0, 0);
+#elif defined(P9S_PROBE_AHALF)   // timing probe (wrong results): half the weight-stream bytes through the vector memory pipe
+                ra[slot][i][s] = i ? ra[slot][0][s] : __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + s * (2 * BMT * 16), step_bytes, 0);
 #else
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
 #endif
@@ -256,6 +261,9 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         auto bload = [&](int buf, int j, int u) {
             const int tap = u / KGS, kg = u % KGS;
             const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
+#ifdef P9S_PROBE_NOB    // timing probe (wrong results): B fragments read once per stage -- LDS read traffic out of the picture
+            if (u) return;
+#endif
 #pragma unroll
             for (int s = 0; s < 3; ++s) rb[j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
         };
@@ -283,11 +291,13 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                     __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 == NJ && u + 1 < STEPS) bload(BUF, 0, u + 1);
                 }
+#ifndef P9S_PROBE_NOSTG  // (timing probe, wrong results: no staging after the first stage)
                 if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
                     lstore(BUF ^ 1, (BUF + 1) % PF);
                     if (stage + 1 + PF < s_end) gload((BUF + 1) % PF, stage + 1 + PF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
             }
             __syncthreads();
         };
@@ -435,6 +445,16 @@ template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9s_wide_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, 4, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
+}
+// round 5 experiments on the 256-row banks (JP_P9_X): the two waves of a SIMD no longer belong to one workgroup.
+//  X: 4 waves x (64 channels x 4 rows x 32 px), TWO independent workgroups per CU -- their barriers / prologues / epilogues are not
+//     in phase, so one workgroup's stall is the other's matrix time;
+//  Z: 4 waves x (64 channels x 8 rows x 32 px), ONE wave per SIMD with the whole 512-register file (16 accumulators): half the
+//     weight-stream bytes per MFMA again, everything software-pipelined inside one instruction stream.
+template <int NJ, int OCC, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
+__global__ __launch_bounds__(256, OCC) void jp_igemm_p9s_x_kernel(
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
+    jp_igemm_p9s_body<4, 1, NJ, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
 // small maps (pose encoder 24x80 .. 6x20, BEV 32x32 .. 8x8): masked partial tiles + split-K over grid.z; the epilogue's
 // `slice` member receives blockIdx.z (conv_p9sm.hip)

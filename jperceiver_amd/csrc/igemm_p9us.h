@@ -41,6 +41,9 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 2, py = (wave >> 1) & 1, px = wave & 1, cls = wave & 3;
     const int l31 = lane & 31, lhi = lane >> 5;
+#ifdef P9S_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int mt, nt;
     {   // XCD band order, see jp_igemm_kernel
         const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     }
 #ifdef P9S_TRACE   // debug build: cycle stamps of wave 0 of one workgroup (tools/debug/p9us_trace.py), see igemm_p9s.h
     unsigned long long trc_[40];
-#ifdef P9US_TRACE_WAVES   // every wave's lane 0 stamps S stages 1 and 2: [wave*8 + {start, stored, after barrier 1, issued}] x 2
+#if defined(P9US_TRACE_WAVES) || defined(P9US_TRACE_STEPS)   // every wave's lane 0 stamps S stages 1 and 2: [wave*8 + {start, stored, after barrier 1, issued}] x 2
     const bool tr_on = nt == 1000 && mt == 0 && lane == 0;
 #else
     const bool tr_on = nt == 1000 && mt == 0 && t == 0;
@@ -93,7 +96,12 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * 128 * 16), so, 0);
+            for (int s = 0; s < 3; ++s)
+#ifdef P9S_PROBE_AHALF   // timing probe (wrong results): half the weight-stream bytes through the vector memory pipe
+                ra[slot][i][s] = i ? ra[slot][0][s] : __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + s * (2 * 128 * 16), so, 0);
+#else
+                ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * 128 * 16), so, 0);
+#endif
     };
 
     // ---- staging registers (union of the three stage kinds): item = 8 channels of one patch pixel
@@ -198,6 +206,9 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     // while the 12 MFMAs of the other row run (24 registers instead of a 48-register double buffer)
     jp_u32x4 rb[NJ][3];
     auto breadS = [&](int buf, int j, int tap) {
+#ifdef P9S_PROBE_NOB     // timing probe (wrong results): B fragments read once per stage
+        if (tap) return;
+#endif
         const int ty = tap / 3, tx = tap % 3;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -206,6 +217,9 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         }
     };
     auto breadU = [&](int buf, int j, int sl) {
+#ifdef P9S_PROBE_NOB
+        if (sl) return;
+#endif
         const int r = sl >> 1, sx = sl & 1;
 #pragma unroll
         for (int s = 0; s < 3; ++s) rb[j][s] = bu[buf * BUFW + s * 2 * PLU + (j + r) * PITU + sx];
@@ -229,6 +243,9 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         if (UP) breadU(BUF, 0, 0); else breadS(BUF, 0, 0);
 #pragma unroll
         for (int u = 0; u < T; ++u) {
+#ifdef P9US_TRACE_STEPS
+            if (!UP && k == 2) JP_UTR();
+#endif
             aload((PAR + u + 1) & 1, u + 1 < T ? cur + (u + 1) * SBYTES : nxt);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -261,14 +278,24 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         __syncthreads();
     }
     auto s_stage = [&](auto par_tag, int st) {
-#ifdef P9US_TRACE_WAVES
+#ifdef P9US_TRACE_STEPS
+        if (st == 2) JP_UTR();
+#elif defined(P9US_TRACE_WAVES)
         if (st == 1 || st == 2) JP_UTR();
 #else
         if (st < 4 || st + 2 >= NS0) JP_UTR();                    // S stages 0..3 and the last two: start
 #endif
         if (!DB) {
+#ifdef P9S_PROBE_NOSTG   // timing probe (wrong results): no staging after the first stage (the barriers stay)
+            if (st == 0) lstoreS();
+#else
             lstoreS();
-#ifdef P9US_TRACE_WAVES
+#endif
+#ifdef P9US_TRACE_STEPS
+            if (st == 2) JP_UTR();
+            __syncthreads();
+            if (st == 2) JP_UTR();
+#elif defined(P9US_TRACE_WAVES)
             if (st == 1 || st == 2) JP_UTR();
             __syncthreads();
             if (st == 1 || st == 2) JP_UTR();
@@ -276,14 +303,21 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             if (st < 4) JP_UTR();                                 // ... input arrived, split and stored
             __syncthreads();
 #endif
+#ifndef P9S_PROBE_NOSTG
             if (st + 1 < NS0) gloadS(rsS, (st + 1) * 16, 16);
             else if (NS1) gloadU(0);
             else if (C2) gloadS(rsD, 0, C2);
+#endif
         }
         const int cur = offS + st * 9 * SBYTES;
         const int nxt = st + 1 < NS0 ? cur + 9 * SBYTES : (NS1 ? offU : offD);
         run_stage(par_tag, UPF{}, cur, nxt, par_tag, st);          // NS0 even: stage st's buffer = st & 1 = its ring parity tag
-#ifdef P9US_TRACE_WAVES
+#ifdef P9US_TRACE_STEPS
+        if (st == 2) JP_UTR();
+        __syncthreads();
+        if (st == 2) JP_UTR();
+        return;
+#elif defined(P9US_TRACE_WAVES)
         if (st == 1 || st == 2) JP_UTR();
 #else
         if (st < 4) JP_UTR();                                     // ... step loop issued
@@ -295,21 +329,25 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
         s_stage(P1{}, st + 1);
     }
     auto u_stage = [&](auto buf_tag, int st) {
-#ifndef P9US_TRACE_WAVES
+#if !defined(P9US_TRACE_WAVES) && !defined(P9US_TRACE_STEPS)
         if (st < 4) JP_UTR();                                     // U stages 0..3: start
 #endif
         if (!DB) {
+#ifndef P9S_PROBE_NOSTG
             lstoreU();
-#ifndef P9US_TRACE_WAVES
+#endif
+#if !defined(P9US_TRACE_WAVES) && !defined(P9US_TRACE_STEPS)
             if (st < 4) JP_UTR();
 #endif
             __syncthreads();
+#ifndef P9S_PROBE_NOSTG
             if (st + 1 < NS1) gloadU((st + 1) * 16);
             else if (C2) gloadS(rsD, 0, C2);
+#endif
         }
         const int cur = offU + st * 4 * SBYTES;
         run_stage(P0{}, UPT{}, cur, st + 1 < NS1 ? cur + 4 * SBYTES : offD, buf_tag, NS0 + st);
-#ifndef P9US_TRACE_WAVES
+#if !defined(P9US_TRACE_WAVES) && !defined(P9US_TRACE_STEPS)
         if (st < 4) JP_UTR();
 #endif
         __syncthreads();
@@ -331,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
     }
 #undef JP_P9US_MFMA
 #undef JP_P9US_ROW
-#ifndef P9US_TRACE_WAVES
+#if !defined(P9US_TRACE_WAVES) && !defined(P9US_TRACE_STEPS)
     JP_UTR();                                                     // K loop done
 #endif
 
@@ -350,11 +388,14 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us_kernel(const unsigned* _
             }
         }
     }
-#ifndef P9US_TRACE_WAVES
+#if !defined(P9US_TRACE_WAVES) && !defined(P9US_TRACE_STEPS)
     JP_UTR();                                                     // epilogue done
 #endif
 #ifdef P9S_TRACE
-#ifdef P9US_TRACE_WAVES
+#ifdef P9US_TRACE_STEPS      // waves 0, 1 (older) and 4, 5 (younger): 16 stamps each
+    if (tr_on && (wave & 3) < 2)
+        for (int i = 0; i < 16; ++i) jp_p9s_trace[((wave >> 2) * 2 + (wave & 3)) * 16 + i] = trc_[1 + i];
+#elif defined(P9US_TRACE_WAVES)
     if (tr_on)
         for (int i = 0; i < 8; ++i) jp_p9s_trace[wave * 8 + i] = trc_[1 + i];
 #else

@@ -115,12 +115,14 @@ def test_epoch_numbering_train_save_resume_matches_mmcv(tmp_path):
     runner.after_train_epoch_hooks.append(lambda r: seen.append(("after_epoch", r.epoch)))
     runner.train_epoch(Loader())
     assert runner.epoch == 1 and runner.iter == 3
-    assert sorted(os.listdir(tmp_path)) == ["epoch_1.pth"]
+    assert sorted(os.listdir(tmp_path)) == ["epoch_1.pth", "latest.pth"]
+    assert os.path.realpath(tmp_path / "latest.pth") == os.path.realpath(tmp_path / "epoch_1.pth")     # mmcv's `latest.pth` link
     ck = torch.load(os.path.join(tmp_path, "epoch_1.pth"), weights_only=False)
     assert ck["meta"]["epoch"] == 1 and ck["meta"]["iter"] == 3
     assert seen[0] == ("set_epoch", 0) and seen[1] == ("iter", 0, 1e-4) and seen[-1] == ("after_epoch", 0)
     runner.train_epoch(Loader())                             # second epoch: lr halves at epoch index 1
-    assert sorted(os.listdir(tmp_path)) == ["epoch_1.pth", "epoch_2.pth"]
+    assert sorted(os.listdir(tmp_path)) == ["epoch_1.pth", "epoch_2.pth", "latest.pth"]
+    assert torch.load(tmp_path / "latest.pth", weights_only=False)["meta"]["epoch"] == 2     # the configs' resume_from='.../latest.pth'
     assert ("iter", 1, 5e-5) in seen and ("set_epoch", 1) in seen
     # resume from the first file in a fresh runner: continues with epoch index 1, i.e. lr 5e-5, then writes epoch_2
     model2 = _model()
@@ -132,5 +134,5 @@ def test_epoch_numbering_train_save_resume_matches_mmcv(tmp_path):
     r2.train_iter = lambda batch: lrs.append(r2.current_lr()[0])
     r2.train_epoch(Loader())
     assert lrs == [5e-5] * 3 and r2.epoch == 2
-    assert os.listdir(tmp_path / "resumed") == ["epoch_2.pth"]
+    assert sorted(os.listdir(tmp_path / "resumed")) == ["epoch_2.pth", "latest.pth"]
     assert torch.load(tmp_path / "resumed" / "epoch_2.pth", weights_only=False)["meta"]["epoch"] == 2

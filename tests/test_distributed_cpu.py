@@ -254,9 +254,9 @@ def test_train_mono_world2_epochs_shards_checkpoint_resume(tmp_path):
             assert lr == (1e-2 if e == 0 else 5e-3)
     assert [idx for e, _, idx in f0[3] if e == 0] != [idx for e, _, idx in f0[3] if e == 1]      # set_epoch reshuffles
     files = sorted(os.listdir(tmp_path))
-    assert files == ["epoch_1.pth", "epoch_2.pth", "r"], files    # no temp files left, one writer
+    assert files == ["epoch_1.pth", "epoch_2.pth", "latest.pth", "r"], files    # no temp files left, one writer
     ck = torch.load(tmp_path / "epoch_2.pth", weights_only=False)
     assert ck["meta"]["epoch"] == 2 and ck["meta"]["iter"] == 6 and list(ck["state_dict"]) == ["w"]
     assert r0[:2] == r1[:2] == (3, 9)                           # resumed at epoch 1 / iter 3, trained epochs 1 and 2
     assert [e for e, _, _ in r0[2]] == [1] * 3 + [2] * 3 and {lr for _, lr, _ in r0[2]} == {5e-3}
-    assert sorted(os.listdir(tmp_path / "r")) == ["epoch_2.pth", "epoch_3.pth"]
+    assert sorted(os.listdir(tmp_path / "r")) == ["epoch_2.pth", "epoch_3.pth", "latest.pth"]

@@ -163,3 +163,58 @@ def test_standalone_pose_nets_repack_after_in_place_weight_load():
         for n, t in dec.state_dict().items():
             t.copy_(ck_a["state_dict"]["PoseDecoder." + n])
     assert torch.equal(pose_between(enc, dec, f0, f1), T_a)
+
+
+def test_validate_hook_reports_depth_and_layout_metrics_like_the_eval_hook():
+    """VERDICT r04 missing 6: `train_mono(validate=True)`'s hook == DistEvalMonoHook (mono/core/evaluation/eval_hooks.py:120-262,
+    268-327) on its numbers: the rank-strided slice, the seven depth metrics + `scale mean` (zeros for items without gt_depth),
+    `iou_road / mAP_road / iou_vehicle / mAP_vehicle` = class 1 of mean_IU / mean_precision of argmax(topview[B]) against
+    bothS / bothD, averaged over the set."""
+    from types import SimpleNamespace
+    from jperceiver_amd.apis.trainer import _validate_hook
+    from jperceiver_amd.core import evaluation as ev
+    HW = 256
+    opt = J.default_opt(frame_ids=[0, -1, 1], imgs_per_gpu=1, height=HW, width=HW, occ_map_size=HW // 4, type="Argo_both",
+                        split="argo", loss_weightS=20, loss2_weightS=20)
+    model = MONO.module_dict["Baseline"](opt)
+    model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=3, bn_stats=True))
+    model = model.to(DEV).train()
+    gen = np.random.default_rng(7)
+    items = []
+    for i in range(3):
+        b = syn.make_batch(1, HW, HW, [0, -1, 1], HW // 4, (129, 154), "argo", seed=20 + i)
+        it = {k: v[0].numpy() for k, v in b.items() if isinstance(v, torch.Tensor)}
+        if i != 1:                                                   # item 1 has no LiDAR: zeros in the depth columns
+            gt = gen.uniform(0.0, 90.0, size=(129, 154)).astype(np.float32)
+            gt[gen.uniform(size=gt.shape) < 0.5] = 0.0
+            it["gt_depth"] = gt
+        items.append(it)
+    cfg = dict(validate_interval=1, data=dict(stereo_scale=False))
+    runner = SimpleNamespace(model=model, epoch=0, eval_result=None)
+    _validate_hook(items, cfg, None)(runner)
+    avg, n = runner.eval_result
+    assert n == 3 and model.training                                # training mode restored
+    # the same numbers from the metric entry points, item by item
+    model.eval()
+    exp = {k: 0.0 for k in avg}
+    with torch.no_grad():
+        for it in items:
+            inp = {k: torch.as_tensor(v).float().unsqueeze(0).to(DEV) for k, v in it.items() if k != "gt_depth"}
+            out = model(inp)
+            if "gt_depth" in it:
+                r = ev.eval_depth(out[("disp", 0, 0)], torch.as_tensor(it["gt_depth"]).to(DEV))
+                for k in ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"):
+                    exp[k] += r[k] / 3
+                exp["scale mean"] += r["scale"] / 3
+            for name, key, tag in (("topview", ("bothS", 0, 0), "road"), ("topviewB", ("bothD", 0, 0), "vehicle")):
+                pred = out[name].argmax(1)[0].cpu().numpy()
+                true = it[key].reshape(pred.shape)
+                iu = np.array([0., 0.]) + np.asarray(ev.mean_IU(pred, true))         # the hook's broadcast-add, then [1]
+                pr = np.array([0., 0.]) + np.asarray(ev.mean_precision(pred, true))
+                exp["iou_" + tag] += iu[1] / 3
+                exp["mAP_" + tag] += pr[1] / 3
+    assert set(avg) == {"abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3", "scale mean", "iou_road", "mAP_road",
+                        "iou_vehicle", "mAP_vehicle"}
+    for k in avg:
+        assert avg[k] == pytest.approx(exp[k], rel=1e-6, abs=1e-9), k
+    assert avg["abs_rel"] > 0 and 0 <= avg["iou_road"] <= 1

@@ -150,6 +150,6 @@ if __name__ == "__main__":
     if a.acc:
         accuracy()
     for c in CASES:
-        if a.only and a.only not in c[0]:
+        if a.only and not any(pat in c[0] for pat in a.only.split(",")):
             continue
         run_case(c, a.iters)
