@@ -440,6 +440,9 @@ def _kernel_name(tag):
     parts.append(cur.strip())
     kv = dict(p.split(" = ", 1) for p in parts if " = " in p)
     kv = {k: v.replace("(anonymous namespace)::", "") for k, v in kv.items()}
+    if "p9sx_tag" in tag:
+        taps = kv.get("TAPS", "1")
+        return f"jp_igemm_p9s_x_kernel<{kv['NJ']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {taps}>"
     if "p9sw_tag" in tag:
         taps = kv.get("TAPS", "1")
         return f"jp_igemm_p9s_wide_kernel<{kv['WM']}, {kv['WN']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {taps}, {1 if taps == '9' else 2}>"
@@ -471,6 +474,8 @@ def _kernel_name(tag):
         return f"jp_wgrad_w4s_kernel<{kv['TR']}>"
     if "p9sd_tag" in tag:
         return f"jp_igemm_p9sd_kernel<{kv['E']}>"
+    if "p9us2_tag" in tag:
+        return f"jp_igemm_p9us2_kernel<{kv['E']}>"
     if "p9us_tag" in tag:
         return f"jp_igemm_p9us_kernel<{kv['E']}, {kv.get('NJ', '2')}>"
     if "p9u_tag" in tag:

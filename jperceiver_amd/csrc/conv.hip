@@ -28,6 +28,7 @@
 #include "igemm_w9s.h"
 #include "igemm_w9s2.h"
 #include "igemm_p9us.h"
+#include "igemm_p9us2.h"
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
 #include "igemm_p9s2d.h"
@@ -2103,6 +2104,8 @@ inline bool p9us_enabled() {
 }
 template <class E, int NJ>
 const char* p9us_tag() { return __PRETTY_FUNCTION__; }
+template <class E>
+const char* p9us2_tag() { return __PRETTY_FUNCTION__; }
 // P9SD (igemm_p9sd.h): dgrad of the upsampled iconv segment at half resolution on the bf16 pipe; JP_P9SD=0 keeps DgradUPB
 inline bool p9sd_enabled() {
     static const int on = [] { const char* e = getenv("JP_P9SD"); return e ? atoi(e) : 1; }();
@@ -2718,6 +2721,16 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             // default: the kernel alone gains 6 % (6.03 -> 5.65 ms per step, profiles/r04_p9us_tile_ab.log) but it then holds a CU's
             // whole register file and 65 KB of LDS (256 VGPRs, 39 of them spilled), the side streams' kernels no longer fit beside
             // it, and the overlapped step LOSES 0.2-0.9 ms (same-box pairs 86.10 / 85.52 -> 86.32 / 86.39 ms).
+            // P9US2 (round 5, igemm_p9us2.h): the same tiles and arithmetic with every operand request inside an MFMA pair's shadow
+            // and the next patch staged by the half of the workgroup that is not on the pipe; JP_P9US2=0 keeps the round-3 stream
+            static const bool v2_on = [] { const char* e_ = getenv("JP_P9US2"); return !(e_ && e_[0] == '0'); }();
+            if (v2_on && c0 % 32 == 0 && c1 % 32 == 0) {
+                jp_prof_before(p9us2_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
+                hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
+                                   reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+                jp_prof_after(st);
+                JP_LAUNCH_CHECK();
+            }
             static const bool wide_on = [] { const char* e_ = getenv("JP_P9US_TILE"); return e_ && e_[0] == '1'; }();
             const bool wide = wide_on && H % 8 == 0 && (long)MT * N * (H / 8) * (W / 64) >= 256;
             jp_prof_before(wide ? p9us_tag<FwdEpi, 4>() : p9us_tag<FwdEpi, 2>(),

@@ -85,6 +85,8 @@ def _split_name(w):
     if w == "WgradAP, WgradBP" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w4s_kernel<2>"                               # parity-class wgrad of the upsampled segment (igemm_w4s.h)
     if w == "jp_igemm_p9u_kernel<FwdEpi>" and os.environ.get("JP_P9US", "1") != "0":
+        if os.environ.get("JP_P9US2", "1") != "0":
+            return "jp_igemm_p9us2_kernel<FwdEpi>"         # round 5: the re-laid instruction stream (igemm_p9us2.h)
         return "jp_igemm_p9us_kernel<FwdEpi, "            # NJ = 2 (4 x 64-pixel tiles) or 4 (8 x 64, round 4)
     m = re.fullmatch(r"jp_igemm_p9_kernel<(\d), (\d), (\w+), (\w+), (\w+), (\d), \d>", w)
     if m is None or os.environ.get("JP_P9S", "1") == "0":

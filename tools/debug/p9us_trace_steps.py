@@ -22,9 +22,12 @@ f.argtypes = [ctypes.c_void_p]
 assert f(ctypes.cast(buf, ctypes.c_void_p)) == 0
 t = list(buf)
 t0 = min(v for v in t if v)
-names = ["start", "stored", "bar1"] + [f"u{i}" for i in range(9)] + ["issued", "bar2"]
+# round-3 kernel (JP_P9US2=0): stage start, patch stored, after barrier 1, steps, loop issued, after the stage-end barrier;
+# P9US2: stage start (after the younger half's staging burst), steps, loop issued, after the barrier
+V2 = os.environ.get("JP_P9US2", "1") != "0"
+names = (["start"] if V2 else ["start", "stored", "bar1"]) + [f"u{i}" for i in range(9)] + ["issued", "bar2"]
 print("wave | " + " ".join(f"{n:>7s}" for n in names))
 for slot, wv_ in enumerate((0, 1, 4, 5)):
-    row = [t[slot * 16 + i] - t0 if t[slot * 16 + i] else -1 for i in range(14)]
+    row = [t[slot * 16 + i] - t0 if t[slot * 16 + i] else -1 for i in range(len(names))]
     print(f"  w{wv_} | " + " ".join(f"{v:7d}" for v in row))
-    print("       " + " ".join(f"{(row[i] - row[i - 1]) if i else 0:7d}" for i in range(14)))
+    print("       " + " ".join(f"{(row[i] - row[i - 1]) if i else 0:7d}" for i in range(len(names))))
