@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     static_assert(KG == 1 || KG == 2, "one or two K groups");
     static_assert(NCB == 1 || NCB == 2, "one or two input-channel blocks");
     static_assert(2 * SPL + ((TR + 1) * PC + 18) * 64 + 256 < 65536, "transpose-read immediates must fit 16 bits");
-    static_assert(KGW % 2 == 0 || KG == 1, "a wave group's K groups must be whole pixel rows");
+    static_assert(KGW % 2 == 0, "a wave's K groups per tile: whole pixel rows, and an even count (operand / fragment set parities)");
     constexpr bool DB = W9S_DB != 0;
     constexpr int BUFB = 3 * SPL;                  // bytes per patch buffer
     __shared__ __attribute__((aligned(16))) unsigned char patch[(DB ? 2 : 1) * BUFB];
@@ -177,6 +177,116 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+#ifndef W9S_OLD_STREAM
+    // Round 5: the instruction stream is laid out for an in-order wave that shares its SIMD's matrix pipe with ONE partner which the
+    // arbiter serves strictly by age (tools/ubench/mfma_lone_wave.hip: of two waves with MFMAs ready the older issues all of its
+    // own first).  A wave that stops issuing MFMAs to run a burst of other work leaves the pipe to its partner only if the partner
+    // has operands ready, so nothing here is a burst any more:
+    //   * dY of K group g + 2 is requested at the start of group g (the raw registers of group g are dead: it was split during
+    //     group g - 1) and group g + 1 is split into the OTHER operand set in twelve pieces of <= 5 VALU instructions, one behind
+    //     every fourth MFMA of group g -- the 44-VALU block that used to open every K group is gone;
+    //   * the six transpose reads of tap t + 1 go out one behind each of the six MFMAs of tap t;
+    //   * the next tile's patch items keep their place behind the taps of the tile's last K group (W9S_DB).
+    // Same products in the same order: results are bit-identical to the round-4 stream.
+    jp_u32x4 sa[2][3];                                   // [K group parity][split]: bf16 operand sets
+    float sr[2];                                         // residuals of the pair being split (between two pieces)
+    // piece c = 3 * pair + phase of the split of raw set `rs` into operand set `ds`; pair p = floats 2p, 2p + 1 of the 8 pixels
+    auto split_piece = [&](int rs, int ds, int c) {
+        const int pr = c / 3, ph = c % 3;
+        const jp_u32x4& src = araw[rs][pr >> 1];
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const int k = 2 * (pr >> 1) + (pr & 1);          // word of the operand registers: lo pairs 0, 1 -> 0, 1; hi pairs -> 2, 3
+        if (ph == 0) {
+            const float x_ = __uint_as_float(src[2 * (pr & 1)]), y_ = __uint_as_float(src[2 * (pr & 1) + 1]);
+            const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x_, y_}, bf2));
+            sr[0] = x_ - __uint_as_float(h0 << 16);
+            sr[1] = y_ - __uint_as_float(h0 & 0xffff0000u);
+            sa[ds][0][k] = h0;
+        } else if (ph == 1) {
+            const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{sr[0], sr[1]}, bf2));
+            sr[0] -= __uint_as_float(h1 << 16);
+            sr[1] -= __uint_as_float(h1 & 0xffff0000u);
+            sa[ds][1][k] = h1;
+        } else {
+            sa[ds][2][k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{sr[0], sr[1]}, bf2));
+        }
+    };
+    typedef short jp_s16x4_ __attribute__((ext_vector_type(4)));
+    jp_s16x4_ bh[2][3][2];                               // [tap parity][split][pixel half] transpose-read results
+    auto bread_half = [&](int ty, int tx, int g, int s, int h) -> jp_s16x4_ {
+        const int imm = s * SPL + ((g / 2 + ty) * PC + 16 * (g % 2) + tx) * 64;
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (jp_s16x4 __attribute__((address_space(3)))*)(patch + (bbase[tx][h] + rbuf) + imm + 256 * h));
+    };
+    auto bfrag = [&](int par, int s) -> jp_bf16x8 {
+        return __builtin_bit_cast(jp_bf16x8, __builtin_shufflevector(bh[par][s][0], bh[par][s][1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    if (T0 < T1) {
+        int img, y0, x0;
+        tile_org(T0, img, y0, x0);
+        int tb = (img * Cout) * (int)HW + y0 * W + x0;
+        tile_org(T0 + 1, img, y0, x0);
+        int tbn = (img * Cout) * (int)HW + y0 * W + x0;
+        aload(0, tb, kg * KGW);
+        if (KGW > 1) aload(1, tb, kg * KGW + 1); else aload(1, tbn, kg * KGW);
+        gload(T0);
+        if (DB) lstore(0);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) split_piece(0, 0, c);
+        for (int T = T0; T < T1; ++T) {
+            if (!DB) lstore(0);
+            __syncthreads();                                        // DB: buffer rbuf is complete, the other one is free
+            gload(T + 1);                                            // next tile's patch: in flight during the MFMAs below
+            tile_org(T + 2, img, y0, x0);
+            const int tbnn = (img * Cout) * (int)HW + y0 * W + x0;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bh[0][s_][h] = bread_half(0, 0, 0, s_, h);
+#pragma unroll
+            for (int gi = 0; gi < KGW; ++gi) {
+                const int g = gi, cur = gi & 1;
+                // dY of K group gi + 2 (this tile, the next one or the one after it) -> the raw set group gi used
+                if (gi + 2 < KGW) aload(cur, tb, kg * KGW + gi + 2);
+                else if (gi + 2 - KGW < KGW) aload(cur, tbn, kg * KGW + gi + 2 - KGW);
+                else aload(cur, tbnn, kg * KGW + gi + 2 - 2 * KGW);
+                const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[cur][0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[cur][1]),
+                                a2 = __builtin_bit_cast(jp_bf16x8, sa[cur][2]);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int tp = (9 * gi + tap) & 1;               // fragment set of this tap (9 taps per K group: the parity runs on)
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+                        // the six products with split index sum <= 2, smallest terms first
+                        const jp_bf16x8 av = (m == 0) ? a2 : ((m == 1 || m == 3) ? a1 : a0);
+                        const int sb = (m == 0 || m == 3 || m == 5) ? 0 : ((m == 1 || m == 4) ? 1 : 2);
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bfrag(tp, sb), acc[tap], 0, 0, 0);
+                        // behind MFMA m: transpose read m of the next tap (of the next K group's first tap behind the last one)
+                        if (tap + 1 < 9) bh[tp ^ 1][m >> 1][m & 1] = bread_half((tap + 1) / 3, (tap + 1) % 3, g, m >> 1, m & 1);
+                        else if (gi + 1 < KGW) bh[tp ^ 1][m >> 1][m & 1] = bread_half(0, 0, g + 1, m >> 1, m & 1);
+                        // ... and, behind every fourth MFMA, one piece of the next K group's dY split
+                        {
+                            const int slot = 6 * tap + m;
+                            if (slot >= 2 && (slot - 2) % 4 == 0 && (slot - 2) / 4 < 12) split_piece(cur ^ 1, cur ^ 1, (slot - 2) / 4);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // DB: one item of the NEXT tile's patch is split and stored into the other buffer behind each of the first
+                    // NQ taps of the tile's last K group
+                    if (DB && gi == KGW - 1 && tap < NQ) {
+                        lstore1(tap, rbuf ^ BUFB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            tb = tbn;
+            tbn = tbnn;
+            if (DB) rbuf ^= BUFB;
+            else __syncthreads();
+        }
+    }
+#else
     if (T0 < T1) {
         int img, y0, x0;
         tile_org(T0, img, y0, x0);
@@ -259,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         }
     }
 
+#endif
     // ---- partial tile -> ws[zs][m][tap*Cm + ci]; C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long Np = 9L * Cm;
     float* wz = ws + (long)(zs * KG + kg) * Cout * Np;

@@ -201,7 +201,8 @@ def test_config_step(name):
             r64 = g64[n]
             eh = float((named[n].grad.detach().cpu().double() - r64).norm() / (r64.norm() + 1e-30))
             ec = float((P[n].grad.double() - r64).norm() / (r64.norm() + 1e-30))
-            if eh > referee_bound(n, ec):
+            print(f"referee {name} {n}: hip {eh:.4f} fp32-oracle {ec:.4f} bound {referee_bound(n, ec, name):.4f}")
+            if eh > referee_bound(n, ec, name):
                 worse.append((n, eh, ec))
         assert not worse, f"{name}: gradients further from the float64 oracle than the fp32 oracle (name, hip, cpu32): {worse[:8]}"
 

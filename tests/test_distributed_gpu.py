@@ -350,7 +350,7 @@ def test_train_mono_two_epochs_single_rank(tmp_path):
     w1 = runner.model.module.DepthDecoder.iconv3.conv.weight.detach().cpu()
     moved = (w1 - w0).abs().max()
     assert 1e-5 < float(moved) < 1e-3                          # 2 steps at 1e-4 + 2 at 5e-5: |dw| <= 3e-4 per weight
-    assert os.listdir(tmp_path) == ["epoch_2.pth"]
+    assert sorted(os.listdir(tmp_path)) == ["epoch_2.pth", "latest.pth"]          # mmcv's `latest.pth` link beside the epoch file
     m2 = MONO.module_dict["Baseline"](opt)
     r2 = train_mono(m2, _SynthSet(HW, FR), None, Cfg(cfg, resume_from=str(tmp_path / "epoch_2.pth"), total_epochs=2,
                                                      work_dir=str(tmp_path / "r")), None)
