@@ -43,7 +43,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TF, PEAK_BF16_TF, PEAK_HBM_TBS = 157.3, 2500.0, 8.0     # dense fp32-MFMA / dense bf16-MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
-SPLIT_TAGS = ("p9sm_tag", "p9sw_tag", "p9s_tag", "w9s_tag", "p9us_tag", "w1s_tag", "p9sd_tag", "w4s_tag", "p9s2d_tag", "p9s2f_tag", "w9s2_tag", "p9sx2_tag", "p7s_tag")     # kernels on the bf16 pipe: 6 bf16 MFMA products per fp32 product (igemm_p9s.h)
+SPLIT_TAGS = ("p9sm_tag", "p9sw_tag", "p9s_tag", "w9s_tag", "p9us2_tag", "w1s_tag", "p9sd_tag", "w4s_tag", "p9s2d_tag", "p9s2f_tag", "w9s2_tag", "p9sx2_tag", "p7s_tag")     # kernels on the bf16 pipe: 6 bf16 MFMA products per fp32 product (igemm_p9s.h)
 
 # BASELINE.json `configs`, in order.  Per-GPU batch = BASELINE.json's figure (the reference's files carry IMGS_PER_GPU = 1/3/3/3/1
 # for a 24 GB card; /root/reference/config/<name>.py:3-6 give frames / size, :19 the type, :47-55 loss_sum / split).  The
@@ -440,9 +440,6 @@ def _kernel_name(tag):
     parts.append(cur.strip())
     kv = dict(p.split(" = ", 1) for p in parts if " = " in p)
     kv = {k: v.replace("(anonymous namespace)::", "") for k, v in kv.items()}
-    if "p9sx_tag" in tag:
-        taps = kv.get("TAPS", "1")
-        return f"jp_igemm_p9s_x_kernel<{kv['NJ']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {taps}>"
     if "p9sw_tag" in tag:
         taps = kv.get("TAPS", "1")
         return f"jp_igemm_p9s_wide_kernel<{kv['WM']}, {kv['WN']}, {kv['REFLECT']}, {kv['REV']}, {kv['E']}, {taps}, {1 if taps == '9' else 2}>"
@@ -476,8 +473,6 @@ def _kernel_name(tag):
         return f"jp_igemm_p9sd_kernel<{kv['E']}>"
     if "p9us2_tag" in tag:
         return f"jp_igemm_p9us2_kernel<{kv['E']}>"
-    if "p9us_tag" in tag:
-        return f"jp_igemm_p9us_kernel<{kv['E']}, {kv.get('NJ', '2')}>"
     if "p9u_tag" in tag:
         return f"jp_igemm_p9u_kernel<{kv['E']}>"
     if "w9s_tag" in tag:
@@ -565,7 +560,7 @@ def measure_roofline(runner, batch, B, t_step, rank):
                 # (r[5] = executed FLOPs in fp32 products: a split-bf16 kernel issues 6 bf16 MFMA FLOPs per fp32 FLOP)
                 big = max(r[5] for r in sub)
                 main = [r for r in sub if r[5] >= 0.1 * big]
-                par = [r for r in main if re.search(r"FwdBP|WgradBP|DgradUPB|DgradS2B|p9u_tag|p9us_tag|p9sd_tag|w4s_tag", r[0]) and "p9_tag" not in r[0]]
+                par = [r for r in main if re.search(r"FwdBP|WgradBP|DgradUPB|DgradS2B|p9u_tag|p9us2_tag|p9sd_tag|w4s_tag", r[0]) and "p9_tag" not in r[0]]
                 plain = [r for r in main if r not in par]
                 left = shp[1]
                 tot_plain = sum(r[5] for r in plain)

@@ -27,7 +27,6 @@
 #include "conv_p9sm.h"
 #include "igemm_w9s.h"
 #include "igemm_w9s2.h"
-#include "igemm_p9us.h"
 #include "igemm_p9us2.h"
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
@@ -210,7 +209,7 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
         }
         case PACK_SPLITSEG: {  // p = Cout, Cin, c_off, C, up: one channel segment of an iconv bank as bf16 three-way splits in the
-                               // fragment order of the P9US kernel (igemm_p9us.h): [class (up only)][M tile of 128][step = (16-channel
+                               // fragment order of the P9US2 kernel (igemm_p9us2.h): [class (up only)][M tile of 128][step = (16-channel
                                // stage, tap | slot)][split][k-half][row 128][4 words]; word w4 = channels stage*16 + khalf*8 + 2*w4 + {0,1}
             const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], up = p[4];
             const int T = up ? 4 : 9, MT = Cout / 128;
@@ -539,11 +538,7 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
         if (bias) v += bias[m];
-#ifdef JP_EPI_NT     // experiment: non-temporal output stores (profiles/r04_epi_nt_ab.log)
-        __builtin_nontemporal_store(jp_act(v, act), y + base + (size_t)m * OHW);
-#else
         y[base + (size_t)m * OHW] = jp_act(v, act);
-#endif
     }
     // four consecutive pixels of channel m (16-byte aligned: the patch kernels' tiles start at multiples of 32 pixels)
     __device__ __forceinline__ void put4(St base, int m, float4 v) const {
@@ -697,9 +692,6 @@ struct DgradEpi {  // dx[img][ci][pix] (= or +=) acc
     }
     __device__ __forceinline__ void put(St base, int m, float v) const {
         float* q = dx + base + (size_t)m * HW;
-#ifdef JP_EPI_NT
-        if (!accumulate) { __builtin_nontemporal_store(v, q); return; }
-#endif
         *q = accumulate ? (*q + v) : v;
     }
     __device__ __forceinline__ void put4(St base, int m, float4 v) const {
@@ -2102,8 +2094,6 @@ inline bool p9us_enabled() {
     static const int on = [] { const char* e = getenv("JP_P9US"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
-template <class E, int NJ>
-const char* p9us_tag() { return __PRETTY_FUNCTION__; }
 template <class E>
 const char* p9us2_tag() { return __PRETTY_FUNCTION__; }
 // P9SD (igemm_p9sd.h): dgrad of the upsampled iconv segment at half resolution on the bf16 pipe; JP_P9SD=0 keeps DgradUPB
@@ -2136,20 +2126,11 @@ inline bool p9_m256() {
 // `ptiles` = N * (H/4) * (W/32) pixel tiles of the launch (the conv entry points know it when they pack: a layer's pack is
 // keyed by its shape on the host side); the 8-wave variant needs >= 256 workgroups or it leaves CUs empty
 // (512->512 @32x32: 141 -> 92 TF), where it has them it is 2-4 % faster (256->256 @128x128: 141 -> 146 TF)
-// JP_P1_TILE (1x1 layers with 256-row banks): 0 (default) = 256 rows x 4x32 pixels on 8 waves (rounds 2-3); 1 = 256 rows x 8x32
-// pixels (jp_igemm_p9s_wide_kernel<4, 2, ..., 1, 2>: NJ = 4 pixel rows per wave, one workgroup per CU: half the weight-stream bytes
-// per MFMA); 2 = 128 rows x 8x32 pixels on 4 waves (two workgroups per CU; 128-row pack).  Same box, CRP 256->256 @256^2 forward /
-// dgrad alone: 0.545 / 0.488 ms (0), 0.522 / 0.461 (1), 0.556 / 0.500 (2); @128^2 0.128 / 0.120, 0.121 / 0.110, 0.134 / 0.118
-// (profiles/r04_p1_tile_ab.log) -- but in the overlapped step mode 1 LOSES 0.3 ms (84.69 -> 84.99 ms, r04_tile_step_ab.log: the wide
-// kernel takes a CU's whole register file, nothing of the side streams fits beside it), so it stays opt-in.
-inline int p1_tile() {
-    static const int m = [] { const char* e = getenv("JP_P1_TILE"); return e ? atoi(e) : 0; }();
-    return m;
-}
+// (1x1 layers keep the 4x32-pixel tiles: 8x32 ones and 128-row 4-wave tiles were measured in round 4, profiles/r04_p1_tile_ab.log,
+// r04_p1_tile3_ab.log; 4-wave 256-row workgroups, two per CU, in round 5: -7..-9 % alone, +0.3 ms in the step, profiles/r05_x_ab.log)
 inline bool p9_wide256(int rows, long ptiles) { return p9_m256() && rows % 256 == 0 && ptiles * (rows / 256) >= 256; }
 inline int p9_bmt(int rows, int khw = 9, long ptiles = 0) {
     if (rows <= 64) return 64;
-    if (khw == 1 && p1_tile() >= 2) return 128;      // 3: the plain 4-wave <2, 2, 2> kernel on 128-row tiles (two workgroups per CU)
     return p9_wide256(rows, ptiles) ? 256 : 128;
 }
 inline long p9_ptiles(int N, int H, int W) { return (long)N * (H / 4) * (W / 32); }
@@ -2205,40 +2186,14 @@ inline int p9_tile() {
     static const int m = [] { const char* e = getenv("JP_P9_TILE"); return e ? atoi(e) : 3; }();
     return m;
 }
-template <int NJ, bool REFLECT, bool REV, class E, int TAPS>
-const char* p9sx_tag() { return __PRETTY_FUNCTION__; }
-// JP_P9_X (round 5): 256-row banks on 4-wave workgroups -- 1: <NJ = 4>, two workgroups per CU; 2: <NJ = 8>, one wave per SIMD.
-// JP_P1_X: the same for the 1x1 layers.
-inline int p9_x(int taps) {
-    static const int m9 = [] { const char* e = getenv("JP_P9_X"); return e ? atoi(e) : 0; }();
-    static const int m1 = [] { const char* e = getenv("JP_P1_X"); return e ? atoi(e) : 0; }();
-    return taps == 9 ? m9 : m1;
-}
 template <bool REFLECT, bool REV, class E, int TAPS>
 void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
-    if (bmt == 256 && p9_x(TAPS)) {
-        const int xm = p9_x(TAPS);
-        if (xm == 1 && (long)N * (H / 4) * (W / 32) * jp_cdiv(rows, 256) >= 512) {
-            jp_prof_before(p9sx_tag<4, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
-            hipLaunchKernelGGL((jp_igemm_p9s_x_kernel<4, 2, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1),
-                               dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
-            jp_prof_after(st);
-            return;
-        }
-        if (xm == 2 && H % 8 == 0 && (long)N * (H / 8) * (W / 32) * jp_cdiv(rows, 256) >= 256) {
-            jp_prof_before(p9sx_tag<8, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
-            hipLaunchKernelGGL((jp_igemm_p9s_x_kernel<8, 1, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 8) * (W / 32), jp_cdiv(rows, 256), 1),
-                               dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
-            jp_prof_after(st);
-            return;
-        }
-    }
     {
         // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy
-        const int mode = TAPS == 1 ? (p1_tile() ? (bmt == 256 ? 1 : (p1_tile() == 2 ? 2 : 0)) : 0) : p9_tile();
+        const int mode = TAPS == 1 ? 0 : p9_tile();
         if (TAPS == 9 && mode >= 3 && bmt == 64 && H % 16 == 0 && (long)N * (H / 16) * (W / 32) >= 256) {
             jp_prof_before(p9sw_tag<1, 4, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
             hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<1, 4, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 16) * (W / 32), 1, 1), dim3(256), 0,
@@ -2267,15 +2222,6 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
         hipLaunchKernelGGL((jp_igemm_p9s_kernel<1, 4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
     } else if (bmt == 256) {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1);
-        if constexpr (TAPS == 1) {
-            // 1x1: more 16-channel groups per stage = fewer barrier pairs per MFMA (the pack's step order does not depend on KGS)
-            static const int kgs1 = [] { const char* e_ = getenv("JP_P1_KGS"); return e_ ? atoi(e_) : 2; }();
-            if (kgs1 == 4 && red % 64 == 0) {
-                hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, 4>), grid, dim3(512), 0, st, wq, x, e, rows, red, red / 64, H, W, mt_off);
-                jp_prof_after(st);
-                return;
-            }
-        }
         hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
@@ -2709,7 +2655,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         (long)(Cout / 128) * N * (H / 4) * (W / 64) >= 128 && p9u_enabled()) {
         const int MT = Cout / 128;
         if (p9us_enabled()) {
-            // P9US: the same tiles on the bf16 matrix pipe (three-way split products, igemm_p9us.h)
+            // P9US2: the same tiles on the bf16 matrix pipe (three-way split products, igemm_p9us2.h)
             const long fS = (long)MT * (c0 / 16) * 9 * 3072, fU = 4L * MT * (c1 / 16) * 4 * 3072, fD = c2 ? (long)MT * 9 * 3072 : 0;
             if (!ws_state) {
                 do_pack(PACK_SPLITSEG, w, ws, fS, Cout, Cin, 0, c0, 0, 0, st);
@@ -2717,39 +2663,12 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                 if (c2) do_pack(PACK_SPLITSEG, w, ws + fS + fU, fD, Cout, Cin, c0 + c1, c2, 0, 0, st);
                 // (the kernel's last weight prefetch reads one step past the streams: inside the scratch, never used)
             }
-            // JP_P9US_TILE=1: 8 x 64-pixel tiles (4 rows per parity class and wave) where they still give >= 256 workgroups.  OFF by
-            // default: the kernel alone gains 6 % (6.03 -> 5.65 ms per step, profiles/r04_p9us_tile_ab.log) but it then holds a CU's
-            // whole register file and 65 KB of LDS (256 VGPRs, 39 of them spilled), the side streams' kernels no longer fit beside
-            // it, and the overlapped step LOSES 0.2-0.9 ms (same-box pairs 86.10 / 85.52 -> 86.32 / 86.39 ms).
-            // P9US2 (round 5, igemm_p9us2.h): the same tiles and arithmetic with every operand request inside an MFMA pair's shadow
-            // and the next patch staged by the half of the workgroup that is not on the pipe; JP_P9US2=0 keeps the round-3 stream
-            static const bool v2_on = [] { const char* e_ = getenv("JP_P9US2"); return !(e_ && e_[0] == '0'); }();
-            if (v2_on && c0 % 32 == 0 && c1 % 32 == 0) {
-                jp_prof_before(p9us2_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
-                hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
-                                   reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
-                jp_prof_after(st);
-                JP_LAUNCH_CHECK();
-            }
-            static const bool wide_on = [] { const char* e_ = getenv("JP_P9US_TILE"); return e_ && e_[0] == '1'; }();
-            const bool wide = wide_on && H % 8 == 0 && (long)MT * N * (H / 8) * (W / 64) >= 256;
-            jp_prof_before(wide ? p9us_tag<FwdEpi, 4>() : p9us_tag<FwdEpi, 2>(),
-                           6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
-            if (wide)
-                hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 4>), dim3(N * (H / 8) * (W / 64), MT, 1), dim3(512), 0, st,
-                                   reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
-            else {
-                // JP_P9US_DB=1: double-buffered patch (igemm_p9us.h, DB = true) where the stage counts of both segments are even.  OFF by
-                // default: unlike the P9S kernels this one does not gain from it (same box, three pairs: 5.83 / 5.70 / 5.58 ms per step
-                // with, 5.75 / 5.69 / 5.66 without; profiles/r04_p9us_db_ab.log)
-                static const bool db_on = [] { const char* e_ = getenv("JP_P9US_DB"); return e_ && e_[0] == '1'; }();
-                if (db_on && c0 % 32 == 0 && c1 % 32 == 0)
-                    hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2, true>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
-                                       reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
-                else
-                    hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
-                                       reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
-            }
+            // P9US2 (igemm_p9us2.h, round 5): every operand request inside an MFMA pair's shadow, the next patch staged by the half of
+            // the workgroup that is off the pipe.  (The round-3 stream, its 8-row tiles and its double buffer are gone: logs in
+            // profiles/r04_p9us_*.log, r05_p9us2_*.log.)
+            jp_prof_before(p9us2_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
+            hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
+                               reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }

@@ -80,13 +80,6 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 #ifndef P9S_DB
 #define P9S_DB 1           // double-buffered patch, one barrier per stage (round 4); 0: the two-barrier stage of round 3
 #endif
-#ifndef P9S_PF1
-#define P9S_PF1 1          // stages of the 1x1 kernels' input in flight.  2 was measured (profiles/r04_p9s_pf_ab.log): no change --
-                           // the 1 900-2 500 cycles a 1x1 stage spends in its split + store are not a wait for data
-#endif
-#ifndef P9S_OCC
-#define P9S_OCC 2          // waves per SIMD the 4-wave variants are compiled for (3: <= 168 VGPRs, B fragments re-read per row)
-#endif
 // XS = input stride (1x1 only): output pixel (y, x) reads input pixel (XS*y, XS*x) of an (XS*H) x (XS*W) map.
 // MASK (small maps, igemm_p9sm kernels below): H / W need not be multiples of the tile -- partial tiles stage zeros outside
 // the map and store only pixels inside it -- and the workgroup runs the stage range [s_begin, s_end) of the reduction only
@@ -95,7 +88,7 @@ constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring
 // lets a wave hold NJ = 4 pixel rows (8 accumulators) in 230-250 registers -- the 1x1 "wide" tiles of round 4, which halve the
 // L2 weight-stream traffic per MFMA (a wave's A fragments serve 4 pixel rows instead of 2).
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS, int XS, bool MASK = false,
-          bool ROWB = (P9S_OCC >= 3)>
+          bool ROWB = false>
 __device__ __forceinline__ void jp_igemm_p9s_body(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
     int s_begin = 0, int s_end = -1) {
@@ -112,15 +105,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     constexpr int STEPS = TAPS * KGS;                         // (tap, group) steps per stage
     constexpr int BMT = 64 * WM;
     constexpr int LSU = STEPS >= 3 ? STEPS - 3 : 0;           // P9S_DB: the step behind whose MFMAs the next stage's patch is stored
-#ifdef P9S_NO_VEC4
-    constexpr bool VEC = false;
-#else
     // transposed accumulators + 16-byte stores: the 4-wave 3x3 kernels only.  Same box, alone (profiles/r04_vec4_ab.log): <1,4> wide
     // 64->64 @256^2 0.225 / 0.216 -> 0.208 / 0.204 ms, <2,2> wide 128->128 @128^2 0.176 / 0.172 -> 0.166 / 0.167; the 8-wave 3x3
     // kernels do not care (2.469 -> 2.480) and the 1x1 kernels, whose tile is mostly stores, LOSE 2-6 % (a 16-byte store per lane
     // covers an eighth of a 128-byte line; the scalar stores of 32 adjacent lanes cover it whole).
     constexpr bool VEC = jp_has_put4<Epi>::value && !MASK && TAPS == 9 && WM * WN <= 4;
-#endif
     // P9S_DB (round 4): the patch is double-buffered.  A stage used to be [split + LDS store, barrier, MFMAs, barrier]: the cycle
     // stamps of a 1x1 tile (profiles/r04_p1_trace.log) show ~2 300 cycles per stage with no MFMA in flight (drain, barrier, store,
     // barrier) next to 3 100 (1x1) / 13 800 (3x3) cycles of MFMA issue.  Now stage s + 1's patch is split and stored into the other
@@ -134,9 +123,6 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-#ifdef P9S_PRIO      // guide, "Two waves per SIMD" item 4: the second-dispatched half of an 8-wave workgroup loses every arbitration
-    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     int mt, nt;
     {   // XCD band order, see jp_igemm_kernel
         const int gx = gridDim.x, gy = gridDim.y, G = gx & ~7;
@@ -181,19 +167,14 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         loff[q] = e < ITEMS ? (kh * PR + pr) * COLS + col : -1;
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)((long)C * HWI * 4), 0x00020000);
-    // PF = stages of the input in flight (P9S_DB; the 1x1 kernels may take 2, see P9S_PF1)
-    constexpr int PF = (DB && TAPS == 1) ? P9S_PF1 : 1;
-    static_assert(PF == 1 || PF == 2, "one or two stages in flight");
+    constexpr int PF = 1;                                     // stages of the input in flight (2 was measured for the 1x1 kernels: no change,
+                                                              // profiles/r04_p9s_pf_ab.log)
     float rv_[PF][NQ][8];
     auto gload = [&](int slot, int stage) {
         float (&rv)[NQ][8] = rv_[slot];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-#ifdef P9S_PROBE_X      // timing probe (wrong results): every stage re-reads channel k of the first one -- input traffic from L2 only
-            const int ub = __builtin_amdgcn_readfirstlane((int)((long)k * HWI * 4));
-#else
             const int ub = __builtin_amdgcn_readfirstlane((int)(((long)stage * CS + k) * HWI * 4));
-#endif
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const float v = jp_gather(xrs, soff[q] & ~1u, ub);
@@ -242,13 +223,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
-#ifdef P9S_PROBE_W      // timing probe (wrong results): every step re-reads the first one -- weight stream latency / bandwidth out of the picture
-                ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), 0, 0);
-#elif defined(P9S_PROBE_AHALF)   // timing probe (wrong results): half the weight-stream bytes through the vector memory pipe
-                ra[slot][i][s] = i ? ra[slot][0][s] : __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + s * (2 * BMT * 16), step_bytes, 0);
-#else
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
-#endif
     };
 #pragma unroll
     for (int d = 0; d < P9S_AHEAD; ++d) aload(d, (s_begin * STEPS + d) * SBYTES);
@@ -261,9 +236,6 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         auto bload = [&](int buf, int j, int u) {
             const int tap = u / KGS, kg = u % KGS;
             const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
-#ifdef P9S_PROBE_NOB    // timing probe (wrong results): B fragments read once per stage -- LDS read traffic out of the picture
-            if (u) return;
-#endif
 #pragma unroll
             for (int s = 0; s < 3; ++s) rb[j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
         };
@@ -291,13 +263,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                     __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 == NJ && u + 1 < STEPS) bload(BUF, 0, u + 1);
                 }
-#ifndef P9S_PROBE_NOSTG  // (timing probe, wrong results: no staging after the first stage)
                 if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
                     lstore(BUF ^ 1, (BUF + 1) % PF);
                     if (stage + 1 + PF < s_end) gload((BUF + 1) % PF, stage + 1 + PF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
             }
             __syncthreads();
         };
@@ -417,11 +387,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-#ifdef P9S_PROBE_NOST   // timing probe (wrong results): (almost) no output stores
-                if (m < M && acc[i][j][r] == 123456.75f) epi.put(se, m, acc[i][j][r]);
-#else
                 if (m < M) epi.put(se, m, acc[i][j][r]);
-#endif
             }
         }
     }
@@ -434,7 +400,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 }
 
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
+__global__ __launch_bounds__(64 * WM * WN, NJ <= 2 ? 2 : 1) void jp_igemm_p9s_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
@@ -445,16 +411,6 @@ template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9s_wide_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, 4, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
-}
-// round 5 experiments on the 256-row banks (JP_P9_X): the two waves of a SIMD no longer belong to one workgroup.
-//  X: 4 waves x (64 channels x 4 rows x 32 px), TWO independent workgroups per CU -- their barriers / prologues / epilogues are not
-//     in phase, so one workgroup's stall is the other's matrix time;
-//  Z: 4 waves x (64 channels x 8 rows x 32 px), ONE wave per SIMD with the whole 512-register file (16 accumulators): half the
-//     weight-stream bytes per MFMA again, everything software-pipelined inside one instruction stream.
-template <int NJ, int OCC, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
-__global__ __launch_bounds__(256, OCC) void jp_igemm_p9s_x_kernel(
-    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
-    jp_igemm_p9s_body<4, 1, NJ, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
 }
 // small maps (pose encoder 24x80 .. 6x20, BEV 32x32 .. 8x8): masked partial tiles + split-K over grid.z; the epilogue's
 // `slice` member receives blockIdx.z (conv_p9sm.hip)
@@ -468,7 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9sm_kernel(
 }
 // 1x1 stride-2 (the ResNet downsample branches): same tiles, the staging gather reads every second input pixel
 template <int WM, int WN, int NJ, class Epi>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NJ <= 2) ? P9S_OCC : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_x2_kernel(
+__global__ __launch_bounds__(64 * WM * WN, NJ <= 2 ? 2 : 1) void jp_igemm_p9s_x2_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
     jp_igemm_p9s_body<WM, WN, NJ, false, false, Epi, 1, 2, 2>(wp, x, epi, M, C, NST, H, W, mt_off);
 }

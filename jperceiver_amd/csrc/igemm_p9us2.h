@@ -1,8 +1,18 @@
-// "P9US2" (round 5): the iconv forward kernel of igemm_p9us.h  --  y = act(Conv3x3_reflect(cat(skip, up2x(x), disp)) + b),
-// depth_decoder.py:76-77, parity-class form, every fp32 product as six bf16 MFMA products of exact three-way splits  --  with its
-// instruction stream re-laid for how a CDNA4 SIMD issues.
+// "P9US2" patch kernel: the decoder's iconv layers  y = act(Conv3x3_reflect(cat(skip, up2x(x), disp)) + b)  (depth_decoder.py:76-77)
+// in the parity-class form of igemm_p9u.h, every fp32 product as six bf16 MFMA products of exact three-way splits (igemm_p9s.h has the
+// arithmetic argument).  Round 5 re-laid the round-3 kernel's instruction stream for how a CDNA4 SIMD issues; the tiling is unchanged:
 //
-// What the round-5 step trace of the old kernel showed (profiles/r05_p9us_steps_before.log, cycle stamps per 24-MFMA step):
+// Workgroup: 8 waves, output tile 128 channels x (4 rows x 64 columns).  Wave (wm, class (py, px)) owns 64 channels x the tile's
+// 2 x 32 pixels of its parity class (rows py, py+2; columns px, px+2, ...): a wave is class-uniform, so the upsampled stages read a
+// class-specific weight stream while the skip / disparity stages share one.  Stages of 16 channels:
+//   S (skip, 9 taps = 9 steps): full-resolution patch 6 x 66, columns stored de-interleaved by parity ([even | odd]) so that a
+//       fragment's 32 same-parity pixels are 32 consecutive 16-byte words;
+//   U (upsampled, 4 slots = 4 steps): low-resolution patch 4 x 34 (edge clamp == reflection of up(x));
+//   D (the disparity channel(s), padded to 16: 9 steps).
+// LDS word = 8 channels of one pixel as bf16, [split][k-half][patch row][position]; weights (PACK_SPLITSEG, conv.hip): streams
+// [S: M tile][U: class][M tile][D: M tile] of steps, a step = [split][k-half][128 rows] x 16 bytes, one step ahead.
+//
+// What the round-5 step trace of the round-3 stream showed (profiles/r05_p9us_steps_before.log, cycle stamps per 24-MFMA step):
 //   * ONE wave never issued faster than ~44 cycles per MFMA (1 050 cycles per step, with or without a partner on its SIMD),
 //     although the matrix pipe takes a `32x32x16` every 32: a step began with a burst of 6 weight loads + 3 LDS reads (+ waits), and
 //     an in-order wave issues nothing else while those go out;
@@ -16,7 +26,7 @@
 // to wait for the younger half at the barrier (they land during that wait instead of holding up the in-order vmcnt queue in front of
 // the next weight loads).  Matrix beside memory on every SIMD, one barrier per stage.
 //
-// Tiles, LDS layout, weight streams (PACK_SPLITSEG) and arithmetic are those of igemm_p9us.h (bit-identical results).
+// Results are bit-identical to the round-3 stream's (same products, same order per accumulator).
 // Preconditions (host-checked): Cout % 128 == 0, C0 % 32 == 0, C1 % 32 == 0 (a stage's patch buffer is its index parity),
 // C2 <= 8, H % 4 == 0, W % 64 == 0.
 #pragma once
@@ -179,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- B fragment bases (16-byte words), see igemm_p9us.h
+    // ---- B fragment bases (16-byte words).  S / D: pixel (row py + 2j + ty, patch column 2*l31 + px + tx) -> de-interleaved
+    // position ((px+tx)&1)*PHALF + l31 + ((px+tx)>>1): taps tx = 0, 2 share a base (+0 / +1), tap tx = 1 has its own.
     const jp_u32x4* bsA = patch + (lhi * PRS + py) * PITS + l31 + px * PHALF;                 // u = px (+2 -> +1)
     const jp_u32x4* bsB = patch + (lhi * PRS + py) * PITS + l31 + (px ? 1 : PHALF);           // u = px + 1
     const jp_u32x4* bu = patch + (lhi * PRU + py) * PITU + l31 + px;

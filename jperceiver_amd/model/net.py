@@ -157,8 +157,9 @@ class Baseline(nn.Module):
     def _pose_stream(self, dev):
         st = getattr(self, "_side_stream", None)
         if st is None or st.device != dev:
-            # on the MODEL's device, not the current one.  JP_SIDE_PRIO = -1 gives the side stream the high hardware priority
-            st = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("JP_SIDE_PRIO", "0")))
+            # on the MODEL's device, not the current one
+            from ..runtime import new_stream
+            st = self._side_stream = new_stream(dev, "JP_SIDE_CUMASK")
         return st
 
     def _layout_head(self, sfx, F, f4, n_updates):

@@ -121,7 +121,8 @@ def _wgrad_stream():
     key = (base.device, base.cuda_stream)
     st = _WG_STREAMS.get(key)
     if st is None:
-        st = _WG_STREAMS[key] = torch.cuda.Stream(device=base.device, priority=int(_os.environ.get("JP_WG_PRIO", "0")))
+        from .runtime import new_stream
+        st = _WG_STREAMS[key] = new_stream(base.device, "JP_WG_CUMASK")
     return st
 
 

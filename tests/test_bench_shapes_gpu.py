@@ -56,7 +56,7 @@ class kernel_tags:
 def _split_name(w):
     """Names of the split-bf16 twins the library launches for the same tiles unless JP_P9S / JP_W9S / JP_P9US = 0:
     jp_igemm_p9_kernel<WM, WN, REFLECT, REV, Epi, TAPS, CPB> -> jp_igemm_p9s_kernel<WM, WN, 2, REFLECT, REV, Epi, TAPS, KGS>
-    (igemm_p9s.h), the wide W9 -> jp_wgrad_w9s_kernel<TR, REFLECT> (igemm_w9s.h), P9U -> P9US (igemm_p9us.h)."""
+    (igemm_p9s.h), the wide W9 -> jp_wgrad_w9s_kernel<TR, REFLECT> (igemm_w9s.h), P9U -> P9US2 (igemm_p9us2.h)."""
     import os
     import re
     mw = re.fullmatch(r"jp_wgrad_w9_kernel<2, 2, 1, (\w+)>", w)
@@ -85,9 +85,7 @@ def _split_name(w):
     if w == "WgradAP, WgradBP" and os.environ.get("JP_W9S", "1") != "0":
         return "jp_wgrad_w4s_kernel<2>"                               # parity-class wgrad of the upsampled segment (igemm_w4s.h)
     if w == "jp_igemm_p9u_kernel<FwdEpi>" and os.environ.get("JP_P9US", "1") != "0":
-        if os.environ.get("JP_P9US2", "1") != "0":
-            return "jp_igemm_p9us2_kernel<FwdEpi>"         # round 5: the re-laid instruction stream (igemm_p9us2.h)
-        return "jp_igemm_p9us_kernel<FwdEpi, "            # NJ = 2 (4 x 64-pixel tiles) or 4 (8 x 64, round 4)
+        return "jp_igemm_p9us2_kernel<FwdEpi>"             # igemm_p9us2.h (round 5: the re-laid instruction stream)
     m = re.fullmatch(r"jp_igemm_p9_kernel<(\d), (\d), (\w+), (\w+), (\w+), (\d), \d>", w)
     if m is None or os.environ.get("JP_P9S", "1") == "0":
         return w

@@ -1,4 +1,4 @@
-"""Accuracy of the split-product kernels (igemm_p9s.h / igemm_w9s.h / igemm_p9us.h / igemm_p9sd.h / igemm_w4s.h / igemm_p9s2*.h)
+"""Accuracy of the split-product kernels (igemm_p9s.h / igemm_w9s.h / igemm_p9us2.h / igemm_p9sd.h / igemm_w4s.h / igemm_p9s2*.h)
 against FLOAT64.
 
 The patch convolutions form every fp32 product on the bf16 matrix pipe as 6 bf16 products of exact three-way bf16 splits

@@ -1,4 +1,4 @@
-// Standalone harness for the iconv forward kernel (igemm_p9us2.h; -DOLD: igemm_p9us.h) at the step's largest shape
+// Standalone harness for the iconv forward kernel (igemm_p9us2.h) at the step's largest shape
 // (8 x [256 skip + 256 up + 1] -> 256 @256^2): random inputs and weight bits (timing only, results unchecked), HIP-event time,
 // and -- built with -DP9S_TRACE -- the per-step cycle stamps of S stage 2 (waves 0, 1, 4, 5 of one workgroup).
 // Compiles in seconds, so stream variants (-DP9US2_xxx probes) can be A/B'd without rebuilding the library:
@@ -7,11 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#ifdef OLD
-#include "igemm_p9us.h"
-#else
 #include "igemm_p9us2.h"
-#endif
 struct FwdEpi {
     typedef size_t St;
     float* y; const float* bias; int Cout, OHW, act;
@@ -41,11 +37,7 @@ int main(int argc, char** argv) {
     const double flops = 6.0 * 2.0 * M * (double)N * H * W * (9.0 * C0 + 4.0 * C1 + 9.0 * 16);
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(e0);
-#ifdef OLD
-        hipLaunchKernelGGL((jp_igemm_p9us_kernel<FwdEpi, 2>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, 0, wp, x0, x1, x2, e, M, C0, C1, C2, H, W);
-#else
         hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, 0, wp, x0, x1, x2, e, M, C0, C1, C2, H, W);
-#endif
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (r >= 2) printf("%s %.3f ms  %.0f TF executed\n", argv[0], ms, flops / ms / 1e9);

@@ -1,7 +1,6 @@
 // Standalone harness for the 3x3 weight-gradient kernel jp_wgrad_w9s_kernel<4, true, 1, 1> (igemm_w9s.h) at the step's by-time
 // dominant shape (8 x 256 -> 256 reflect @256^2; grid and split-K plan as conv.hip's w9_plan gives them): random inputs, HIP-event
-// time; -DW9S_OLD_STREAM builds the round-4 instruction stream for A/B.  With -DCHECK the two streams' outputs can be compared
-// through the checksum it prints (same inputs -> bit-identical partial sums).
+// time and a checksum of the partial sums (the round-4 stream, removed since, gave the same checksum: profiles/r05_w9s_ab.log).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -Ijperceiver_amd/csrc tools/ubench/w9s_bench.hip -o ubench_bin/w9s_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
