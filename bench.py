@@ -43,7 +43,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TF, PEAK_BF16_TF, PEAK_HBM_TBS = 157.3, 2500.0, 8.0     # dense fp32-MFMA / dense bf16-MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
-SPLIT_TAGS = ("p9sm_tag", "p9sw_tag", "p9s_tag", "w9s_tag", "p9us2_tag", "w1s_tag", "p9sd_tag", "w4s_tag", "p9s2d_tag", "p9s2f_tag", "w9s2_tag", "p9sx2_tag", "p7s_tag")     # kernels on the bf16 pipe: 6 bf16 MFMA products per fp32 product (igemm_p9s.h)
+SPLIT_TAGS = ("p1l_tag", "p9sm_tag", "p9sw_tag", "p9s_tag", "w9s_tag", "p9us2_tag", "w1s_tag", "p9sd_tag", "w4s_tag", "p9s2d_tag", "p9s2f_tag", "w9s2_tag", "p9sx2_tag", "p7s_tag")     # kernels on the bf16 pipe: 6 bf16 MFMA products per fp32 product (igemm_p9s.h)
 
 # BASELINE.json `configs`, in order.  Per-GPU batch = BASELINE.json's figure (the reference's files carry IMGS_PER_GPU = 1/3/3/3/1
 # for a 24 GB card; /root/reference/config/<name>.py:3-6 give frames / size, :19 the type, :47-55 loss_sum / split).  The
@@ -471,6 +471,8 @@ def _kernel_name(tag):
         return f"jp_wgrad_w4s_kernel<{kv['TR']}>"
     if "p9sd_tag" in tag:
         return f"jp_igemm_p9sd_kernel<{kv['E']}>"
+    if "p1l_tag" in tag:
+        return f"jp_conv1x1_p1l_kernel<{kv['E']}>"
     if "p9us2_tag" in tag:
         return f"jp_igemm_p9us2_kernel<{kv['E']}>"
     if "p9u_tag" in tag:

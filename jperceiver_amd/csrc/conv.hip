@@ -28,6 +28,7 @@
 #include "igemm_w9s.h"
 #include "igemm_w9s2.h"
 #include "igemm_p9us2.h"
+#include "igemm_p1l.h"
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
 #include "igemm_p9s2d.h"
@@ -2186,14 +2187,46 @@ inline int p9_tile() {
     static const int m = [] { const char* e = getenv("JP_P9_TILE"); return e ? atoi(e) : 3; }();
     return m;
 }
+// P1L (igemm_p1l.h, round 5): the 256-row 1x1 layers as a persistent kernel with LDS-resident weight stages -- OPT-IN (JP_P1L=1).
+// Alone it is 8-9 % faster than the patch kernel on the @256^2 layers (0.556 / 0.501 -> 0.512 / 0.456 ms forward / dgrad, same pack,
+// bit-identical results: profiles/r05_p1l_conv_bench.log); in the overlapped step it LOSES: same-box pairs 82.4 -> 83.2 ms with it in
+// both directions, 83.2 -> 83.7 ms forward-only (profiles/r05_p1l_step_ab.log, r05_p1l_fwd_only_step_ab.log) -- a persistent workgroup
+// with 144 KB of LDS and 250 registers per lane owns its CU for the whole launch, while the patch kernel's short-lived workgroups
+// (49 KB, ~90 registers) let the side streams' kernels in beside them.  tests/test_kernels_gpu.py::test_p1l_persistent_1x1 runs it.
+template <class E>
+const char* p1l_tag() { return __PRETTY_FUNCTION__; }
+inline bool p1l_enabled() {
+    static const bool on = [] { const char* e = getenv("JP_P1L"); return e && e[0] == '1'; }();
+    return on;
+}
+inline int jp_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
 template <bool REFLECT, bool REV, class E, int TAPS>
 void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
-    {
-        // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy
-        const int mode = TAPS == 1 ? 0 : p9_tile();
+    if constexpr (TAPS == 1) {
+        const long ntiles = (long)N * (H / 4) * (W / 32), xb = (long)N * red * H * W * 4;
+        if (bmt == 256 && mt_off == 0 && p1l_enabled() && rows % 256 == 0 && red % 128 == 0 && H % 4 == 0 && W % 32 == 0 && xb < (1L << 31) &&
+            ntiles >= 8L * jp_num_cus()) {     // (4 tiles per workgroup, the @128^2 layers: no gain over the patch kernel, profiles/r05_p1l_conv_bench.log)
+            const int G = jp_num_cus(), tpw = jp_cdiv(ntiles, G);
+            jp_prof_before(p1l_tag<E>(), 6.0 * 2.0 * rows * (double)N * H * W * red, st);
+            hipLaunchKernelGGL((jp_conv1x1_p1l_kernel<E>), dim3(jp_cdiv(ntiles, tpw), rows / 256, 1), dim3(512), 0, st, wq, x, e, rows, red, NST,
+                               H, W, (int)ntiles, tpw, (int)xb);
+            jp_prof_after(st);
+            return;
+        }
+    }
+    if constexpr (TAPS == 9) {
+        // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy (3x3 layers only)
+        const int mode = p9_tile();
         if (TAPS == 9 && mode >= 3 && bmt == 64 && H % 16 == 0 && (long)N * (H / 16) * (W / 32) >= 256) {
             jp_prof_before(p9sw_tag<1, 4, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
             hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<1, 4, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 16) * (W / 32), 1, 1), dim3(256), 0,

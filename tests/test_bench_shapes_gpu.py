@@ -90,8 +90,9 @@ def _split_name(w):
     if m is None or os.environ.get("JP_P9S", "1") == "0":
         return w
     taps = m.group(6)
-    if taps == "1" and m.group(1) == "4" and os.environ.get("JP_P1_TILE", "0") == "1":
-        return f"jp_igemm_p9s_wide_kernel<4, 2, false, false, {m.group(5)}, 1, 2>"        # 8x32-pixel 1x1 tiles (NJ = 4), round 4
+    if taps == "1" and m.group(1) == "4" and os.environ.get("JP_P1L", "0") == "1":
+        # opt-in (round 5): the persistent 1x1 kernel (igemm_p1l.h) where every CU gets >= 8 tiles, the patch kernel elsewhere
+        return (f"jp_conv1x1_p1l_kernel<{m.group(5)}>", f"jp_igemm_p9s_kernel<4, 2, 2, false, false, {m.group(5)}, 1, 2>")
     tile = int(os.environ.get("JP_P9_TILE", "3"))
     if taps == "9" and ((m.group(1) == "4" and tile >= 1) or (m.group(1) == "2" and tile >= 2) or (m.group(1) == "1" and tile >= 3)):
         # round 4: 8x32-pixel "wide" tiles where H % 8 == 0 and they still give >= 256 workgroups, the 4x32 ones elsewhere

@@ -800,3 +800,50 @@ def test_small_channel_direct_conv(N, Cin, Cout, H, W, up, act, bias):
     close(wv.g, wr.grad, rtol=2e-4, msg="dw")
     if bias:
         close(bv.g, br.grad, rtol=2e-4, msg="db")
+
+
+def test_p1l_persistent_1x1():
+    """The opt-in persistent 1x1 kernel (csrc/igemm_p1l.h, JP_P1L=1: weight stages through LDS-DMA, one sequence of stages over a
+    range of tiles; layers.py:147-167 / 184-199 at the CRP shape): forward and dgrad must be BIT-IDENTICAL to the default patch
+    kernel's (same pack, same products in the same order) and the profiler must name the kernel.  The switch is read once per
+    process, so the two runs are subprocesses."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+sys.path.insert(0, %r + "/tools")
+from jperceiver_amd import ops
+from jperceiver_amd.ops import Var, Tape, recording
+from conv_bench import profiled
+g = torch.Generator().manual_seed(7)
+N, C, H, W, Co = 8, 256, 256, 256, 256
+x = torch.randn(N, C, H, W, generator=g).cuda()
+w = (torch.randn(Co, C, 1, 1, generator=g) * C ** -0.5).cuda()
+gy = torch.randn(N, Co, H, W, generator=g).cuda()
+xv, wv = Var(x, True), Var(w, True, torch.zeros_like(w))
+tape = Tape()
+def step():
+    with recording(tape):
+        step.y = ops.conv2d(xv, wv, None, 1, 0, 0, 0)
+    step.y.g = gy
+    tape.backward()
+names = sorted({r[0] for r in profiled(step)})
+h = hashlib.sha256(step.y.t.cpu().numpy().tobytes() + xv.g.cpu().numpy().tobytes()).hexdigest()
+ref = torch.nn.functional.conv2d(x.cpu()[:1], w.cpu())
+err = float((step.y.t[:1].cpu() - ref).abs().max() / ref.abs().max())
+print("RESULT", h, err, "|".join(names))
+''' % (ROOT, ROOT)
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, JP_P1L=flag)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split(" ", 3)
+        out[flag] = (line[1], float(line[2]), line[3])
+    assert "jp_conv1x1_p1l_kernel<FwdEpi>" in out["1"][2] and "jp_conv1x1_p1l_kernel<DgradEpi>" in out["1"][2], out["1"][2]
+    assert "p1l" not in out["0"][2]
+    assert out["0"][0] == out["1"][0], "the persistent 1x1 kernel's results differ from the patch kernel's"
+    assert out["1"][1] < 2e-5
