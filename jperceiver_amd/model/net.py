@@ -158,8 +158,7 @@ class Baseline(nn.Module):
         st = getattr(self, "_side_stream", None)
         if st is None or st.device != dev:
             # on the MODEL's device, not the current one
-            from ..runtime import new_stream
-            st = self._side_stream = new_stream(dev, "JP_SIDE_CUMASK")
+            st = self._side_stream = torch.cuda.Stream(device=dev)
         return st
 
     def _layout_head(self, sfx, F, f4, n_updates):

@@ -121,8 +121,9 @@ def _wgrad_stream():
     key = (base.device, base.cuda_stream)
     st = _WG_STREAMS.get(key)
     if st is None:
-        from .runtime import new_stream
-        st = _WG_STREAMS[key] = new_stream(base.device, "JP_WG_CUMASK")
+        # (confining this stream or the side stream to a subset of the CUs -- hipExtStreamCreateWithCUMask, halves / quarters, disjoint
+        # or not -- was measured in round 5: 82.4 -> 98-109 ms per step, profiles/r05_cumask_ab.log; stream priorities in round 4: no effect)
+        st = _WG_STREAMS[key] = torch.cuda.Stream(device=base.device)
     return st
 
 

@@ -31,28 +31,6 @@ SEGMENT_ORDER = ("DepthDecoder", "heads", "LayoutEncoder", "Pose", "DepthEncoder
 _HEAD_PREFIXES = ("CycledViewProjection", "CrossViewTransformer", "LayoutDecoder", "LayoutTransformDecoder")
 
 
-def new_stream(dev, mask_env=None):
-    """A HIP stream for the step's side work.  With `mask_env` set in the environment to a 32-bit hex pattern (e.g. JP_SIDE_CUMASK=
-    0x11111111: every fourth CU) the stream is created with `hipExtStreamCreateWithCUMask` -- the pattern repeated over the device's
-    CU mask words -- so its kernels can only occupy that subset of the CUs (round-5 experiment, VERDICT r04 item 8:
-    profiles/r05_cumask_ab.log; unset = a plain stream on all CUs)."""
-    import ctypes
-    import os
-    pat = os.environ.get(mask_env) if mask_env else None
-    if not pat:
-        return torch.cuda.Stream(device=dev)
-    hip = ctypes.CDLL("libamdhip64.so")
-    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-    words = (ncu + 31) // 32
-    mask = (ctypes.c_uint32 * words)(*([int(pat, 16) & 0xffffffff] * words))
-    h = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
-    if rc != 0:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-    return torch.cuda.ExternalStream(h.value, device=dev)
-
-
 def segment_of(name: str) -> str:
     top = name.split(".")[0]
     if top.startswith(_HEAD_PREFIXES):
