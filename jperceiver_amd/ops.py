@@ -464,8 +464,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 del ws_s
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
+                # (split-K scratch as in the single-source call: small-grid layers then fold their K slices in a fixed order
+                # instead of meeting in fp32 atomics)
+                nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
+                ws_s = _new((nsd,), dy) if nsd else None
                 _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
-                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (None,))
+                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (ws_s,))
+                del ws_s
                 c0 = 0
                 for v, u in srcs:
                     C = v.t.shape[1]
