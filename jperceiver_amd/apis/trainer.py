@@ -123,21 +123,25 @@ class CapturedStep:
     and the host-side counters the eager step advances (Adam step, RNG counter, BatchNorm `num_batches_tracked`, the pack
     registry's weight epoch) are advanced per replay.  The first `WARMUP` iterations run eagerly on the same static buffers
     (they are real training steps: packs are recorded, scratch and optimizer state are allocated); the graph is captured at
-    the next call and re-captured when the batch signature (keys, shapes, dtypes) changes.  Single process only: RCCL work
-    handles are not captured (world > 1 keeps the eager, overlapped exchange)."""
+    the next call and re-captured when the batch signature (keys, shapes, dtypes) changes.
+
+    More than one rank (round 5; BASELINE.json's configs[4] is an 8-GPU, one-image-per-GPU config): the iteration is TWO graphs
+    around the gradient exchange -- graph A = forward, loss sum, zero_grad, backward; then the bucketed SUM all-reduce of the
+    arena's live prefix issued eagerly (work handles are host objects, not graph nodes); graph B = global norm, clip + Adam
+    (1 / world folded in), weight re-pack.  What this gives up against the eager multi-rank step is the overlap of the exchange
+    with the backward pass (208.7 MB: 0.35-2.4 ms on xGMI); what it removes is the host from ~1 500 launches per step."""
     WARMUP = 2
 
     def __init__(self, runner):
         from ..runtime import FlatAdam
         self.r = runner
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise RuntimeError("CapturedStep: single-process steps only (the bucketed RCCL exchange runs eagerly)")
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if not isinstance(runner.optimizer, FlatAdam):
             raise RuntimeError("CapturedStep needs the flat-arena optimizer (apis.build_optimizer)")
         if runner.batch_processor is not batch_processor:
             raise RuntimeError("CapturedStep replays the stock batch_processor")
         self.m = getattr(runner.model, "module", runner.model)
-        self.sig, self.static, self.graph, self.eager_done = None, None, None, 0
+        self.sig, self.static, self.graph, self.graph_b, self.eager_done = None, None, None, None, 0
         self.replays, self.recaptures = 0, 0
         self._table, self._h2d_done = None, None
 
@@ -176,9 +180,9 @@ class CapturedStep:
                 import gc
                 torch.cuda.synchronize()
                 self.model_out = self.losses = self.loss = None
-                self.graph = None
+                self.graph = self.graph_b = None
                 gc.collect()
-            self.sig, self.graph, self.eager_done = sig, None, 0
+            self.sig, self.graph, self.graph_b, self.eager_done = sig, None, None, 0
             self.static = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in data.items()}
             return
         for k, v in data.items():
@@ -193,6 +197,33 @@ class CapturedStep:
         r.outputs = dict(loss=loss, log_vars=None, num_samples=len(self.static[("color", 0, 0)]))
         r.hook.after_train_iter(r)
         return model_out, losses, loss
+
+    # ---- more than one rank: the iteration in two halves around the exchange
+    def _body_a(self):
+        """forward, loss sum, zero_grad, backward -- everything in front of the exchange (no grad_ready hook: no collective here)"""
+        r = self.r
+        model_out, losses = r.model(dict(self.static))
+        loss = losses.total()
+        r.outputs = dict(loss=loss, log_vars=None, num_samples=len(self.static[("color", 0, 0)]))
+        r.optimizer.zero_grad()
+        loss.backward()
+        return model_out, losses, loss
+
+    def _exchange(self):
+        from ..core.dist_utils import _Exchange
+        ex = _Exchange(self.r.optimizer.arena, getattr(self.r.hook, "bucket_size_mb", -1))
+        ex.events = getattr(self.r.hook, "exposed_events", None)
+        ex.finish(with_norm=False)
+
+    def _body_b(self):
+        """global norm over the reduced prefix, clip + Adam with the 1 / world averaging folded in, weight re-pack epoch"""
+        opt = self.r.optimizer
+        gc = getattr(self.r.hook, "grad_clip", None)
+        max_norm = gc.get("max_norm") if gc else None
+        if max_norm:
+            opt.arena.add_norm_partial(0, opt.arena.live_numel)
+        opt.grad_scale, opt.max_norm = 1.0 / self.world, max_norm
+        opt.step()
 
     def _finish(self, losses, loss, model_out):
         log_vars = LazyLogVars(losses._lv.names, losses._lv.vals)      # async D2H + event, OUTSIDE the captured region
@@ -221,8 +252,15 @@ class CapturedStep:
         gc_was = gc.isenabled()
         gc.disable()                # no collector run (it may destroy HIP objects) while the stream is capturing
         try:
-            with ops.rng_capture(self.base_dev) as cap, torch.cuda.graph(self.graph):
-                self.model_out, self.losses, self.loss = self._body()
+            if self.world == 1:
+                with ops.rng_capture(self.base_dev) as cap, torch.cuda.graph(self.graph):
+                    self.model_out, self.losses, self.loss = self._body()
+            else:
+                with ops.rng_capture(self.base_dev) as cap, torch.cuda.graph(self.graph):
+                    self.model_out, self.losses, self.loss = self._body_a()
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                    self._body_b()
         finally:
             arena.dev_state = None
             if gc_was:
@@ -245,7 +283,12 @@ class CapturedStep:
         self._load(self._prepare(data_batch))
         if self.eager_done < self.WARMUP:                                # real steps, issued launch by launch
             self.eager_done += 1
-            model_out, losses, loss = self._body()
+            if self.world == 1:
+                model_out, losses, loss = self._body()
+            else:                                                        # the same three pieces the replays will run
+                model_out, losses, loss = self._body_a()
+                self._exchange()
+                self._body_b()
             return self._finish(losses, loss, model_out)
         opt, arena = r.optimizer, r.optimizer.arena
         if self.graph is not None and not self._table_current(arena.params.device):
@@ -255,7 +298,7 @@ class CapturedStep:
             import gc
             torch.cuda.synchronize()
             self.model_out = self.losses = self.loss = None
-            self.graph = None
+            self.graph = self.graph_b = None
             gc.collect()
             self.recaptures += 1
         if self.graph is None:
@@ -272,6 +315,9 @@ class CapturedStep:
             self._h2d_done = torch.cuda.Event()
         self._h2d_done.record()
         self.graph.replay()
+        if self.world > 1:
+            self._exchange()
+            self.graph_b.replay()
         ops.rng_advance(self.rng_calls)
         for b, d in self.bn_delta:
             b._pending += d

@@ -101,6 +101,8 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     constexpr int KH = 2 * KGS;                               // k-halves (8 channels each) per stage
     constexpr int CS = 16 * KGS;
     constexpr int PLANE = PR * COLS;                          // 16-byte words per (split, k-half)
+    // (round 5: gathering / splitting / storing the 1x1 kernels' patch by waves 4-7 alone -- so that the older half's in-order vmcnt queue
+    // holds weight loads only -- was measured: 0.561-0.581 -> 0.584-0.599 ms, profiles/r05_p1_halfstg_ab.log; not kept)
     constexpr int ITEMS = KH * PLANE, NQ = (ITEMS + NT - 1) / NT;
     constexpr int STEPS = TAPS * KGS;                         // (tap, group) steps per stage
     constexpr int BMT = 64 * WM;

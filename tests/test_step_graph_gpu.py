@@ -122,3 +122,80 @@ def test_captured_step_recaptures_on_a_new_signature_and_refuses_foreign_setups(
     assert all(v == v for v in out["log_vars"].values())
     with pytest.raises(RuntimeError):
         CapturedStep(Runner(model, lambda *a, **k: None, optim, None))
+
+
+# ------------------------------------------------------------------------------------------- two ranks
+def _two_rank_worker(rank, world, port, q):
+    """One rank of a world-2 gloo job, both ranks on the one GPU: an eager runner (overlapped bucketed exchange through
+    DistOptimizerHook) and a graph runner (CapturedStep: graph A | eager exchange | graph B) take the same steps from identical
+    state on this rank's own batches; every collective is issued in the same order on both ranks."""
+    import os
+    import traceback
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import hashlib
+        import torch.distributed as dist
+        from jperceiver_amd.apis import DataParallelShell
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type="static", split="odometry")
+
+        def runner(graph):
+            model = MONO.module_dict["Baseline"](opt)
+            model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
+            model = model.cuda().train()
+            optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+            return Runner(DataParallelShell(model), batch_processor, optim,
+                          DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), bucket_size_mb=16), step_graph=graph)
+        E, G = runner(False), runner(True)
+        batches = [syn.make_batch(B, HW, HW, FR, HW // 4, (94, 311), "odometry", seed=60 + 10 * rank + i) for i in range(2)]
+        ops.manual_seed(5 + rank)
+        worst_l, worst_p, frac = 0.0, 0.0, 0.0
+        for i in range(5):
+            _copy_state(E, G)
+            c0 = ops._RNG_STATE["ctr"]
+            oe = E.train_iter({k: v.clone() for k, v in batches[i % 2].items()})
+            c1 = ops._RNG_STATE["ctr"]
+            ops._RNG_STATE["ctr"] = c0
+            og = G.train_iter({k: v.clone() for k, v in batches[i % 2].items()})
+            assert ops._RNG_STATE["ctr"] == c1
+            torch.cuda.synchronize()
+            le, lg = dict(oe["log_vars"]), dict(og["log_vars"])
+            for k in le:
+                worst_l = max(worst_l, abs(le[k] - lg[k]) / max(1.0, abs(le[k])))
+            n = E.optimizer.arena.live_numel
+            d = (E.optimizer.arena.params[:n] - G.optimizer.arena.params[:n]).abs()
+            worst_p, frac = max(worst_p, float(d.max())), max(frac, float((d > 1e-7).float().mean()))
+            assert E.optimizer.arena.step_count == G.optimizer.arena.step_count == i + 1
+        digest = hashlib.sha1(G.optimizer.arena.params.detach().cpu().numpy().tobytes()).hexdigest()
+        q.put((rank, worst_l, worst_p, frac, G.captured.replays, digest, None))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, 0, 0, 0, 0, "", traceback.format_exc()))
+
+
+def test_captured_step_two_ranks_two_graphs_around_the_exchange():
+    """CapturedStep with world_size 2 (gloo, both ranks on this GPU): 2 eager warm-up iterations (forward + backward | exchange |
+    clip + Adam issued as the same three pieces), the two captures, then 3 replays -- each against the eager overlapped step from
+    the same state; the replicas of the graph runner stay bit-identical to each other."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=1200) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert r[6] is None, f"rank {r[0]} failed:\n{r[6]}"
+    for rank, worst_l, worst_p, frac, replays, digest, _ in res:
+        assert worst_l <= 2e-5 and worst_p <= 2.2e-4 and frac < 0.02, (rank, worst_l, worst_p, frac)
+        assert replays == 3
+    assert res[0][5] == res[1][5], "the graph runner's replicas diverged"
