@@ -259,7 +259,9 @@ def main():
     cfg = CONFIGS[args.config]
     B, HW, frames = (args.batch or cfg["B"]), args.hw, cfg["frames"]
     optd = make_opt(B, HW, HW, frames, cfg["type"], cfg["split"], loss_sum=cfg["loss_sum"], **cfg.get("extra", {}))
-    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and B <= 2))
+    # more than one rank: only on request (--graph on: graph A | eager exchange | graph B, apis/trainer.py); `auto` calibrates per
+    # process, and the ranks must not choose differently
+    use_graph = args.graph == "on" or (world == 1 and args.graph == "auto" and B <= 2)
     runner, batch = build_runner(optd, dev, world, rank,
                                  dict(B=B, height=HW, width=HW, frame_ids=frames, occ=HW // 4, full_hw=cfg["full_hw"],
                                       split=cfg["split"], seed=1), step_graph=use_graph)
