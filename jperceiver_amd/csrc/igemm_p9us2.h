@@ -27,6 +27,10 @@
 // the next weight loads).  Matrix beside memory on every SIMD, one barrier per stage.
 //
 // Results are bit-identical to the round-3 stream's (same products, same order per accumulator).
+// Measured and not kept (profiles/r05_p9us2_ldsa_ab.log): the S stages' weight fragments through LDS -- LDS-DMA copies of three-step
+// chunks issued by the older half, one barrier per chunk, ds_read_b128 fragments shared by the four waves of a channel half (a quarter
+// of the L2 -> CU weight bytes) -- gives the same results and the same time (3.87-3.95 vs 3.89-3.91 ms): what the L2 stream costs in
+// power the extra LDS traffic, copies and barriers cost again.
 // Preconditions (host-checked): Cout % 128 == 0, C0 % 32 == 0, C1 % 32 == 0 (a stage's patch buffer is its index parity),
 // C2 <= 8, H % 4 == 0, W % 64 == 0.
 #pragma once

@@ -22,6 +22,12 @@ __global__ void fill(unsigned* p, size_t n, unsigned seed, int as_float) {
         else p[i] = (h & 0x807f807fu) | 0x3c003c00u;     // two bf16 of magnitude ~2^-7 .. 2^-6, random sign / mantissa
     }
 }
+__global__ void checksum(const float* p, size_t n, unsigned long long* out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    unsigned long long s = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) s += (unsigned long long)__float_as_uint(p[i]) * (i % 1000003 + 1);
+    atomicAdd(out, s);
+}
 int main(int argc, char** argv) {
     const int N = 8, H = 256, W = 256, C0 = 256, C1 = 256, C2 = 1, M = 256, MT = M / 128;
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
@@ -43,6 +49,12 @@ int main(int argc, char** argv) {
         if (r >= 2) printf("%s %.3f ms  %.0f TF executed\n", argv[0], ms, flops / ms / 1e9);
     }
     if (hipGetLastError() != hipSuccess) { printf("launch error\n"); return 1; }
+    {
+        unsigned long long* cs; hipMalloc(&cs, 8); hipMemset(cs, 0, 8);
+        checksum<<<2048, 256>>>(y, ny, cs);
+        unsigned long long h; hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost);
+        printf("checksum %llx\n", h);
+    }
 #ifdef P9S_TRACE
     unsigned long long t[64];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(jp_p9s_trace), sizeof(t));
