@@ -305,7 +305,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 6 bf16-MFMA "
                           "products of exact 3-way bf16 operand splits (igemm_p9s.h): error vs float64 <= the fp32 FMA chain's "
-                          "(tests/test_split_accuracy_gpu.py); JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
+                          "(tests/test_split_accuracy_gpu.py) on FINITE inputs (an Inf input yields NaN where fp32 arithmetic yields Inf: "
+                          "Inf - bf16(Inf), and Inf x a zero residual split); JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
+            "workload_note": "random-init network: its disparity is pixel noise, so the CGT warp kernels' gathers are L2-miss-bound here "
+                             "(cgt_warp_bwd: 6.3 x its algorithmic bytes, 2.3 x / 1.3 x slower than on a smooth disparity, DESIGN 4.5); "
+                             "the photometric family is overstated by ~1 ms per step against a trained network",
             "config": {"workload": f"{cfg['name']}: {HW}x{HW}, frames {frames}, {B} images/GPU, type {cfg['type']}, "
                                    f"loss_sum {cfg['loss_sum']}, occ {HW // 4}, full-res frame {cfg['full_hw'][0]}x{cfg['full_hw'][1]}",
                        "config_index": args.config, "global_batch": B * world,
