@@ -27,7 +27,14 @@
 #include "igemm.h"
 
 typedef __bf16 jp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 jp_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned jp_u32x4 __attribute__((ext_vector_type(4)));
+
+// JP_NS = operand splits per fp32 value.  3: three bf16 splits, six products (exact operands).  2: two fp16 splits of the operand scaled by
+// a power of two (the caller's, from the tensor's largest magnitude), three products a0 b0 + a0 b1 + a1 b0 -- see jp_split2h below.
+#ifndef JP_NS
+#define JP_NS 3
+#endif
 
 // three-way bf16 split of a pair of floats -> packed words {lo = x, hi = y} of split 0, 1, 2 (round to nearest even)
 __device__ __forceinline__ void jp_split3(float x, float y, unsigned& s0, unsigned& s1, unsigned& s2) {
@@ -42,6 +49,24 @@ __device__ __forceinline__ void jp_split3(float x, float y, unsigned& s0, unsign
     v[1] -= __uint_as_float(h1 & 0xffff0000u);
     const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
     s0 = h0; s1 = h1; s2 = h2;
+}
+
+// two-way fp16 split of a pair of floats scaled by the power of two `sc` (sc * largest magnitude of the tensor in (2^15, 65504]):
+//     h0 = fp16(sc x)    h1 = fp16(sc x - h0)          (both round to nearest; the subtraction is exact)
+// sc x = h0 + h1 to within 2^-23 |sc x| while h1 is a normal fp16, i.e. for every element within 2^-17 of the tensor's largest; below
+// that h1 is subnormal and the error is 2^-25 ABSOLUTE = 2^-40 of the largest magnitude.  The three products a0 b0 + a0 b1 + a1 b0 are
+// exact in fp32 and leave out a1 b1 <= 2^-22 |a b|: measured against float64 on layer-shaped data this is 3-4x BELOW the rounding error
+// of the fp32 accumulation itself (tools/split_study.py), so the result is as far from float64 as an all-fp32 kernel's, to within ~5 %.
+__device__ __forceinline__ void jp_split2h(float x, float y, float sc, unsigned& s0, unsigned& s1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {x * sc, y * sc};
+    const h2 a = __builtin_convertvector(v, h2);
+    const f2 af = __builtin_convertvector(a, f2);
+    f2 r = {v[0] - af[0], v[1] - af[1]};
+    const h2 b = __builtin_convertvector(r, h2);
+    s0 = __builtin_bit_cast(unsigned, a);
+    s1 = __builtin_bit_cast(unsigned, b);
 }
 
 // gather load: SGPR buffer resource + per-lane byte offset (a loop-invariant 32-bit VGPR) + wave-uniform byte offset (SGPR):
@@ -67,10 +92,17 @@ template <class E>
 struct jp_has_put4<E, std::void_t<decltype(&E::put4)>> : std::true_type {};
 template <bool SWAP>
 __device__ __forceinline__ jp_f32x16 jp_mfma_bf16_sw(jp_u32x4 a, jp_u32x4 b, jp_f32x16 c) {
+#if JP_NS == 2
+    if constexpr (SWAP)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(jp_f16x8, b), __builtin_bit_cast(jp_f16x8, a), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(jp_f16x8, a), __builtin_bit_cast(jp_f16x8, b), c, 0, 0, 0);
+#else
     if constexpr (SWAP)
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, b), __builtin_bit_cast(jp_bf16x8, a), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, a), __builtin_bit_cast(jp_bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring of P9S_AHEAD + 1 slots)
@@ -91,8 +123,9 @@ template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, i
           bool ROWB = false>
 __device__ __forceinline__ void jp_igemm_p9s_body(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
-    int s_begin = 0, int s_end = -1) {
+    int s_begin = 0, int s_end = -1, float xsc = 1.f, float osc = 1.f) {
     if (!MASK) { s_begin = 0; s_end = NST; }
+    constexpr int NS = JP_NS;
     constexpr int NT = 64 * WM * WN;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     static_assert(XS == 1 || TAPS == 1, "strided input: 1x1 only");
@@ -116,7 +149,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     // stamps of a 1x1 tile (profiles/r04_p1_trace.log) show ~2 300 cycles per stage with no MFMA in flight (drain, barrier, store,
     // barrier) next to 3 100 (1x1) / 13 800 (3x3) cycles of MFMA issue.  Now stage s + 1's patch is split and stored into the other
     // buffer underneath the MFMAs of stage s (its loads were requested a whole stage earlier) and a stage ends in ONE barrier.
-    constexpr int BUFW = 3 * KH * PLANE;                      // 16-byte words per patch buffer
+    constexpr int BUFW = NS * KH * PLANE;                     // 16-byte words per patch buffer
     // (not where two buffers would cost the 4-wave kernels their second workgroup per CU: the 16x32-pixel tiles of <1, 4> wide)
     constexpr bool DB = P9S_DB != 0 && (WM * WN == 8 || 2 * BUFW * 16 <= 80 * 1024);
     __shared__ jp_u32x4 patch[(DB ? 2 : 1) * BUFW];
@@ -193,13 +226,14 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             jp_u32x4 w0, w1, w2;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                unsigned a, b, c;
-                jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
+                unsigned a, b, c = 0;
+                if constexpr (NS == 2) jp_split2h(rv[q][2 * k], rv[q][2 * k + 1], xsc, a, b);
+                else jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
                 w0[k] = a; w1[k] = b; w2[k] = c;
             }
             patch_[loff[q]] = w0;
             patch_[KH * PLANE + loff[q]] = w1;
-            patch_[2 * KH * PLANE + loff[q]] = w2;
+            if constexpr (NS == 3) patch_[2 * KH * PLANE + loff[q]] = w2;
         }
     };
 
@@ -213,18 +247,18 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 
     // ---- weight stream of this M tile: step u (global over stages) = [split][k-half][row] x 16 B; lane (l31, lhi) of row
     // block i reads [s][lhi][wm*64 + i*32 + l31].  SGPR buffer resource + constant per-lane offset + scalar step offset.
-    constexpr int SBYTES = 3 * 2 * BMT * 16;                  // bytes per step
+    constexpr int SBYTES = NS * 2 * BMT * 16;                 // bytes per step
     constexpr int RING = P9S_AHEAD + 1;
     const long tile_bytes = ((long)NST * STEPS + P9S_AHEAD) * SBYTES;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)(mt + mt_off) * tile_bytes, 0, (int)tile_bytes, 0x00020000);
     const int avo = (lhi * BMT + wm * 64 + l31) * 16;
-    jp_u32x4 ra[RING][2][3];
+    jp_u32x4 ra[RING][2][NS];
     auto aload = [&](int slot, int step_bytes) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NS; ++s)
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
     };
 #pragma unroll
@@ -234,12 +268,12 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     if constexpr (ROWB) {
         // B fragments of pixel row j, [split]: each row is re-read just in time -- row j of the next use is requested while the
         // MFMAs of the other rows run (12*NJ registers instead of a double buffer of 24*NJ)
-        jp_u32x4 rb[NJ][3];
+        jp_u32x4 rb[NJ][NS];
         auto bload = [&](int buf, int j, int u) {
             const int tap = u / KGS, kg = u % KGS;
             const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) rb[j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+            for (int s = 0; s < NS; ++s) rb[j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
         };
 #define JP_P9S_MFMA_ROW(J_, SA_, SB_)                                                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
@@ -260,7 +294,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 for (int j = 0; j < NJ; ++j) {
                     if (j + 1 < NJ) bload(BUF, j + 1, u);
                     __builtin_amdgcn_sched_barrier(0);
-                    JP_P9S_MFMA_ROW(j, 2, 0); JP_P9S_MFMA_ROW(j, 1, 1); JP_P9S_MFMA_ROW(j, 0, 2);
+                    if constexpr (NS == 3) { JP_P9S_MFMA_ROW(j, (NS - 1), 0); JP_P9S_MFMA_ROW(j, 1, 1); JP_P9S_MFMA_ROW(j, 0, (NS - 1)); }
                     JP_P9S_MFMA_ROW(j, 1, 0); JP_P9S_MFMA_ROW(j, 0, 1); JP_P9S_MFMA_ROW(j, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 == NJ && u + 1 < STEPS) bload(BUF, 0, u + 1);
@@ -288,14 +322,14 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
         }
     } else {
         // B fragments of step u: [j][split], compile-time LDS offsets (the step loop is fully unrolled)
-        jp_u32x4 rb[2][NJ][3];
+        jp_u32x4 rb[2][NJ][NS];
         auto bload = [&](int buf, int slot, int u) {
             const int tap = u / KGS, kg = u % KGS;
             const int dy = TAPS == 1 ? 0 : (REV ? 2 - tap / 3 : tap / 3), dx = TAPS == 1 ? 0 : (REV ? 2 - tap % 3 : tap % 3);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) rb[slot][j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
+                for (int s = 0; s < NS; ++s) rb[slot][j][s] = bp[buf * BUFW + s * KH * PLANE + (kg * 2 * PR + j + dy) * COLS + dx];
         };
 #define JP_P9S_MFMA(SA_, SB_)                                                                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
@@ -324,9 +358,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
                 // (the issue order does not matter to the matrix pipe: tools/ubench/mfma_bf16_chain.hip measures 86-90 % of 2.5 PF for
                 // dependent chains, round robin and six-in-a-row alike -- and the compiler's scheduler interleaves them anyway)
-                JP_P9S_MFMA(2, 0);
-                JP_P9S_MFMA(1, 1);
-                JP_P9S_MFMA(0, 2);
+                if constexpr (NS == 3) {
+                    JP_P9S_MFMA((NS - 1), 0);
+                    JP_P9S_MFMA(1, 1);
+                    JP_P9S_MFMA(0, (NS - 1));
+                }
                 JP_P9S_MFMA(1, 0);
                 JP_P9S_MFMA(0, 1);
                 JP_P9S_MFMA(0, 0);
@@ -361,6 +397,14 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #undef JP_P9S_MFMA
 #undef JP_P9S_MFMA_ROW
 
+    if constexpr (NS == 2) {        // undo the operands' power-of-two scales (exact)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= osc;
+    }
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if constexpr (VEC) {
         // transposed tile: col = output channel, row = pixel -> register quad k holds pixels 8k + 4*lhi + {0..3} of the row
