@@ -29,6 +29,8 @@
 #include "igemm_w9s2.h"
 #include "igemm_p9us2.h"
 #include "igemm_p1l.h"
+#include "scale.h"
+constexpr double JP_NPROD = JP_NS == 2 ? 3.0 : 6.0;     // matrix-pipe products per fp32 product of the P9S-family kernels
 #include "igemm_p9sd.h"
 #include "igemm_w4s.h"
 #include "igemm_p9s2d.h"
@@ -77,7 +79,7 @@ __device__ __forceinline__ float pack_slot_sum(const float* wc, int pl) {
     return v;
 }
 
-__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w, long i, const int* p) {
+__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w, long i, const int* p, float sc = 1.f) {
     switch (mode) {
         case PACK_TAP: {       // p = Cout, Cin, KHW, Cp, for_dgrad: wp[tap][row][Cp], rows = Cout (fwd) / Cin (dgrad)
             const int Cout = p[0], Cin = p[1], KHW = p[2], Cp = p[3], for_dgrad = p[4];
@@ -135,22 +137,22 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             const int co = for_dgrad ? c : m, ci = for_dgrad ? m : c;
             return w[((size_t)co * Cin + ci) * KHW + tap];
         }
-        case PACK_SPLIT: {     // p = Cout, Cin, for_dgrad, BMT, KHW (9 or 1), KGS: bf16 three-way split weights in the fragment order
+        case PACK_SPLIT: {     // p = Cout, Cin, for_dgrad, BMT, KHW (9 or 1), KGS: split weights (JP_NS planes; i counts behind the pack header) in the fragment order
                                // of the P9S kernel (igemm_p9s.h): wp[M tile][step = (stage, tap, 16-channel group) (+ slack)]
                                // [split][k-half][row][4 words]; word w4 = the bf16 pair of reduction channels
                                // stage*16*KGS + group*16 + khalf*8 + 2*w4 + {0, 1} (low half = the even channel)
             const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4], KGS = p[5];
             const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
             const long nsteps = (long)(red / (16 * KGS)) * KHW * KGS;
-            const long per_tile = (nsteps + P9S_AHEAD) * 24 * BMT;
+            const long per_tile = (nsteps + P9S_AHEAD) * (JP_NS * 8) * BMT;
             const int mt = (int)(i / per_tile);
             long t = i - (long)mt * per_tile;
             const int w4 = (int)(t & 3); t >>= 2;
             const int m = mt * BMT + (int)(t % BMT);
             t /= BMT;
             const int khalf = (int)(t & 1); t >>= 1;
-            const int sp = (int)(t % 3);
-            const long U = t / 3;
+            const int sp = (int)(t % JP_NS);
+            const long U = t / JP_NS;
             if (U >= nsteps || m >= rows) return 0.f;
             const int stage = (int)(U / (KHW * KGS)), u = (int)(U % (KHW * KGS));
             const int tap = u / KGS, kg = u % KGS;
@@ -162,9 +164,9 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                 const int co = for_dgrad ? cc : m, ci = for_dgrad ? m : cc;
                 v[k] = cc < red ? w[((size_t)co * Cin + ci) * KHW + tap] : 0.f;
             }
-            unsigned s0, s1, s2;
-            jp_split3(v[0], v[1], s0, s1, s2);
-            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+            unsigned sq[3];
+            jp_split_ns(v[0], v[1], sc, sq);
+            return __uint_as_float(sp == 0 ? sq[0] : (sp == 1 ? sq[1] : sq[2]));
         }
         case PACK_SPLIT7: {    // p = Cout (<= 64), Cin: 7x7 stem weights as bf16 three-way splits in the fragment order of the P7S kernel
                                // (igemm_p7s.h): [step u = (c, tap-row pair v)][split][k-half][64 rows][4 words]; word w4 of k-half h =
@@ -209,12 +211,13 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             jp_split3(v[0], v[1], s0, s1, s2);
             return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
         }
-        case PACK_SPLITSEG: {  // p = Cout, Cin, c_off, C, up: one channel segment of an iconv bank as bf16 three-way splits in the
+        case PACK_SPLITSEG: {  // p = Cout, Cin, c_off, C, up, hdr_back: one channel segment of an iconv bank as JP_NS-way splits (the scale header
+                               // of the bank sits hdr_back words in front of this segment, JP_NS == 2) in the
                                // fragment order of the P9US2 kernel (igemm_p9us2.h): [class (up only)][M tile of 128][step = (16-channel
                                // stage, tap | slot)][split][k-half][row 128][4 words]; word w4 = channels stage*16 + khalf*8 + 2*w4 + {0,1}
             const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], up = p[4];
             const int T = up ? 4 : 9, MT = Cout / 128;
-            const long tile = (long)((C + 15) / 16) * T * 3072;
+            const long tile = (long)((C + 15) / 16) * T * (JP_NS * 1024);
             const int cm = (int)(i / tile);
             if (cm >= (up ? 4 : 1) * MT) return 0.f;            // slack words behind the last stream
             long t = i - (long)cm * tile;
@@ -222,8 +225,8 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             const int w4 = (int)(t & 3); t >>= 2;
             const int row = (int)(t & 127); t >>= 7;
             const int khalf = (int)(t & 1); t >>= 1;
-            const int sp = (int)(t % 3);
-            const int U = (int)(t / 3);
+            const int sp = (int)(t % JP_NS);
+            const int U = (int)(t / JP_NS);
             const int stage = U / T, tap = U - stage * T;
             const int c = stage * 16 + khalf * 8 + 2 * w4, co = mt * 128 + row;
             float v[2];
@@ -232,9 +235,9 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                 const float* wc = w + ((size_t)co * Cin + c_off + c + k) * 9;
                 v[k] = (c + k < C && co < Cout) ? (up ? pack_slot_sum(wc, cls * 4 + tap) : wc[tap]) : 0.f;
             }
-            unsigned s0, s1, s2;
-            jp_split3(v[0], v[1], s0, s1, s2);
-            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+            unsigned sq[3];
+            jp_split_ns(v[0], v[1], sc, sq);
+            return __uint_as_float(sp == 0 ? sq[0] : (sp == 1 ? sq[1] : sq[2]));
         }
         case PACK_FRAGSEG: {   // p = Cout, Cin, c_off, C, KP, up: one channel segment of an iconv bank in the fragment order of
                                // the P9U kernel (igemm_p9u.h): [class (up only)][M tile of 128][quad][k parity][row][4],
@@ -264,9 +267,50 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
     }
 }
 
+// Split packs of the fp16 two-way scheme (JP_NS == 2) start with a header {s, 1 / s, 0, 0}: s = the power of two that puts the weight
+// tensor's largest magnitude into [2^14, 2^15) (jp_scale_exp); the fragments hold the splits of s * w.  pack_scale_kernel writes the
+// headers (one workgroup per job) BEFORE the pack kernels of the same stream read them.
+__device__ __forceinline__ int pack_hdr(int mode) { return mode == PACK_SPLIT ? JP_PACK_HDR : 0; }
+// the weight scale a split pack's elements are multiplied by: PACK_SPLIT's own header; PACK_SPLITSEG: the bank's header, p[5] words back
+__device__ __forceinline__ float pack_scale_of(const JpPackJob& j) {
+    if (!JP_PACK_HDR) return 1.f;
+    if (j.mode == PACK_SPLIT) return j.wp[0];
+    if (j.mode == PACK_SPLITSEG) return *(j.wp - j.p[5]);
+    return 1.f;
+}
+__device__ __forceinline__ void pack_scale_job(const JpPackJob& j) {
+    const bool seg = j.mode == PACK_SPLITSEG && j.p[2] == 0;          // the bank's first segment writes the bank's header
+    if (!JP_PACK_HDR || !(j.mode == PACK_SPLIT || seg)) return;
+    float* hdr = seg ? j.wp - j.p[5] : j.wp;
+    const long n = (long)j.p[0] * j.p[1] * (seg ? 9 : j.p[4]);
+    unsigned m = 0;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        m = max(m, jp_amag(__float_as_uint(j.w[i])));    // largest ordinary magnitude (scale.hip)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    __shared__ unsigned sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        // (iconv banks: the upsampled segment's elements are sums of up to four taps -- pack_slot_sum -- and all segments share one scale)
+        const int k = jp_scale_exp(__uint_as_float(m) * (seg ? 4.f : 1.f));
+        hdr[0] = jp_exp2i(k);
+        hdr[1] = jp_exp2i(-k);
+        hdr[2] = hdr[3] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void pack_scale_one_kernel(JpPackJob job) { pack_scale_job(job); }
+__global__ __launch_bounds__(256) void pack_scale_kernel(const JpPackJob* __restrict__ jobs, int njobs) {
+    if ((int)blockIdx.x < njobs) pack_scale_job(jobs[blockIdx.x]);
+}
+
 __global__ __launch_bounds__(256) void pack_one_kernel(JpPackJob job) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < job.total; i += (long)gridDim.x * 256)
-        job.wp[i] = pack_elem(job.mode, job.w, i, job.p);
+    const int hdr = pack_hdr(job.mode);
+    const float sc = pack_scale_of(job);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < job.total - hdr; i += (long)gridDim.x * 256)
+        job.wp[hdr + i] = pack_elem(job.mode, job.w, i, job.p, sc);
 }
 
 // every pack of the model in one launch.  The concatenated element range is walked in groups of FOUR consecutive elements
@@ -354,8 +398,9 @@ __global__ __launch_bounds__(256) void pack_split_replay_kernel(const JpPackJob*
         const int jj = lo, loc = item - pre[lo];
         const JpPackJob& j = jobs[jj];
         const int* p = j.p;
-        unsigned* out = reinterpret_cast<unsigned*>(j.wp);
+        unsigned* out = reinterpret_cast<unsigned*>(j.wp) + pack_hdr(j.mode);
         if (j.mode == PACK_SPLIT) {
+            const float wsc = JP_PACK_HDR ? j.wp[0] : 1.f;
             const int Cout = p[0], Cin = p[1], for_dgrad = p[2], BMT = p[3], KHW = p[4], KGS = p[5];
             const int rows = for_dgrad ? Cin : Cout, red = for_dgrad ? Cout : Cin;
             const int CS = 16 * KGS, nst = red / CS, rch = BMT / 64;
@@ -376,7 +421,7 @@ __global__ __launch_bounds__(256) void pack_split_replay_kernel(const JpPackJob*
             }
             __syncthreads();
             const long nsteps = (long)nst * KHW * KGS;
-            const long per_tile = (nsteps + P9S_AHEAD) * 24 * BMT;
+            const long per_tile = (nsteps + P9S_AHEAD) * (JP_NS * 8) * BMT;
             const int trip = KHW * KGS * 2 * 64;        // (tap, group, k-half, row) triples of this item
             for (int e = t; e < trip; e += 256) {
                 const int r = e & 63, kh = (e >> 6) & 1, u = e >> 7;      // u = tap*KGS + kg
@@ -387,15 +432,15 @@ __global__ __launch_bounds__(256) void pack_split_replay_kernel(const JpPackJob*
                     const int c = kg * 16 + kh * 8 + 2 * k;
                     const float a = for_dgrad ? tile[(c * 64 + r) * KHW + tap] : tile[(r * CS + c) * KHW + tap];
                     const float b = for_dgrad ? tile[((c + 1) * 64 + r) * KHW + tap] : tile[(r * CS + c + 1) * KHW + tap];
-                    unsigned s0, s1, s2;
-                    jp_split3(a, b, s0, s1, s2);
-                    w0[k] = s0; w1[k] = s1; w2[k] = s2;
+                    unsigned sq[3];
+                    jp_split_ns(a, b, wsc, sq);
+                    w0[k] = sq[0]; w1[k] = sq[1]; w2[k] = sq[2];
                 }
                 const long U = (long)stage * KHW * KGS + u;
-                unsigned* q = out + (long)mt * per_tile + ((U * 3) * 2 + kh) * (long)BMT * 4 + (long)(rc * 64 + r) * 4;
+                unsigned* q = out + (long)mt * per_tile + ((U * JP_NS) * 2 + kh) * (long)BMT * 4 + (long)(rc * 64 + r) * 4;
                 *reinterpret_cast<jp_u32x4*>(q) = w0;
                 *reinterpret_cast<jp_u32x4*>(q + 2L * BMT * 4) = w1;
-                *reinterpret_cast<jp_u32x4*>(q + 4L * BMT * 4) = w2;
+                if (JP_NS == 3) *reinterpret_cast<jp_u32x4*>(q + 4L * BMT * 4) = w2;
             }
         } else {            // PACK_SPLITSEG: p = Cout, Cin, c_off, C, up
             const int Cout = p[0], Cin = p[1], c_off = p[2], C = p[3], up = p[4];
@@ -407,8 +452,9 @@ __global__ __launch_bounds__(256) void pack_split_replay_kernel(const JpPackJob*
                 tile[e] = (c0 + c < C && m0 + r < Cout) ? j.w[((size_t)(m0 + r) * Cin + c_off + c0) * 9 + o] : 0.f;
             }
             __syncthreads();
-            const long tl = (long)nst * T * 3072;
+            const long tl = (long)nst * T * (JP_NS * 1024);
             const int ncls = up ? 4 : 1, trip = ncls * T * 2 * 64;
+            const float wsc = pack_scale_of(j);
             for (int e = t; e < trip; e += 256) {
                 const int r = e & 63, kh = (e >> 6) & 1, ct = e >> 7, tap = ct % T, cls = ct / T;
                 jp_u32x4 w0, w1, w2;
@@ -418,15 +464,15 @@ __global__ __launch_bounds__(256) void pack_split_replay_kernel(const JpPackJob*
                     const float* wa = tile + (r * 16 + c) * 9;
                     const float a = up ? pack_slot_sum(wa, cls * 4 + tap) : wa[tap];
                     const float b = up ? pack_slot_sum(wa + 9, cls * 4 + tap) : wa[9 + tap];
-                    unsigned s0, s1, s2;
-                    jp_split3(a, b, s0, s1, s2);
-                    w0[k] = s0; w1[k] = s1; w2[k] = s2;
+                    unsigned sq[3];
+                    jp_split_ns(a, b, wsc, sq);
+                    w0[k] = sq[0]; w1[k] = sq[1]; w2[k] = sq[2];
                 }
                 const long U = (long)stage * T + tap;
-                unsigned* q = out + (long)(cls * MT + mt) * tl + ((U * 3) * 2 + kh) * 512L + (long)(rc * 64 + r) * 4;
+                unsigned* q = out + (long)(cls * MT + mt) * tl + ((U * JP_NS) * 2 + kh) * 512L + (long)(rc * 64 + r) * 4;
                 *reinterpret_cast<jp_u32x4*>(q) = w0;
                 *reinterpret_cast<jp_u32x4*>(q + 1024) = w1;
-                *reinterpret_cast<jp_u32x4*>(q + 2048) = w2;
+                if (JP_NS == 3) *reinterpret_cast<jp_u32x4*>(q + 2048) = w2;
             }
         }
     }
@@ -441,6 +487,8 @@ void do_pack(int mode, const float* w, float* wp, long total, int p0, int p1, in
         if (g_pack_rec_n < g_pack_rec_cap) g_pack_rec[g_pack_rec_n] = j;
         ++g_pack_rec_n;      // counted even when the buffer is full: jp_pack_record_end reports the overflow
     }
+    if (JP_PACK_HDR && (mode == PACK_SPLIT || (mode == PACK_SPLITSEG && p2 == 0)))
+        hipLaunchKernelGGL(pack_scale_one_kernel, dim3(1), dim3(256), 0, st, j);
     hipLaunchKernelGGL(pack_one_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, j);
 }
 
@@ -2149,7 +2197,7 @@ inline bool p9s_enabled() {
 inline int p9s_kgs(int khw) { return khw == 9 ? 1 : 2; }       // 16-channel groups per stage
 inline long p9s_ws_floats(int rows, int red, int khw = 9) {
     const int bmt = rows <= 64 ? 64 : 128, kgs = p9s_kgs(khw);
-    return ((long)(red / (16 * kgs)) * khw * kgs + P9S_AHEAD) * 24 * bmt * jp_cdiv(rows, bmt);
+    return ((long)(red / (16 * kgs)) * khw * kgs + P9S_AHEAD) * (JP_NS * 8) * bmt * jp_cdiv(rows, bmt) + JP_PACK_HDR;
 }
 // scratch that holds either pack of a bank
 inline long p9_alloc_floats(int rows, int red, int khw = 9) { return std::max(p9_ws_floats(rows, red, khw), p9s_ws_floats(rows, (red + 31) / 32 * 32, khw)); }
@@ -2196,7 +2244,7 @@ inline int p9_tile() {
 template <class E>
 const char* p1l_tag() { return __PRETTY_FUNCTION__; }
 inline bool p1l_enabled() {
-    static const bool on = [] { const char* e = getenv("JP_P1L"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char* e = getenv("JP_P1L"); return JP_NS == 3 && e && e[0] == '1'; }();     // (written for the three-plane bf16 pack)
     return on;
 }
 inline int jp_num_cus() {
@@ -2212,14 +2260,16 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
+    const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * H * W, st) : nullptr;
     if constexpr (TAPS == 1) {
         const long ntiles = (long)N * (H / 4) * (W / 32), xb = (long)N * red * H * W * 4;
         if (bmt == 256 && mt_off == 0 && p1l_enabled() && rows % 256 == 0 && red % 128 == 0 && H % 4 == 0 && W % 32 == 0 && xb < (1L << 31) &&
             ntiles >= 8L * jp_num_cus()) {     // (4 tiles per workgroup, the @128^2 layers: no gain over the patch kernel, profiles/r05_p1l_conv_bench.log)
             const int G = jp_num_cus(), tpw = jp_cdiv(ntiles, G);
-            jp_prof_before(p1l_tag<E>(), 6.0 * 2.0 * rows * (double)N * H * W * red, st);
-            hipLaunchKernelGGL((jp_conv1x1_p1l_kernel<E>), dim3(jp_cdiv(ntiles, tpw), rows / 256, 1), dim3(512), 0, st, wq, x, e, rows, red, NST,
-                               H, W, (int)ntiles, tpw, (int)xb);
+            jp_prof_before(p1l_tag<E>(), JP_NPROD * 2.0 * rows * (double)N * H * W * red, st);
+            if constexpr (JP_NS == 3)
+                hipLaunchKernelGGL((jp_conv1x1_p1l_kernel<E>), dim3(jp_cdiv(ntiles, tpw), rows / 256, 1), dim3(512), 0, st, wq, x, e, rows, red, NST,
+                                   H, W, (int)ntiles, tpw, (int)xb);
             jp_prof_after(st);
             return;
         }
@@ -2228,37 +2278,37 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
         // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy (3x3 layers only)
         const int mode = p9_tile();
         if (TAPS == 9 && mode >= 3 && bmt == 64 && H % 16 == 0 && (long)N * (H / 16) * (W / 32) >= 256) {
-            jp_prof_before(p9sw_tag<1, 4, REFLECT, REV, E, TAPS>(), 6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+            jp_prof_before(p9sw_tag<1, 4, REFLECT, REV, E, TAPS>(), JP_NPROD * 2.0 * rows * (double)N * H * W * TAPS * red, st);
             hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<1, 4, REFLECT, REV, E, TAPS, KGS>), dim3(N * (H / 16) * (W / 32), 1, 1), dim3(256), 0,
-                               st, wq, x, e, rows, red, NST, H, W, mt_off);
+                               st, wq, x, e, rows, red, NST, H, W, mt_off, xam);
             jp_prof_after(st);
             return;
         }
         const bool want = (mode >= 1 && bmt == 256) || (mode >= 2 && bmt == 128);
         if (want && H % 8 == 0 && (long)N * (H / 8) * (W / 32) * jp_cdiv(rows, bmt) >= 256) {
             jp_prof_before(bmt == 256 ? p9sw_tag<4, 2, REFLECT, REV, E, TAPS>() : p9sw_tag<2, 2, REFLECT, REV, E, TAPS>(),
-                           6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+                           JP_NPROD * 2.0 * rows * (double)N * H * W * TAPS * red, st);
             dim3 grid(N * (H / 8) * (W / 32), jp_cdiv(rows, bmt), 1);
             if (bmt == 256)
-                hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+                hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off, xam);
             else
-                hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+                hipLaunchKernelGGL((jp_igemm_p9s_wide_kernel<2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off, xam);
             jp_prof_after(st);
             return;
         }
     }
     // executed FLOPs: 6 bf16 MFMA products per fp32 product
     jp_prof_before(bmt == 64 ? p9s_tag<1, 4, REFLECT, REV, E, TAPS>() : (bmt == 256 ? p9s_tag<4, 2, REFLECT, REV, E, TAPS>() : p9s_tag<2, 2, REFLECT, REV, E, TAPS>()),
-                   6.0 * 2.0 * rows * (double)N * H * W * TAPS * red, st);
+                   JP_NPROD * 2.0 * rows * (double)N * H * W * TAPS * red, st);
     if (bmt == 64) {
         dim3 grid(N * (H / 8) * (W / 32), 1, 1);
-        hipLaunchKernelGGL((jp_igemm_p9s_kernel<1, 4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<1, 4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off, xam);
     } else if (bmt == 256) {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 256), 1);
-        hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(512), 0, st, wq, x, e, rows, red, NST, H, W, mt_off, xam);
     } else {
         dim3 grid(N * (H / 4) * (W / 32), jp_cdiv(rows, 128), 1);
-        hipLaunchKernelGGL((jp_igemm_p9s_kernel<2, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<2, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, NST, H, W, mt_off, xam);
     }
     jp_prof_after(st);
 }
@@ -2276,14 +2326,15 @@ template <class E>
 void launch_p1s2(const float* wp, const float* x, E e, int rows, int red, int N, int OH, int OW, hipStream_t st) {
     const int bmt = p9_bmt(rows, 1, p9_ptiles(N, OH, OW)), NST = red / 32;
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
+    const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * (2L * OH) * (2L * OW), st) : nullptr;
     jp_prof_before(bmt == 64 ? p9sx2_tag<1, 4, E>() : (bmt == 256 ? p9sx2_tag<4, 2, E>() : p9sx2_tag<2, 2, E>()),
-                   6.0 * 2.0 * rows * (double)N * OH * OW * red, st);
+                   JP_NPROD * 2.0 * rows * (double)N * OH * OW * red, st);
     if (bmt == 64)
-        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<1, 4, 2, E>), dim3(N * (OH / 8) * (OW / 32), 1, 1), dim3(256), 0, st, wq, x, e, rows, red, NST, OH, OW, 0);
+        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<1, 4, 2, E>), dim3(N * (OH / 8) * (OW / 32), 1, 1), dim3(256), 0, st, wq, x, e, rows, red, NST, OH, OW, 0, xam);
     else if (bmt == 256)
-        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<4, 2, 2, E>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(rows, 256), 1), dim3(512), 0, st, wq, x, e, rows, red, NST, OH, OW, 0);
+        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<4, 2, 2, E>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(rows, 256), 1), dim3(512), 0, st, wq, x, e, rows, red, NST, OH, OW, 0, xam);
     else
-        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<2, 2, 2, E>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(rows, 128), 1), dim3(256), 0, st, wq, x, e, rows, red, NST, OH, OW, 0);
+        hipLaunchKernelGGL((jp_igemm_p9s_x2_kernel<2, 2, 2, E>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(rows, 128), 1), dim3(256), 0, st, wq, x, e, rows, red, NST, OH, OW, 0, xam);
     jp_prof_after(st);
 }
 template <bool REFLECT, bool REV, class E>
@@ -2429,27 +2480,29 @@ static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx,
         // executed FLOPs: 6 bf16 MFMA products per fp32 product
         const int dyb = (int)((long)N * Cout * H * W * 4);
         const int xb = (int)std::min<long>((long)N * Cx * H * W * 4, 0x7fffffffL);       // (w9_plan: the X tensor is < 2 GiB too)
+        const float* gam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * H * W, st) : nullptr;
+        const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * Cx * H * W, st) : nullptr;
         if (p.narrow) {
-            jp_prof_before(w9s_tag<W9S_TRN, REFLECT, 2>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+            jp_prof_before(w9s_tag<W9S_TRN, REFLECT, 2>(), JP_NPROD * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
             dim3 grid(Cm / 64, jp_cdiv(Cout, 64), p.splits);
             hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TRN, REFLECT, 2>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                               p.ntiles, p.tps, dyb, xb);
+                               p.ntiles, p.tps, dyb, xb, gam, xam);
         } else if (p.ncb1) {
             dim3 grid(Cm / 32, Cout / 256, p.splits);
             if (w9s_tr1() == 4) {
-                jp_prof_before(w9s_tag<4, REFLECT, 1, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+                jp_prof_before(w9s_tag<4, REFLECT, 1, 1>(), JP_NPROD * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
                 hipLaunchKernelGGL((jp_wgrad_w9s_kernel<4, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                                   p.ntiles, p.tps, dyb, xb);
+                                   p.ntiles, p.tps, dyb, xb, gam, xam);
             } else {
-                jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+                jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1, 1>(), JP_NPROD * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
                 hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                                   p.ntiles, p.tps, dyb, xb);
+                                   p.ntiles, p.tps, dyb, xb, gam, xam);
             }
         } else {
-            jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1>(), 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
+            jp_prof_before(w9s_tag<W9S_TR, REFLECT, 1>(), JP_NPROD * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
             dim3 grid(Cm / 64, jp_cdiv(Cout, 128), p.splits);
             hipLaunchKernelGGL((jp_wgrad_w9s_kernel<W9S_TR, REFLECT, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                               p.ntiles, p.tps, dyb, xb);
+                               p.ntiles, p.tps, dyb, xb, gam, xam);
         }
         jp_prof_after(st);
         return;
@@ -2689,19 +2742,23 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         const int MT = Cout / 128;
         if (p9us_enabled()) {
             // P9US2: the same tiles on the bf16 matrix pipe (three-way split products, igemm_p9us2.h)
-            const long fS = (long)MT * (c0 / 16) * 9 * 3072, fU = 4L * MT * (c1 / 16) * 4 * 3072, fD = c2 ? (long)MT * 9 * 3072 : 0;
+            constexpr long SF = JP_NS * 1024;         // floats per weight step
+            const long fS = (long)MT * (c0 / 16) * 9 * SF, fU = 4L * MT * (c1 / 16) * 4 * SF, fD = c2 ? (long)MT * 9 * SF : 0;
+            constexpr int HD = JP_PACK_HDR;           // one scale header in front of the bank (JP_NS == 2); every segment knows how far back
             if (!ws_state) {
-                do_pack(PACK_SPLITSEG, w, ws, fS, Cout, Cin, 0, c0, 0, 0, st);
-                do_pack(PACK_SPLITSEG, w, ws + fS, fU, Cout, Cin, c0, c1, 1, 0, st);
-                if (c2) do_pack(PACK_SPLITSEG, w, ws + fS + fU, fD, Cout, Cin, c0 + c1, c2, 0, 0, st);
+                do_pack(PACK_SPLITSEG, w, ws + HD, fS, Cout, Cin, 0, c0, 0, HD, st);
+                do_pack(PACK_SPLITSEG, w, ws + HD + fS, fU, Cout, Cin, c0, c1, 1, (int)(HD + fS), st);
+                if (c2) do_pack(PACK_SPLITSEG, w, ws + HD + fS + fU, fD, Cout, Cin, c0 + c1, c2, 0, (int)(HD + fS + fU), st);
                 // (the kernel's last weight prefetch reads one step past the streams: inside the scratch, never used)
             }
             // P9US2 (igemm_p9us2.h, round 5): every operand request inside an MFMA pair's shadow, the next patch staged by the half of
             // the workgroup that is off the pipe.  (The round-3 stream, its 8-row tiles and its double buffer are gone: logs in
             // profiles/r04_p9us_*.log, r05_p9us2_*.log.)
-            jp_prof_before(p9us2_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
+            const float* xam = JP_NS == 2 ? jp_amax_of3(x0, (long)N * c0 * H * W, x1, (long)N * c1 * (H / 2) * (W / 2), x2,
+                                                        c2 ? (long)N * c2 * H * W : 0L, st) : nullptr;
+            jp_prof_before(p9us2_tag<FwdEpi>(), JP_NPROD * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
             hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
-                               reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W);
+                               reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W, xam);
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }
@@ -2767,9 +2824,10 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             (long)N * Cin * H * W * 4 < (1L << 31) && (long)jp_cdiv(Cout, 128) * N * (OH / 4) * (OW / 32) >= 192) {
             // 3x3 stride 2: P9S2F patch kernel (igemm_p9s2f.h) on the P9S forward pack (instead of the tap-major one)
             if (!ws_state) pack_p9(w, ws, Cout, Cin, 0, 128, 9, st);
-            jp_prof_before(p9s2f_tag<FwdEpi>(), 6.0 * 2.0 * Cout * (double)npix * 9.0 * Cin, st);
+            const float* xam = JP_NS == 2 ? jp_amax_of(x0, (long)N * Cin * H * W, st) : nullptr;
+            jp_prof_before(p9s2f_tag<FwdEpi>(), JP_NPROD * 2.0 * Cout * (double)npix * 9.0 * Cin, st);
             hipLaunchKernelGGL((jp_igemm_p9s2f_kernel<FwdEpi>), dim3(N * (OH / 4) * (OW / 32), jp_cdiv(Cout, 128), 1), dim3(256), 0, st,
-                               reinterpret_cast<const unsigned*>(ws), x0, e, Cout, Cin, Cin / 16, OH, OW);
+                               reinterpret_cast<const unsigned*>(ws), x0, e, Cout, Cin, Cin / 16, OH, OW, xam);
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }
@@ -2965,14 +3023,15 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             if (!ws_state) pack_p9(w, wfr, Cout, Cin, 1, bmt, 9, st);
             const unsigned* wq = reinterpret_cast<const unsigned*>(wfr);
             const int NST = Cout / 16;
+            const float* xam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * OH * OW, st) : nullptr;
             jp_prof_before(bmt == 64 ? p9s2d_tag<1, 4, DgradEpi>() : p9s2d_tag<2, 2, DgradEpi>(),
-                           6.0 * 2.0 * Cin * (double)N * OH * OW * 9.0 * Cout, st);
+                           JP_NPROD * 2.0 * Cin * (double)N * OH * OW * 9.0 * Cout, st);
             if (bmt == 64)
                 hipLaunchKernelGGL((jp_igemm_p9s2d_kernel<1, 4, 2, DgradEpi>), dim3(4 * N * (OH / 8) * (OW / 32), 1, 1), dim3(256), 0, st,
-                                   wq, dy, e, Cin, Cout, NST, OH, OW);
+                                   wq, dy, e, Cin, Cout, NST, OH, OW, xam);
             else
                 hipLaunchKernelGGL((jp_igemm_p9s2d_kernel<2, 2, 2, DgradEpi>), dim3(4 * N * (OH / 4) * (OW / 32), jp_cdiv(Cin, 128), 1),
-                                   dim3(256), 0, st, wq, dy, e, Cin, Cout, NST, OH, OW);
+                                   dim3(256), 0, st, wq, dy, e, Cin, Cout, NST, OH, OW, xam);
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }
@@ -3280,9 +3339,11 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
     W1Plan w1;
     if (single && ws && w1_plan(N, Cin, H, W, Cout, KH, stride, pad, ws_floats, &w1)) {
         if (w9s_enabled()) {    // W1S: the same tile and split-K plan on the bf16 pipe (igemm_w9s.h)
-            jp_prof_before(w1s_tag(), 6.0 * 2.0 * Cout * (double)Cin * N * H * W, st);
+            const float* gam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * H * W, st) : nullptr;
+            const float* xam = JP_NS == 2 ? jp_amax_of(x0, (long)N * Cin * H * W, st) : nullptr;
+            jp_prof_before(w1s_tag(), JP_NPROD * 2.0 * Cout * (double)Cin * N * H * W, st);
             hipLaunchKernelGGL(jp_wgrad_w1s_kernel, dim3(Cin / 128, jp_cdiv(Cout, 256), w1.splits), dim3(512), 0, st, dy, x0, ws, Cout,
-                               Cin, Cin, H, W, w1.ntiles, w1.tps, (int)((long)N * Cout * H * W * 4));
+                               Cin, Cin, H, W, w1.ntiles, w1.tps, (int)((long)N * Cout * H * W * 4), gam, xam);
         } else {
             jp_prof_before(w1_tag(), 2.0 * Cout * (double)Cin * N * H * W, st);
             hipLaunchKernelGGL(jp_wgrad_w1_kernel, dim3(Cin / 128, jp_cdiv(Cout, 256), w1.splits), dim3(512), 0, st, dy, x0, ws, Cout,
@@ -3590,6 +3651,8 @@ extern "C" int jp_pack_record_end(void) {
 // jobs: DEVICE copy of `njobs` records whose `begin` fields hold the exclusive prefix sum of `total`; total_elems = the sum.
 extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, void* stream) {
     JP_CHECK_ARG(jobs && njobs > 0 && total_elems > 0, "pack_replay: bad args");
+    if (JP_PACK_HDR)    // headers (weight scales) of the fp16 split packs first: the pack kernels below read them
+        hipLaunchKernelGGL(pack_scale_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
     hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 4095) / 4096, 16384)), dim3(256), 0,
                        (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
     // the split-bf16 packs of the table: LDS-staged, grid-stride over their work items (a block without an item returns)

@@ -12,6 +12,7 @@
 
 #include "igemm_p9s.h"
 #include "conv_p9sm.h"
+#include "scale.h"
 
 namespace {
 
@@ -59,15 +60,16 @@ void launch(const JpP9smPlan& p, const float* wp, const float* x, E e, int rows,
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     // executed FLOPs (6 bf16 products per fp32 product) of the tiles as launched, padding included
     const double px = (double)N * jp_cdiv(H, p.tr) * p.tr * jp_cdiv(W, 32) * 32;
+    const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * H * W, st) : nullptr;
     jp_prof_before(p.bmt == 64 ? p9sm_tag<1, 4, REFLECT, REV, E, TAPS>() : p9sm_tag<2, 2, REFLECT, REV, E, TAPS>(),
-                   6.0 * 2.0 * rows * px * TAPS * red, st);
+                   (JP_NS == 2 ? 3.0 : 6.0) * 2.0 * rows * px * TAPS * red, st);
     const dim3 grid(N * jp_cdiv(H, p.tr) * jp_cdiv(W, 32), jp_cdiv(rows, p.bmt), p.splits);
     if (p.bmt == 64)
         hipLaunchKernelGGL((jp_igemm_p9sm_kernel<1, 4, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, p.nst,
-                           H, W, p.sps);
+                           H, W, p.sps, xam);
     else
         hipLaunchKernelGGL((jp_igemm_p9sm_kernel<2, 2, 2, REFLECT, REV, E, TAPS, KGS>), grid, dim3(256), 0, st, wq, x, e, rows, red, p.nst,
-                           H, W, p.sps);
+                           H, W, p.sps, xam);
     jp_prof_after(st);
 }
 
@@ -124,3 +126,7 @@ void jp_p9sm_launch(const JpP9smPlan& p, const float* wp, const float* x, float*
     else if (reflect) launch_epi<true, false, 9>(p, wp, x, out, bias, act, accumulate, part, rows, red, N, H, W, st);
     else launch_epi<false, false, 9>(p, wp, x, out, bias, act, accumulate, part, rows, red, N, H, W, st);
 }
+
+// 2: the patch kernels of this build form fp32 products from two fp16 splits per operand (three products, operand scales from
+// jp_amax / scale.hip); 3: from three bf16 splits (six products).  The host mirror uses it to decide whether to hand amax hints.
+extern "C" int jp_split_scheme(void) { return JP_NS; }

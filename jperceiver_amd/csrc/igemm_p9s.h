@@ -33,7 +33,7 @@ typedef unsigned jp_u32x4 __attribute__((ext_vector_type(4)));
 // JP_NS = operand splits per fp32 value.  3: three bf16 splits, six products (exact operands).  2: two fp16 splits of the operand scaled by
 // a power of two (the caller's, from the tensor's largest magnitude), three products a0 b0 + a0 b1 + a1 b0 -- see jp_split2h below.
 #ifndef JP_NS
-#define JP_NS 3
+#define JP_NS 2
 #endif
 
 // three-way bf16 split of a pair of floats -> packed words {lo = x, hi = y} of split 0, 1, 2 (round to nearest even)
@@ -67,6 +67,37 @@ __device__ __forceinline__ void jp_split2h(float x, float y, float sc, unsigned&
     const h2 b = __builtin_convertvector(r, h2);
     s0 = __builtin_bit_cast(unsigned, a);
     s1 = __builtin_bit_cast(unsigned, b);
+}
+
+// exponent k of the power-of-two operand scale 2^k that puts a tensor's largest magnitude `amax` into [2^14, 2^15) (fp16 tops out at
+// 65504); 0 for an all-zero tensor.  jp_amag (below) is what the reductions feed on: Inf / NaN and finite magnitudes of 2^100 and more
+// do not take part in `amax` -- they overflow fp16 under the scale of the rest and are treated like Inf (outputs that read them: NaN).
+// k is clamped to 126 (tensors whose largest magnitude is below 2^-112 are scaled by 2^126: still >= 22 significant bits down to 2^-126).
+__device__ __forceinline__ int jp_scale_exp(float amax) {
+    const unsigned u = __float_as_uint(amax) & 0x7fffffffu;
+    const int k = 14 - ((int)(u >> 23) - 127);
+    return u == 0 ? 0 : min(126, k);
+}
+__host__ __device__ __forceinline__ unsigned jp_amag(unsigned bits) {
+    const unsigned u = bits & 0x7fffffffu;
+    return u >= (227u << 23) ? 0u : u;          // |x| >= 2^100, Inf, NaN: not part of the scale
+}
+__device__ __forceinline__ float jp_exp2i(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+// products of a K step, smallest terms first: M_(split of A, split of B)
+#if JP_NS == 2
+#define JP_SPLIT_PRODUCTS(M_) M_(1, 0); M_(0, 1); M_(0, 0)
+#else
+#define JP_SPLIT_PRODUCTS(M_) M_(2, 0); M_(1, 1); M_(0, 2); M_(1, 0); M_(0, 1); M_(0, 0)
+#endif
+constexpr int JP_PACK_HDR = JP_NS == 2 ? 4 : 0;     // words in front of a split pack: {scale, 1 / scale, 0, 0} of the weights
+// split a pair of floats into the JP_NS packed 16-bit pairs the matrix pipe consumes (s[2] unused for JP_NS == 2)
+__device__ __forceinline__ void jp_split_ns(float x, float y, float sc, unsigned (&s)[3]) {
+#if JP_NS == 2
+    jp_split2h(x, y, sc, s[0], s[1]);
+    s[2] = 0;
+#else
+    jp_split3(x, y, s[0], s[1], s[2]);
+#endif
 }
 
 // gather load: SGPR buffer resource + per-lane byte offset (a loop-invariant 32-bit VGPR) + wave-uniform byte offset (SGPR):
@@ -123,9 +154,17 @@ template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, i
           bool ROWB = false>
 __device__ __forceinline__ void jp_igemm_p9s_body(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
-    int s_begin = 0, int s_end = -1, float xsc = 1.f, float osc = 1.f) {
+    const float* __restrict__ xam, int s_begin = 0, int s_end = -1) {
     if (!MASK) { s_begin = 0; s_end = NST; }
     constexpr int NS = JP_NS;
+    // JP_NS == 2: operand scales.  Input: from its largest magnitude *xam (jp_amax_of, scale.hip); weights: the pack's header
+    float xsc = 1.f, osc = 1.f;
+    if constexpr (NS == 2) {
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        xsc = jp_exp2i(kx);
+        osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
+        wp += JP_PACK_HDR;
+    }
     constexpr int NT = 64 * WM * WN;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     static_assert(XS == 1 || TAPS == 1, "strided input: 1x1 only");
@@ -226,10 +265,9 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             jp_u32x4 w0, w1, w2;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                unsigned a, b, c = 0;
-                if constexpr (NS == 2) jp_split2h(rv[q][2 * k], rv[q][2 * k + 1], xsc, a, b);
-                else jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
-                w0[k] = a; w1[k] = b; w2[k] = c;
+                unsigned sp[3];
+                jp_split_ns(rv[q][2 * k], rv[q][2 * k + 1], xsc, sp);
+                w0[k] = sp[0]; w1[k] = sp[1]; w2[k] = sp[2];
             }
             patch_[loff[q]] = w0;
             patch_[KH * PLANE + loff[q]] = w1;
@@ -294,8 +332,9 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 for (int j = 0; j < NJ; ++j) {
                     if (j + 1 < NJ) bload(BUF, j + 1, u);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (NS == 3) { JP_P9S_MFMA_ROW(j, (NS - 1), 0); JP_P9S_MFMA_ROW(j, 1, 1); JP_P9S_MFMA_ROW(j, 0, (NS - 1)); }
-                    JP_P9S_MFMA_ROW(j, 1, 0); JP_P9S_MFMA_ROW(j, 0, 1); JP_P9S_MFMA_ROW(j, 0, 0);
+#define JP_P9S_ROWJ(SA_, SB_) JP_P9S_MFMA_ROW(j, SA_, SB_)
+                    JP_SPLIT_PRODUCTS(JP_P9S_ROWJ);
+#undef JP_P9S_ROWJ
                     __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 == NJ && u + 1 < STEPS) bload(BUF, 0, u + 1);
                 }
@@ -358,14 +397,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
                 // (the issue order does not matter to the matrix pipe: tools/ubench/mfma_bf16_chain.hip measures 86-90 % of 2.5 PF for
                 // dependent chains, round robin and six-in-a-row alike -- and the compiler's scheduler interleaves them anyway)
-                if constexpr (NS == 3) {
-                    JP_P9S_MFMA((NS - 1), 0);
-                    JP_P9S_MFMA(1, 1);
-                    JP_P9S_MFMA(0, (NS - 1));
-                }
-                JP_P9S_MFMA(1, 0);
-                JP_P9S_MFMA(0, 1);
-                JP_P9S_MFMA(0, 0);
+                JP_SPLIT_PRODUCTS(JP_P9S_MFMA);
                 __builtin_amdgcn_sched_barrier(0);
                 if (DB && u == LSU && stage + 1 < s_end) {          // next stage's patch -> the other buffer, under the MFMAs just issued
                     JP_TR(3 + 4 * (stage & 7));
@@ -447,30 +479,34 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, NJ <= 2 ? 2 : 1) void jp_igemm_p9s_kernel(
-    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
-    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off);
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
+    const float* __restrict__ xam) {
+    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off, xam);
 }
 // "wide" tiles (round 4): NJ = 4 pixel rows per wave (8 rows x 32 columns per workgroup with WN = 2), B fragments re-read row
 // by row (ROWB): a wave's weight fragments serve twice the pixels, i.e. half the L2 -> CU weight-stream bytes per MFMA, and a 3x3
 // patch carries 10 rows for 8 instead of 6 for 4
 template <int WM, int WN, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9s_wide_kernel(
-    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
-    jp_igemm_p9s_body<WM, WN, 4, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off);
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
+    const float* __restrict__ xam) {
+    jp_igemm_p9s_body<WM, WN, 4, REFLECT, REV, Epi, TAPS, KGS, 1, false, true>(wp, x, epi, M, C, NST, H, W, mt_off, xam);
 }
 // small maps (pose encoder 24x80 .. 6x20, BEV 32x32 .. 8x8): masked partial tiles + split-K over grid.z; the epilogue's
 // `slice` member receives blockIdx.z (conv_p9sm.hip)
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9sm_kernel(
-    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int sps) {
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int sps,
+    const float* __restrict__ xam) {
     const int s_begin = blockIdx.z * sps;
     epi.slice = blockIdx.z;
-    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1, true>(wp, x, epi, M, C, NST, H, W, 0, s_begin,
+    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1, true>(wp, x, epi, M, C, NST, H, W, 0, xam, s_begin,
                                                                           min(NST, s_begin + sps));
 }
 // 1x1 stride-2 (the ResNet downsample branches): same tiles, the staging gather reads every second input pixel
 template <int WM, int WN, int NJ, class Epi>
 __global__ __launch_bounds__(64 * WM * WN, NJ <= 2 ? 2 : 1) void jp_igemm_p9s_x2_kernel(
-    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off) {
-    jp_igemm_p9s_body<WM, WN, NJ, false, false, Epi, 1, 2, 2>(wp, x, epi, M, C, NST, H, W, mt_off);
+    const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
+    const float* __restrict__ xam) {
+    jp_igemm_p9s_body<WM, WN, NJ, false, false, Epi, 1, 2, 2>(wp, x, epi, M, C, NST, H, W, mt_off, xam);
 }

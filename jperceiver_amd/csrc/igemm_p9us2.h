@@ -39,7 +39,18 @@
 template <class Epi>
 __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* __restrict__ wp, const float* __restrict__ x0,
                                                                 const float* __restrict__ x1, const float* __restrict__ x2,
-                                                                Epi epi, int M, int C0, int C1, int C2, int H, int W) {
+                                                                Epi epi, int M, int C0, int C1, int C2, int H, int W,
+                                                                const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    // JP_NS == 2 (two fp16 splits, three products): ONE scale for the three sources -- they meet in one accumulator -- from the largest
+    // magnitude over all of them (*xam, jp_amax_of3), the weights' from the pack header of the first segment (all segments carry the same)
+    float xsc = 1.f, osc = 1.f;
+    if constexpr (NS == 2) {
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        xsc = jp_exp2i(kx);
+        osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
+        wp += JP_PACK_HDR;
+    }
     constexpr int NT = 512, NJ = 2;
     constexpr int TR = 2 * NJ;
     constexpr int PRS = TR + 2, PHALF = 34, PITS = 2 * PHALF, COLS_S = 66; // S / D patch rows x [33 even | pad | 33 odd | pad]
@@ -48,8 +59,8 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     constexpr int ITS = 2 * PRS * COLS_S, NQS = (ITS + NT - 1) / NT;       // 792 items -> 2 rounds
     constexpr int ITU = 2 * PRU * PITU;                                    // 272 items -> 1 round
     static_assert(ITU <= NT && NQS == 2, "staging rounds");
-    constexpr int SBYTES = 3 * 2 * 128 * 16;                               // bytes per weight step
-    constexpr int BUFW = 3 * 2 * PLS;
+    constexpr int SBYTES = NS * 2 * 128 * 16;                              // bytes per weight step
+    constexpr int BUFW = NS * 2 * PLS;
     __shared__ jp_u32x4 patch[2 * BUFW];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -94,10 +105,10 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     const int wbytes = MT * TS + 4 * MT * TU + MT * TD + SBYTES;          // + one step of slack for the last prefetch
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(wp), 0, wbytes, 0x00020000);
     const int avo = (lhi * 128 + wm * 64 + l31) * 16;
-    jp_u32x4 ra[2][2][3];
-    // one sixth of a step's weight fragments: a = 3 i + s
+    jp_u32x4 ra[2][2][NS];
+    // one of a step's 2 * NS weight fragments: a = NS i + s
     auto aload1 = [&](int slot, int so, int a) {
-        const int i = a / 3, s = a % 3;
+        const int i = a / NS, s = a % NS;
         ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * 128 * 16), so, 0);
     };
 
@@ -159,23 +170,24 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     // split + store of one item, in seven pieces (four channel pairs, three 16-byte words) so that a piece fits an MFMA gap
     jp_u32x4 w0, w1, w2_;
     auto split_pair = [&](int q, int kp) {
-        unsigned a, b, c;
-        jp_split3(rv[q][2 * kp], rv[q][2 * kp + 1], a, b, c);
-        w0[kp] = a; w1[kp] = b; w2_[kp] = c;
+        unsigned sq[3];
+        jp_split_ns(rv[q][2 * kp], rv[q][2 * kp + 1], xsc, sq);
+        w0[kp] = sq[0]; w1[kp] = sq[1]; w2_[kp] = sq[2];
     };
     auto store_word = [&](jp_u32x4* pb, int loff, int plane, int s) {
         if (loff >= 0) pb[2 * s * plane + loff] = s == 0 ? w0 : (s == 1 ? w1 : w2_);
     };
-    // piece c of the staging of an S / D stage (14 pieces) or a U stage (7 pieces) into patch buffer `buf`
+    // piece c of the staging of an S / D stage (2 NPC pieces) or a U stage (NPC pieces) into patch buffer `buf`
+    constexpr int NPC = 4 + NS;                      // pieces per item: four channel pairs, NS 16-byte words
     auto piece = [&](bool up, int buf, int c) {
-        const int q = c / 7, r = c % 7;
+        const int q = c / NPC, r = c % NPC;
         if (up && q) return;
         if (r < 4) split_pair(q, r);
         else store_word(patch + buf * BUFW, up ? lU : lS[q], up ? PLU : PLS, r - 4);
     };
     auto lstore_all = [&](bool up, int buf) {
 #pragma unroll
-        for (int c = 0; c < 14; ++c) piece(up, buf, c);
+        for (int c = 0; c < 2 * NPC; ++c) piece(up, buf, c);
     };
     // stage k of the whole sequence [S x NS0][U x NS1][D x (C2 ? 1 : 0)]
     auto gload_stage = [&](int k) {
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     const jp_u32x4* bsB = patch + (lhi * PRS + py) * PITS + l31 + (px ? 1 : PHALF);           // u = px + 1
     const jp_u32x4* bu = patch + (lhi * PRU + py) * PITU + l31 + px;
     // B fragments of a step: [row][split 1, 2] and -- split 0 is wanted by the step's first and last product -- [step parity][row] for split 0
-    jp_u32x4 rb0[2][NJ], rb12[NJ][2];
+    jp_u32x4 rb0[2][NJ], rb12[NJ][NS - 1];
     // split s of the B fragments of pixel row j for tap / slot tp (sb: the step's parity, selects the split-0 buffer)
     auto bread1 = [&](bool up, int buf, int j, int tp, int s, int sb) {
         jp_u32x4 v;
@@ -215,9 +227,8 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     };
 #define JP_P9US2_PAIR(J_, SA_, SB_)                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                          \
-        acc[i][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                              \
-            __builtin_bit_cast(jp_bf16x8, ra[(PAR + u) & 1][i][SA_]),                                                      \
-            __builtin_bit_cast(jp_bf16x8, (SB_) == 0 ? rb0[(PAR + u) & 1][J_] : rb12[J_][(SB_) == 0 ? 0 : (SB_) - 1]), acc[i][J_], 0, 0, 0)
+        acc[i][J_] = jp_mfma_bf16_sw<false>(ra[(PAR + u) & 1][i][SA_],                                                     \
+                                            (SB_) == 0 ? rb0[(PAR + u) & 1][J_] : rb12[J_][(SB_) == 0 ? 0 : (SB_) - 1], acc[i][J_])
 
     // One stage of T steps (9 taps or 4 slots) x 2 pixel rows x 6 MFMA pairs.  After pair g of row (u, j):
     //   g = 0..2: split g of the B fragments of the NEXT row (the other row's registers: its MFMAs were issued before this row began);
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
 #endif
         // the first step's fragments: the only LDS reads of a stage that nothing hides (the patch was complete at the barrier)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bread1(UP, BUF, j, 0, s, PAR & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -257,13 +268,14 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
             //   q 0, 1   the next step's split-0 B fragments (other parity buffer);  q 4, 5 / 8, 9: its split-2 / split-1 ones, as
             //            soon as the last product that reads the current ones has issued;
             //   q 7, 10, 11 (older half, steady state): piece 3u + {0, 1, 2} of the next stage's patch.
+            if constexpr (NS == 3) {
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 const int p_ = q >> 1, j = q & 1;
                 // the six products with split index sum <= 2, smallest terms first
-                if (p_ == 0) { JP_P9US2_PAIR(j, 2, 0); }
+                if (p_ == 0) { JP_P9US2_PAIR(j, (NS - 1), 0); }
                 else if (p_ == 1) { JP_P9US2_PAIR(j, 1, 1); }
-                else if (p_ == 2) { JP_P9US2_PAIR(j, 0, 2); }
+                else if (p_ == 2) { JP_P9US2_PAIR(j, 0, (NS - 1)); }
                 else if (p_ == 3) { JP_P9US2_PAIR(j, 1, 0); }
                 else if (p_ == 4) { JP_P9US2_PAIR(j, 0, 1); }
                 else { JP_P9US2_PAIR(j, 0, 0); }
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
 #ifndef P9US2_NOBR
                 if (u + 1 < T) {
                     if (q < 2) bread1(UP, BUF, j, u + 1, 0, (PAR + u + 1) & 1);
-                    else if (q == 4 || q == 5) bread1(UP, BUF, j, u + 1, 2, 0);
+                    else if (q == 4 || q == 5) bread1(UP, BUF, j, u + 1, NS - 1, 0);
                     else if (q == 8 || q == 9) bread1(UP, BUF, j, u + 1, 1, 0);
                 }
 #endif
@@ -284,6 +296,35 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            } else {
+            // two fp16 splits, three products (1,0) (0,1) (0,0): q = 2 * product + row indexes 6 pairs; after pair q:
+            //   q 0..3   the next step's weights, split 1 first;   q 0, 1: its split-0 B fragments (other parity buffer);  q 4, 5: its split-1
+            //            ones (the last product that reads the current ones, (0,1), has issued);
+            //   q 3, 5 (older half, steady state): piece 2u + {0, 1} of the next stage's patch.
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int p_ = q >> 1, j = q & 1;
+                if (p_ == 0) { JP_P9US2_PAIR(j, 1, 0); }
+                else if (p_ == 1) { JP_P9US2_PAIR(j, 0, 1); }
+                else { JP_P9US2_PAIR(j, 0, 0); }
+#ifndef P9US2_NOA
+                if (q < 4) aload1((PAR + u + 1) & 1, so, 2 * (q & 1) + 1 - (q >> 1));
+#endif
+#ifndef P9US2_NOBR
+                if (u + 1 < T) {
+                    if (q < 2) bread1(UP, BUF, j, u + 1, 0, (PAR + u + 1) & 1);
+                    else if (q >= 4) bread1(UP, BUF, j, u + 1, 1, 0);
+                }
+#endif
+#ifndef P9US2_NOSTG
+                if (ROLE == 0 && NK != 2 && (q == 3 || q == 5)) {
+                    const int c = 2 * u + (q == 3 ? 0 : 1);
+                    if (c < (NK == 1 ? NPC : 2 * NPC)) piece(NK == 1, BUF ^ 1, c);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
             }
         }
 #ifdef P9S_TRACE
@@ -310,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     {
         const int so = __builtin_amdgcn_readfirstlane(NS0 ? offS : offU);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) aload1(0, so, a);
+        for (int a = 0; a < 2 * NS; ++a) aload1(0, so, a);
     }
     gload_stage(0);
     lstore_stage(0, 0);
@@ -359,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < M) epi.put(se, m, acc[i][j][r]);
+                if (m < M) epi.put(se, m, NS == 2 ? acc[i][j][r] * osc : acc[i][j][r]);
             }
         }
     }

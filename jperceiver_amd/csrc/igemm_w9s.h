@@ -39,7 +39,17 @@ typedef short jp_s16x8 __attribute__((ext_vector_type(8)));
 template <int TR, bool REFLECT, int KG = 1, int NCB = 2>
 __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
-                                                             int ntiles, int tiles_per_split, int dy_bytes, int x_bytes) {
+                                                             int ntiles, int tiles_per_split, int dy_bytes, int x_bytes,
+                                                             const float* __restrict__ gam, const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    // JP_NS == 2: power-of-two scales of dY and X from their largest magnitudes (scale.hip); the sums are scaled back on the way out
+    float gsc = 1.f, xsc = 1.f, osc = 1.f;
+    if constexpr (NS == 2) {
+        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(gam[0])), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        gsc = jp_exp2i(kg_);
+        xsc = jp_exp2i(kx_);
+        osc = jp_exp2i(-kg_) * jp_exp2i(-kx_);
+    }
     constexpr int NT = 512, PR = TR + 2, PC = 34;
     constexpr int SLOTS = PR * PC;                 // patch pixels
     constexpr int CBP = SLOTS * 64;                // bytes per (split, channel block) plane
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     static_assert(2 * SPL + ((TR + 1) * PC + 18) * 64 + 256 < 65536, "transpose-read immediates must fit 16 bits");
     static_assert(KGW % 2 == 0, "a wave's K groups per tile: whole pixel rows, and an even count (operand / fragment set parities)");
     constexpr bool DB = W9S_DB != 0;
-    constexpr int BUFB = 3 * SPL;                  // bytes per patch buffer
+    constexpr int BUFB = NS * SPL;                 // bytes per patch buffer
     __shared__ __attribute__((aligned(16))) unsigned char patch[(DB ? 2 : 1) * BUFB];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -148,13 +158,13 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     auto lstore1 = [&](int q, int wbuf) {           // item q of the staged patch -> buffer at byte offset wbuf
         if (ilds[q] < 0) return;
         const int off = wbuf + ilds[q];
-        unsigned a0, a1, a2, b0, b1, b2;
-        jp_split3(rv[q][0], rv[q][1], a0, a1, a2);
-        jp_split3(rv[q][2], rv[q][3], b0, b1, b2);
+        unsigned a[3], b[3];
+        jp_split_ns(rv[q][0], rv[q][1], xsc, a);
+        jp_split_ns(rv[q][2], rv[q][3], xsc, b);
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u2*>(patch + off) = u2{a0, b0};
-        *reinterpret_cast<u2*>(patch + SPL + off) = u2{a1, b1};
-        *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a2, b2};
+        *reinterpret_cast<u2*>(patch + off) = u2{a[0], b[0]};
+        *reinterpret_cast<u2*>(patch + SPL + off) = u2{a[1], b[1]};
+        if constexpr (NS == 3) *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a[2], b[2]};
     };
     auto lstore = [&](int wbuf) {
 #pragma unroll
@@ -177,16 +187,30 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     //   * the six transpose reads of tap t + 1 go out one behind each of the six MFMAs of tap t;
     //   * the next tile's patch items keep their place behind the taps of the tile's last K group (W9S_DB).
     // Same products in the same order: results are bit-identical to the round-4 stream.
-    jp_u32x4 sa[2][3];                                   // [K group parity][split]: bf16 operand sets
+    jp_u32x4 sa[2][NS];                                  // [K group parity][split]: 16-bit operand sets
+    constexpr int NPIECE = 4 * NS;                       // pieces of one K group's dY split: (pair, phase)
+    constexpr int NPROD = NS == 2 ? 3 : 6;               // matrix products per fp32 product
     float sr[2];                                         // residuals of the pair being split (between two pieces)
     // piece c = 3 * pair + phase of the split of raw set `rs` into operand set `ds`; pair p = floats 2p, 2p + 1 of the 8 pixels
     auto split_piece = [&](int rs, int ds, int c) {
-        const int pr = c / 3, ph = c % 3;
+        const int pr = c / NS, ph = c % NS;
         const jp_u32x4& src = araw[rs][pr >> 1];
         typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         typedef float f2 __attribute__((ext_vector_type(2)));
         const int k = 2 * (pr >> 1) + (pr & 1);          // word of the operand registers: lo pairs 0, 1 -> 0, 1; hi pairs -> 2, 3
-        if (ph == 0) {
+        if constexpr (NS == 2) {                         // fp16 two-way split of gsc * dY (jp_split2h, in two pieces)
+            if (ph == 0) {
+                const float x_ = __uint_as_float(src[2 * (pr & 1)]) * gsc, y_ = __uint_as_float(src[2 * (pr & 1) + 1]) * gsc;
+                const h2 a = __builtin_convertvector(f2{x_, y_}, h2);
+                const f2 af = __builtin_convertvector(a, f2);
+                sr[0] = x_ - af[0];
+                sr[1] = y_ - af[1];
+                sa[ds][0][k] = __builtin_bit_cast(unsigned, a);
+            } else {
+                sa[ds][1][k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{sr[0], sr[1]}, h2));
+            }
+        } else if (ph == 0) {
             const float x_ = __uint_as_float(src[2 * (pr & 1)]), y_ = __uint_as_float(src[2 * (pr & 1) + 1]);
             const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x_, y_}, bf2));
             sr[0] = x_ - __uint_as_float(h0 << 16);
@@ -198,18 +222,18 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
             sr[1] -= __uint_as_float(h1 & 0xffff0000u);
             sa[ds][1][k] = h1;
         } else {
-            sa[ds][2][k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{sr[0], sr[1]}, bf2));
+            sa[ds][NS - 1][k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{sr[0], sr[1]}, bf2));
         }
     };
     typedef short jp_s16x4_ __attribute__((ext_vector_type(4)));
-    jp_s16x4_ bh[2][3][2];                               // [tap parity][split][pixel half] transpose-read results
+    jp_s16x4_ bh[2][NS][2];                              // [tap parity][split][pixel half] transpose-read results
     auto bread_half = [&](int ty, int tx, int g, int s, int h) -> jp_s16x4_ {
         const int imm = s * SPL + ((g / 2 + ty) * PC + 16 * (g % 2) + tx) * 64;
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (jp_s16x4 __attribute__((address_space(3)))*)(patch + (bbase[tx][h] + rbuf) + imm + 256 * h));
     };
-    auto bfrag = [&](int par, int s) -> jp_bf16x8 {
-        return __builtin_bit_cast(jp_bf16x8, __builtin_shufflevector(bh[par][s][0], bh[par][s][1], 0, 1, 2, 3, 4, 5, 6, 7));
+    auto bfrag = [&](int par, int s) -> jp_u32x4 {
+        return __builtin_bit_cast(jp_u32x4, __builtin_shufflevector(bh[par][s][0], bh[par][s][1], 0, 1, 2, 3, 4, 5, 6, 7));
     };
     if (T0 < T1) {
         int img, y0, x0;
@@ -222,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         gload(T0);
         if (DB) lstore(0);
 #pragma unroll
-        for (int c = 0; c < 12; ++c) split_piece(0, 0, c);
+        for (int c = 0; c < NPIECE; ++c) split_piece(0, 0, c);
         for (int T = T0; T < T1; ++T) {
             if (!DB) lstore(0);
             __syncthreads();                                        // DB: buffer rbuf is complete, the other one is free
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
             tile_org(T + 2, img, y0, x0);
             const int tbnn = (img * Cout) * (int)HW + y0 * W + x0;
 #pragma unroll
-            for (int s_ = 0; s_ < 3; ++s_)
+            for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) bh[0][s_][h] = bread_half(0, 0, 0, s_, h);
 #pragma unroll
@@ -240,24 +264,28 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
                 if (gi + 2 < KGW) aload(cur, tb, kg * KGW + gi + 2);
                 else if (gi + 2 - KGW < KGW) aload(cur, tbn, kg * KGW + gi + 2 - KGW);
                 else aload(cur, tbnn, kg * KGW + gi + 2 - 2 * KGW);
-                const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[cur][0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[cur][1]),
-                                a2 = __builtin_bit_cast(jp_bf16x8, sa[cur][2]);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int tp = (9 * gi + tap) & 1;               // fragment set of this tap (9 taps per K group: the parity runs on)
 #pragma unroll
-                    for (int m = 0; m < 6; ++m) {
-                        // the six products with split index sum <= 2, smallest terms first
-                        const jp_bf16x8 av = (m == 0) ? a2 : ((m == 1 || m == 3) ? a1 : a0);
-                        const int sb = (m == 0 || m == 3 || m == 5) ? 0 : ((m == 1 || m == 4) ? 1 : 2);
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bfrag(tp, sb), acc[tap], 0, 0, 0);
-                        // behind MFMA m: transpose read m of the next tap (of the next K group's first tap behind the last one)
-                        if (tap + 1 < 9) bh[tp ^ 1][m >> 1][m & 1] = bread_half((tap + 1) / 3, (tap + 1) % 3, g, m >> 1, m & 1);
-                        else if (gi + 1 < KGW) bh[tp ^ 1][m >> 1][m & 1] = bread_half(0, 0, g + 1, m >> 1, m & 1);
-                        // ... and, behind every fourth MFMA, one piece of the next K group's dY split
+                    for (int m = 0; m < NPROD; ++m) {
+                        // the products with split index sum <= NS - 1, smallest terms first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0) | (1,0) (0,1) (0,0)
+                        const int sa_ = NS == 3 ? ((m == 0) ? 2 : ((m == 1 || m == 3) ? 1 : 0)) : (m == 0 ? 1 : 0);
+                        const int sb = NS == 3 ? ((m == 0 || m == 3 || m == 5) ? 0 : ((m == 1 || m == 4) ? 1 : 2)) : (m == 1 ? 1 : 0);
+                        acc[tap] = jp_mfma_bf16_sw<false>(sa[cur][sa_], bfrag(tp, sb), acc[tap]);
+                        // behind the MFMAs of a tap: the 2 * NS transpose reads of the next tap (of the next K group's first tap behind the
+                        // last one), one per MFMA (six products) or two behind the first (three products)
+#pragma unroll
+                        for (int rd = 0; rd < 2 * NS; ++rd) {
+                            if ((NS == 3 ? rd : (rd < 2 ? 0 : rd - 1)) != m) continue;
+                            if (tap + 1 < 9) bh[tp ^ 1][rd >> 1][rd & 1] = bread_half((tap + 1) / 3, (tap + 1) % 3, g, rd >> 1, rd & 1);
+                            else if (gi + 1 < KGW) bh[tp ^ 1][rd >> 1][rd & 1] = bread_half(0, 0, g + 1, rd >> 1, rd & 1);
+                        }
+                        // ... and, spread over the K group, the pieces of the next K group's dY split
                         {
-                            const int slot = 6 * tap + m;
-                            if (slot >= 2 && (slot - 2) % 4 == 0 && (slot - 2) / 4 < 12) split_piece(cur ^ 1, cur ^ 1, (slot - 2) / 4);
+                            const int slot = NPROD * tap + m;
+                            constexpr int EVERY = NS == 3 ? 4 : 3;
+                            if (slot >= 2 && (slot - 2) % EVERY == 0 && (slot - 2) / EVERY < NPIECE) split_piece(cur ^ 1, cur ^ 1, (slot - 2) / EVERY);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -284,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < Cout) wz[(long)m * Np + n] = acc[tap][r];
+            if (m < Cout) wz[(long)m * Np + n] = NS == 2 ? acc[tap][r] * osc : acc[tap][r];
         }
     }
 }
@@ -301,13 +329,22 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
 // Preconditions: Cm % 128 == 0, W % 32 == 0, H % 4 == 0 (rows >= Cout are clamped / masked).
 __global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
-                                                             int ntiles, int tiles_per_split, int dy_bytes) {
+                                                             int ntiles, int tiles_per_split, int dy_bytes,
+                                                             const float* __restrict__ gam, const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    float gsc = 1.f, xsc = 1.f, osc = 1.f;       // JP_NS == 2: operand scales, see jp_wgrad_w9s_kernel
+    if constexpr (NS == 2) {
+        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(gam[0])), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        gsc = jp_exp2i(kg_);
+        xsc = jp_exp2i(kx_);
+        osc = jp_exp2i(-kg_) * jp_exp2i(-kx_);
+    }
     constexpr int NT = 512, TR = 4, NC = 128, P = TR * 32;
     constexpr int PITCH = P * 2 + 16;                 // bytes per channel row of one split plane
     constexpr int SPL = NC * PITCH;                   // bytes per split plane
     constexpr int NQ = NC * (P / 8) / NT;             // (channel, pixel octet) items per thread: 4
     constexpr int KGR = TR * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NS * SPL];
     const int t = threadIdx.x, lane = t & 63;
     const int ab = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -369,16 +406,16 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __res
             jp_u32x4 w0, w1, w2;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                unsigned a, b, cc;
-                jp_split3(__uint_as_float(rx[q][0][2 * k]), __uint_as_float(rx[q][0][2 * k + 1]), a, b, cc);
-                w0[k] = a; w1[k] = b; w2[k] = cc;
-                jp_split3(__uint_as_float(rx[q][1][2 * k]), __uint_as_float(rx[q][1][2 * k + 1]), a, b, cc);
-                w0[2 + k] = a; w1[2 + k] = b; w2[2 + k] = cc;
+                unsigned sq[3];
+                jp_split_ns(__uint_as_float(rx[q][0][2 * k]), __uint_as_float(rx[q][0][2 * k + 1]), xsc, sq);
+                w0[k] = sq[0]; w1[k] = sq[1]; w2[k] = sq[2];
+                jp_split_ns(__uint_as_float(rx[q][1][2 * k]), __uint_as_float(rx[q][1][2 * k + 1]), xsc, sq);
+                w0[2 + k] = sq[0]; w1[2 + k] = sq[1]; w2[2 + k] = sq[2];
             }
             unsigned char* d = patch + c * PITCH + o * 16;
             *reinterpret_cast<jp_u32x4*>(d) = w0;
             *reinterpret_cast<jp_u32x4*>(d + SPL) = w1;
-            *reinterpret_cast<jp_u32x4*>(d + 2 * SPL) = w2;
+            if constexpr (NS == 3) *reinterpret_cast<jp_u32x4*>(d + 2 * SPL) = w2;
         }
     };
     jp_f32x16 acc[4];
@@ -388,8 +425,8 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __res
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // B fragment of K group g (tile row g/2, columns 16*(g%2) + 8*lhi .. +7 = octet 4*(g/2) + 2*(g%2) + lhi), block j, split s
     const unsigned char* bp = patch + l31 * PITCH + lhi * 16;
-    auto bread = [&](int g, int j, int s) -> jp_bf16x8 {
-        return __builtin_bit_cast(jp_bf16x8, *reinterpret_cast<const jp_u32x4*>(bp + s * SPL + j * 32 * PITCH + (4 * (g / 2) + 2 * (g % 2)) * 16));
+    auto bread = [&](int g, int j, int s) -> jp_u32x4 {
+        return *reinterpret_cast<const jp_u32x4*>(bp + s * SPL + j * 32 * PITCH + (4 * (g / 2) + 2 * (g % 2)) * 16);
     };
     if (T0 < T1) {
         int img, y0, x0;
@@ -412,32 +449,26 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __res
                     const jp_u32x4 lo = araw[g & 1][0], hi = araw[g & 1][1];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        unsigned s0, s1, s2;
-                        jp_split3(__uint_as_float(lo[2 * k]), __uint_as_float(lo[2 * k + 1]), s0, s1, s2);
-                        sa[0][k] = s0; sa[1][k] = s1; sa[2][k] = s2;
-                        jp_split3(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), s0, s1, s2);
-                        sa[0][2 + k] = s0; sa[1][2 + k] = s1; sa[2][2 + k] = s2;
+                        unsigned sq[3];
+                        jp_split_ns(__uint_as_float(lo[2 * k]), __uint_as_float(lo[2 * k + 1]), gsc, sq);
+                        sa[0][k] = sq[0]; sa[1][k] = sq[1]; sa[2][k] = sq[2];
+                        jp_split_ns(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), gsc, sq);
+                        sa[0][2 + k] = sq[0]; sa[1][2 + k] = sq[1]; sa[2][2 + k] = sq[2];
                     }
                 }
-                const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[1]),
-                                a2 = __builtin_bit_cast(jp_bf16x8, sa[2]);
-                jp_bf16x8 bq[2][3];
+                jp_u32x4 bq[2][3];
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_) bq[0][s_] = bread(g, 0, s_);
+                for (int s_ = 0; s_ < NS; ++s_) bq[0][s_] = bread(g, 0, s_);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j + 1 < 4) {
 #pragma unroll
-                        for (int s_ = 0; s_ < 3; ++s_) bq[(j + 1) & 1][s_] = bread(g, j + 1, s_);
+                        for (int s_ = 0; s_ < NS; ++s_) bq[(j + 1) & 1][s_] = bread(g, j + 1, s_);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const jp_bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][1], b2 = bq[j & 1][2];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+#define JP_W1S_MFMA(SA_, SB_) acc[j] = jp_mfma_bf16_sw<false>(sa[SA_], bq[j & 1][SB_], acc[j])
+                    JP_SPLIT_PRODUCTS(JP_W1S_MFMA);
+#undef JP_W1S_MFMA
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -452,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < Cout) wz[(long)m * Cm + n] = acc[j][r];
+            if (m < Cout) wz[(long)m * Cm + n] = NS == 2 ? acc[j][r] * osc : acc[j][r];
         }
     }
 }

@@ -21,10 +21,11 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 class Var:
     """A device tensor plus its (lazily allocated) gradient buffer.  `p`: the nn.Parameter a weight Var was made from
     (ops.param) -- conv weights of parameters get persistent packed copies (PackRegistry), raw tensors do not."""
-    __slots__ = ("t", "g", "rg", "p")
+    __slots__ = ("t", "g", "rg", "p", "amax")
 
     def __init__(self, t: torch.Tensor, rg: bool = False, g: torch.Tensor | None = None, p=None):
         self.t, self.rg, self.g, self.p = t, rg, g, p
+        self.amax = None        # device scalar max|t| once a convolution asked for it (_amax_of; fp16 split kernels' operand scale)
 
     def grad_buf(self):
         """-> (buffer, accumulate flag) for kernels that can either write or add."""
@@ -311,6 +312,52 @@ def _conv_call(name, w: Var, which: str, sig, nfloats: int, args_before_ws, args
         call(name, *args_before_ws, e.ws, 1, *args_after_ws)
 
 
+# ---- operand scales of the fp16 two-way split kernels (csrc/scale.hip): a tensor's largest magnitude is reduced ONCE and handed to
+# every convolution call that reads the tensor (forward + weight gradient for an activation, dgrad + weight gradient for a gradient)
+_SPLIT_SCHEME = []
+
+
+def split_scheme() -> int:
+    """2: the library's patch kernels use two fp16 splits per operand (three products), 3: three bf16 splits (six products)."""
+    if not _SPLIT_SCHEME:
+        _SPLIT_SCHEME.append(int(_jplib().fn["jp_split_scheme"]()))
+    return _SPLIT_SCHEME[0]
+
+
+def _amax_of(v) -> torch.Tensor | None:
+    """Device scalar max|v|, reduced on first request and cached on a Var; None when the library does not use operand scales."""
+    if split_scheme() != 2:
+        return None
+    if isinstance(v, Var):
+        if v.amax is None:
+            v.amax = _amax_of(v.t)
+        return v.amax
+    out = torch.empty(1, device=v.device, dtype=torch.float32)
+    call("jp_amax", v, v.numel(), out)
+    return out
+
+
+class _amax_hints:
+    """with _amax_hints((tensor, amax), ...): the conv entry points called inside read the operands' largest magnitudes from
+    `amax` instead of reducing them again (jp_amax_hint; pairs with amax None are skipped)."""
+
+    def __init__(self, *pairs):
+        self.pairs = [(t, a) for t, a in pairs if a is not None and t is not None]
+
+    def __enter__(self):
+        if self.pairs:
+            f = _jplib().fn["jp_amax_hint"]
+            for t, a in self.pairs:
+                if f(t.data_ptr(), a.data_ptr()) != 0:
+                    raise RuntimeError(_jplib().last_error())
+        return self
+
+    def __exit__(self, *exc):
+        if self.pairs:
+            _jplib().fn["jp_amax_hint_clear"]()
+        return False
+
+
 def _ws_floats(Cin, Cout, KH, which):
     """Caller-owned packed-weight scratch of the conv fast path (jp_conv2d_ws_floats)."""
     return int(_jplib().fn["jp_conv2d_ws_floats"](Cin, Cout, KH, which))
@@ -354,8 +401,11 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
     nsp = int(_jplib().fn["jp_conv2d_fwd_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
     ws_s = _new((nsp,), w.t) if nsp else None      # fixed-order split-K reduction of small-grid layers
     sig = (tuple(s3[1::3]), tuple(s3[2::3]), N, H, W, stride, pad, pad_mode)
-    _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
-               (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act), (ws_s,))
+    big = Cin >= 32 and Cout >= 32            # (the few-channel layers run direct kernels without operand scales)
+    x_hints = [(v.t, _amax_of(v)) for v, _ in srcs] if big else []
+    with _amax_hints(*x_hints):
+        _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
+                   (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act), (ws_s,))
     del ws_s
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
 
@@ -373,7 +423,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             else:
                 call("jp_act_bwd", dy, y, d2, dy.numel(), act)
             dy = d2
+        dy_hint = (dy, _amax_of(dy)) if big else (None, None)      # on the tape's stream, before the wgrad stream forks off it
+
         def param_grads():
+            with _amax_hints(dy_hint, *x_hints):
+                _param_grads()
+
+        def _param_grads():
             if b is not None and b.rg and not bias_done:
                 call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
             if w.rg:
@@ -435,7 +491,11 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             dy.record_stream(wgs)
             for v, _ in srcs:
                 v.t.record_stream(wgs)
+            for _, a in (dy_hint, *x_hints):        # the operands' largest magnitudes are read on that stream too
+                if a is not None:
+                    a.record_stream(wgs)
         if any(v.rg for v, _ in srcs):
+          with _amax_hints(dy_hint):
             nwd = _ws_floats(Cin, Cout, KH, 1) if Cout >= 16 else 0
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()

@@ -29,15 +29,17 @@ int main(int argc, char** argv) {
     hipMalloc(&dy, n * 4); hipMalloc(&x, n * 4); hipMalloc(&ws, nws * 4); hipMalloc(&cs, 8);
     fill<<<4096, 256>>>(dy, n, 1u); fill<<<4096, 256>>>(x, n, 2u);
     hipMemset(ws, 0, nws * 4); hipMemset(cs, 0, 8);
+    float* am; hipMalloc(&am, 8);                       // largest magnitudes of dY / X for the fp16 split build (-DJP_NS=2): the fill is in [-2, 2)
+    { const float h[2] = {2.f, 2.f}; hipMemcpy(am, h, 8, hipMemcpyHostToDevice); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const double flops = 6.0 * 2.0 * Cout * 9.0 * C * (double)N * H * W;
+    const double flops = (JP_NS == 2 ? 3.0 : 6.0) * 2.0 * Cout * 9.0 * C * (double)N * H * W;
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((jp_wgrad_w9s_kernel<4, true, 1, 1>), dim3(C / 32, Cout / 256, splits), dim3(512), 0, 0, dy, x, ws, Cout, C, C, H, W,
-                           ntiles, tps, (int)(n * 4), (int)(n * 4));
+                           ntiles, tps, (int)(n * 4), (int)(n * 4), am, am + 1);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        if (r >= 2) printf("%s %.3f ms  %.0f TF executed\n", argv[0], ms, flops / ms / 1e9);
+        if (r >= 2) printf("%s NS=%d %.3f ms  %.0f TF executed  %.0f TF fp32-equivalent\n", argv[0], JP_NS, ms, flops / ms / 1e9, flops / (JP_NS == 2 ? 3 : 6) / ms / 1e9);
     }
     checksum<<<1024, 256>>>(ws, nws, cs);
     unsigned long long h; hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost);
