@@ -251,6 +251,7 @@ class CapturedStep:
         torch.cuda.synchronize(dev)
         gc_was = gc.isenabled()
         gc.disable()                # no collector run (it may destroy HIP objects) while the stream is capturing
+        ops.amax_pool_reset()       # operand-scale slots: zeroed by fills that are part of THIS capture
         try:
             if self.world == 1:
                 with ops.rng_capture(self.base_dev) as cap, torch.cuda.graph(self.graph):
@@ -262,6 +263,7 @@ class CapturedStep:
                 with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
                     self._body_b()
         finally:
+            ops.amax_pool_reset()
             arena.dev_state = None
             if gc_was:
                 gc.enable()

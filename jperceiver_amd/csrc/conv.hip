@@ -192,14 +192,14 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                                // of co, (class, slot) q)][split][k-half][row][4 words]; value = the pre-summed slot weight W'_q[co][c]
             const int Cout = p[0], Cin = p[1], c_off = p[2], Cx = p[3];
             const long nsteps = (long)((Cout + 31) / 32 * 2) * 16;
-            const long per_tile = (nsteps + P9S_AHEAD) * 3072;
+            const long per_tile = (nsteps + P9S_AHEAD) * (JP_NS * 1024);
             const int mt = (int)(i / per_tile);
             long t = i - (long)mt * per_tile;
             const int w4 = (int)(t & 3); t >>= 2;
             const int c = mt * 128 + (int)(t & 127); t >>= 7;
             const int khalf = (int)(t & 1); t >>= 1;
-            const int sp = (int)(t % 3);
-            const long U = t / 3;
+            const int sp = (int)(t % JP_NS);
+            const long U = t / JP_NS;
             if (U >= nsteps || c >= Cx) return 0.f;
             const int stage = (int)(U >> 4), q = (int)(U & 15);
             const int co = stage * 16 + khalf * 8 + 2 * w4;
@@ -207,9 +207,9 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 v[k] = co + k < Cout ? pack_slot_sum(w + ((size_t)(co + k) * Cin + c_off + c) * 9, q) : 0.f;
-            unsigned s0, s1, s2;
-            jp_split3(v[0], v[1], s0, s1, s2);
-            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+            unsigned sq[3];
+            jp_split_ns(v[0], v[1], sc, sq);
+            return __uint_as_float(sp == 0 ? sq[0] : (sp == 1 ? sq[1] : sq[2]));
         }
         case PACK_SPLITSEG: {  // p = Cout, Cin, c_off, C, up, hdr_back: one channel segment of an iconv bank as JP_NS-way splits (the scale header
                                // of the bank sits hdr_back words in front of this segment, JP_NS == 2) in the
@@ -270,40 +270,73 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
 // Split packs of the fp16 two-way scheme (JP_NS == 2) start with a header {s, 1 / s, 0, 0}: s = the power of two that puts the weight
 // tensor's largest magnitude into [2^14, 2^15) (jp_scale_exp); the fragments hold the splits of s * w.  pack_scale_kernel writes the
 // headers (one workgroup per job) BEFORE the pack kernels of the same stream read them.
-__device__ __forceinline__ int pack_hdr(int mode) { return mode == PACK_SPLIT ? JP_PACK_HDR : 0; }
+__device__ __forceinline__ int pack_hdr(int mode) { return (mode == PACK_SPLIT || mode == PACK_SPLITUPD) ? JP_PACK_HDR : 0; }
 // the weight scale a split pack's elements are multiplied by: PACK_SPLIT's own header; PACK_SPLITSEG: the bank's header, p[5] words back
 __device__ __forceinline__ float pack_scale_of(const JpPackJob& j) {
     if (!JP_PACK_HDR) return 1.f;
-    if (j.mode == PACK_SPLIT) return j.wp[0];
+    if (j.mode == PACK_SPLIT || j.mode == PACK_SPLITUPD) return j.wp[0];
     if (j.mode == PACK_SPLITSEG) return *(j.wp - j.p[5]);
     return 1.f;
 }
-__device__ __forceinline__ void pack_scale_job(const JpPackJob& j) {
-    const bool seg = j.mode == PACK_SPLITSEG && j.p[2] == 0;          // the bank's first segment writes the bank's header
-    if (!JP_PACK_HDR || !(j.mode == PACK_SPLIT || seg)) return;
-    float* hdr = seg ? j.wp - j.p[5] : j.wp;
-    const long n = (long)j.p[0] * j.p[1] * (seg ? 9 : j.p[4]);
+// Three small launches: zero the reduction word (header word 2) -- PSL workgroups per job reduce a slice of the weight tensor each into it
+// (a maximum: order-independent) -- one thread per job turns it into {s, 1 / s}.  (One workgroup per job, as first written, took 2 ms per
+// step on the 512 x 512 x 9 tensors: profiles/r05_fp16x2_first_kernel_stats.md.)
+constexpr int PSL = 32;
+__device__ __forceinline__ float* pack_scale_hdr(const JpPackJob& j, long* n) {
+    const bool seg = j.mode == PACK_SPLITSEG && j.p[2] == 0;          // the bank's first segment owns the bank's header
+    const bool upd = j.mode == PACK_SPLITUPD;                         // (pre-summed slot weights of the whole tensor: x 4 bound, like seg)
+    if (!JP_PACK_HDR || !(j.mode == PACK_SPLIT || seg || upd)) return nullptr;
+    *n = (long)j.p[0] * j.p[1] * ((seg || upd) ? 9 : j.p[4]);
+    return seg ? j.wp - j.p[5] : j.wp;
+}
+__device__ __forceinline__ void pack_scale_zero(const JpPackJob& j) {
+    long n;
+    float* hdr = pack_scale_hdr(j, &n);
+    if (hdr && threadIdx.x == 0) reinterpret_cast<unsigned*>(hdr)[2] = 0u;
+}
+__device__ __forceinline__ void pack_scale_reduce(const JpPackJob& j, int slice) {
+    long n;
+    float* hdr = pack_scale_hdr(j, &n);
+    if (!hdr) return;
+    const long per = (n + PSL - 1) / PSL, beg = slice * per, end = min(n, beg + per);
     unsigned m = 0;
-    for (long i = threadIdx.x; i < n; i += 256) {
-        m = max(m, jp_amag(__float_as_uint(j.w[i])));    // largest ordinary magnitude (scale.hip)
-    }
+    for (long i = beg + threadIdx.x; i < end; i += 256) m = max(m, jp_amag(__float_as_uint(j.w[i])));    // largest ordinary magnitude (scale.hip)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    __shared__ unsigned sm[4];
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-        // (iconv banks: the upsampled segment's elements are sums of up to four taps -- pack_slot_sum -- and all segments share one scale)
-        const int k = jp_scale_exp(__uint_as_float(m) * (seg ? 4.f : 1.f));
-        hdr[0] = jp_exp2i(k);
-        hdr[1] = jp_exp2i(-k);
-        hdr[2] = hdr[3] = 0.f;
-    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned*>(hdr) + 2, m);
 }
-__global__ __launch_bounds__(256) void pack_scale_one_kernel(JpPackJob job) { pack_scale_job(job); }
-__global__ __launch_bounds__(256) void pack_scale_kernel(const JpPackJob* __restrict__ jobs, int njobs) {
-    if ((int)blockIdx.x < njobs) pack_scale_job(jobs[blockIdx.x]);
+__device__ __forceinline__ void pack_scale_finish(const JpPackJob& j) {
+    long n;
+    float* hdr = pack_scale_hdr(j, &n);
+    if (!hdr || threadIdx.x) return;
+    // (iconv banks: the upsampled segment's elements are sums of up to four taps -- pack_slot_sum -- and all segments share one scale)
+    const int k = jp_scale_exp(hdr[2] * (j.mode != PACK_SPLIT ? 4.f : 1.f));
+    hdr[0] = jp_exp2i(k);
+    hdr[1] = jp_exp2i(-k);
+    hdr[2] = hdr[3] = 0.f;
+}
+__global__ __launch_bounds__(64) void pack_scale_zero_one_kernel(JpPackJob job) { pack_scale_zero(job); }
+__global__ __launch_bounds__(256) void pack_scale_reduce_one_kernel(JpPackJob job) { pack_scale_reduce(job, blockIdx.x); }
+__global__ __launch_bounds__(64) void pack_scale_finish_one_kernel(JpPackJob job) { pack_scale_finish(job); }
+__global__ __launch_bounds__(64) void pack_scale_zero_kernel(const JpPackJob* __restrict__ jobs, int njobs) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q < njobs) { long n; float* hdr = pack_scale_hdr(jobs[q], &n); if (hdr) reinterpret_cast<unsigned*>(hdr)[2] = 0u; }
+}
+__global__ __launch_bounds__(256) void pack_scale_reduce_kernel(const JpPackJob* __restrict__ jobs, int njobs) {
+    pack_scale_reduce(jobs[blockIdx.y], blockIdx.x);
+}
+__global__ __launch_bounds__(64) void pack_scale_finish_kernel(const JpPackJob* __restrict__ jobs, int njobs) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q < njobs) {
+        long n;
+        float* hdr = pack_scale_hdr(jobs[q], &n);
+        if (hdr) {
+            const int k = jp_scale_exp(hdr[2] * (jobs[q].mode != PACK_SPLIT ? 4.f : 1.f));
+            hdr[0] = jp_exp2i(k);
+            hdr[1] = jp_exp2i(-k);
+            hdr[2] = hdr[3] = 0.f;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_one_kernel(JpPackJob job) {
@@ -487,8 +520,11 @@ void do_pack(int mode, const float* w, float* wp, long total, int p0, int p1, in
         if (g_pack_rec_n < g_pack_rec_cap) g_pack_rec[g_pack_rec_n] = j;
         ++g_pack_rec_n;      // counted even when the buffer is full: jp_pack_record_end reports the overflow
     }
-    if (JP_PACK_HDR && (mode == PACK_SPLIT || (mode == PACK_SPLITSEG && p2 == 0)))
-        hipLaunchKernelGGL(pack_scale_one_kernel, dim3(1), dim3(256), 0, st, j);
+    if (JP_PACK_HDR && (mode == PACK_SPLIT || mode == PACK_SPLITUPD || (mode == PACK_SPLITSEG && p2 == 0))) {
+        hipLaunchKernelGGL(pack_scale_zero_one_kernel, dim3(1), dim3(64), 0, st, j);
+        hipLaunchKernelGGL(pack_scale_reduce_one_kernel, dim3(PSL), dim3(256), 0, st, j);
+        hipLaunchKernelGGL(pack_scale_finish_one_kernel, dim3(1), dim3(64), 0, st, j);
+    }
     hipLaunchKernelGGL(pack_one_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, j);
 }
 
@@ -2150,7 +2186,7 @@ inline bool p9sd_enabled() {
     static const int on = [] { const char* e = getenv("JP_P9SD"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
-inline long p9sd_floats(int rows, int Cout) { return (long)jp_cdiv(rows, 128) * ((long)((Cout + 31) / 32 * 2) * 16 + P9S_AHEAD) * 3072; }
+inline long p9sd_floats(int rows, int Cout) { return (long)jp_cdiv(rows, 128) * ((long)((Cout + 31) / 32 * 2) * 16 + P9S_AHEAD) * (JP_NS * 1024) + JP_PACK_HDR; }
 template <class E>
 const char* p9sd_tag() { return __PRETTY_FUNCTION__; }
 // P9S2D (igemm_p9s2d.h): class-uniform split-bf16 dgrad of the 3x3 stride-2 layers; JP_P9S2=0 keeps the generic DgradS2B form
@@ -3242,10 +3278,11 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
                 // split-product patch kernel over the full-resolution dY (igemm_p9sd.h); its pack sits behind the P9 one
                 float* wsd = ws + dgrad_tap_floats(Cin, Cout, 3) + p9_alloc_floats(Cin, Cp);
                 if (!ws_state) do_pack(PACK_SPLITUPD, w, wsd, p9sd_floats(C, Cout), Cout, Cin, coff, C, 0, 0, st);
-                jp_prof_before(p9sd_tag<DgradEpi>(), 6.0 * 2.0 * C * (double)np2 * 16.0 * Cp, st);
+                const float* xam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * H * W, st) : nullptr;
+                jp_prof_before(p9sd_tag<DgradEpi>(), JP_NPROD * 2.0 * C * (double)np2 * 16.0 * Cp, st);
                 dim3 grid(N * (h2 / 4) * (w2 / 32), jp_cdiv(C, 128), 1);
                 hipLaunchKernelGGL((jp_igemm_p9sd_kernel<DgradEpi>), grid, dim3(256), 0, st, reinterpret_cast<const unsigned*>(wsd), dy, e,
-                                   C, Cout, Cp / 16, h2, w2);
+                                   C, Cout, Cp / 16, h2, w2, xam);
                 jp_prof_after(st);
             } else
             launch_auto(a, bu, e, C, (int)np2, KpU, 1, KpU, st);
@@ -3545,9 +3582,11 @@ extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const floa
                 W4SPlan q;
                 if (w4s_plan(N, Cx, h2, w2, Cout, ws_floats, &q)) {
                     // executed FLOPs: 6 bf16 MFMA products per fp32 product, 16 (class, slot) GEMMs over the half-res pixels
-                    jp_prof_before(w4s_tag<W4S_TR>(), 6.0 * 2.0 * Cout * 16.0 * Cx * (double)Ncl, st);
+                    const float* gam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * H * W, st) : nullptr;
+                    const float* xam = JP_NS == 2 ? jp_amax_of(xs[i], (long)N * Cx * h2 * w2, st) : nullptr;
+                    jp_prof_before(w4s_tag<W4S_TR>(), JP_NPROD * 2.0 * Cout * 16.0 * Cx * (double)Ncl, st);
                     hipLaunchKernelGGL((jp_wgrad_w4s_kernel<W4S_TR>), dim3(Cx / 64, jp_cdiv(Cout, 128), 2 * q.splits), dim3(512), 0,
-                                       st, dy, xs[i], ws, Cout, Cx, h2, w2, q.ntiles, q.tps, (int)((long)N * Cout * H * W * 4));
+                                       st, dy, xs[i], ws, Cout, Cx, h2, w2, q.ntiles, q.tps, (int)((long)N * Cout * H * W * 4), gam, xam);
                     jp_prof_after(st);
                     const long total = (long)Cout * Cx * 9;
                     hipLaunchKernelGGL(wgrad_fold_parity_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
@@ -3652,7 +3691,11 @@ extern "C" int jp_pack_record_end(void) {
 extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, void* stream) {
     JP_CHECK_ARG(jobs && njobs > 0 && total_elems > 0, "pack_replay: bad args");
     if (JP_PACK_HDR)    // headers (weight scales) of the fp16 split packs first: the pack kernels below read them
-        hipLaunchKernelGGL(pack_scale_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
+    {
+        hipLaunchKernelGGL(pack_scale_zero_kernel, dim3((njobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
+        hipLaunchKernelGGL(pack_scale_reduce_kernel, dim3(PSL, njobs), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
+        hipLaunchKernelGGL(pack_scale_finish_kernel, dim3((njobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
+    }
     hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 4095) / 4096, 16384)), dim3(256), 0,
                        (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
     // the split-bf16 packs of the table: LDS-staged, grid-stride over their work items (a block without an item returns)

@@ -14,14 +14,23 @@
 
 template <class Epi>
 __global__ __launch_bounds__(256, 2) void jp_igemm_p9sd_kernel(const unsigned* __restrict__ wp, const float* __restrict__ dy,
-                                                               Epi epi, int M, int Cout, int NST, int h2, int w2) {
+                                                               Epi epi, int M, int Cout, int NST, int h2, int w2,
+                                                               const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    float xsc = 1.f, osc = 1.f;
+    if constexpr (NS == 2) {    // operand scales, see jp_igemm_p9s_body (the pack's header: PACK_SPLITUPD)
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        xsc = jp_exp2i(kx);
+        osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
+        wp += JP_PACK_HDR;
+    }
     constexpr int NT = 256, WN = 2, NJ = 2, TR = WN * NJ;
     constexpr int PR = 2 * TR + 2, COLS = 66, PHALF = 34, PITS = 2 * PHALF;
     constexpr int PLS = PR * PITS;                           // 16-byte words per (split, k-half) plane
     constexpr int ITEMS = 2 * PR * COLS, NQ = (ITEMS + NT - 1) / NT;
     constexpr int STEPS = 16, BMT = 128;
-    constexpr int SBYTES = 3 * 2 * BMT * 16;
-    __shared__ jp_u32x4 patch[3 * 2 * PLS];
+    constexpr int SBYTES = NS * 2 * BMT * 16;
+    __shared__ jp_u32x4 patch[NS * 2 * PLS];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -82,13 +91,13 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9sd_kernel(const unsigned* _
             jp_u32x4 w0, w1, w2_;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                unsigned a, b, c;
-                jp_split3(rv[q][2 * k], rv[q][2 * k + 1], a, b, c);
-                w0[k] = a; w1[k] = b; w2_[k] = c;
+                unsigned sq[3];
+                jp_split_ns(rv[q][2 * k], rv[q][2 * k + 1], xsc, sq);
+                w0[k] = sq[0]; w1[k] = sq[1]; w2_[k] = sq[2];
             }
             patch[loff[q]] = w0;
             patch[2 * PLS + loff[q]] = w1;
-            patch[4 * PLS + loff[q]] = w2_;
+            if constexpr (NS == 3) patch[4 * PLS + loff[q]] = w2_;
         }
     };
 
@@ -104,31 +113,30 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9sd_kernel(const unsigned* _
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)mt * tile_bytes, 0, (int)tile_bytes, 0x00020000);
     const int avo = (lhi * BMT + wm * 64 + l31) * 16;
-    jp_u32x4 ra[2][2][3];
+    jp_u32x4 ra[2][2][NS];
     auto aload = [&](int slot, int step_bytes) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NS; ++s)
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
     };
     aload(0, 0);
     // B fragment of step q = (a, b, r, s), pixel row j of the wave: patch row 2*(wn*NJ + j) + 3 - a - 2r, position
     // (b == 0 ? PHALF : 0) + l31 + 1 - s
     const jp_u32x4* bp = patch + lhi * PLS + (2 * wn * NJ) * PITS + l31;
-    jp_u32x4 rb[2][NJ][3];
+    jp_u32x4 rb[2][NJ][NS];
     auto bload = [&](int slot, int u) {
         const int a = u >> 3, b = (u >> 2) & 1, r = (u >> 1) & 1, s = u & 1;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
+            for (int sp = 0; sp < NS; ++sp)
                 rb[slot][j][sp] = bp[sp * 2 * PLS + (2 * j + 3 - a - 2 * r) * PITS + (b == 0 ? PHALF : 0) + 1 - s];
     };
 #define JP_P9SD_MFMA(SA_, SB_)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[u & 1][i][SA_]),             \
-                                                            __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
+        acc[i][j] = jp_mfma_bf16_sw<false>(ra[u & 1][i][SA_], rb[u & 1][j][SB_], acc[i][j])
     gload(0);
     for (int stage = 0; stage < NST; ++stage) {
         lstore();
@@ -141,12 +149,7 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9sd_kernel(const unsigned* _
             aload((u + 1) & 1, ab + (u + 1) * SBYTES);      // 16 steps per stage: the ring parity is the step parity
             if (u + 1 < STEPS) bload((u + 1) & 1, u + 1);
             __builtin_amdgcn_sched_barrier(0);
-            JP_P9SD_MFMA(2, 0);
-            JP_P9SD_MFMA(1, 1);
-            JP_P9SD_MFMA(0, 2);
-            JP_P9SD_MFMA(1, 0);
-            JP_P9SD_MFMA(0, 1);
-            JP_P9SD_MFMA(0, 0);
+            JP_SPLIT_PRODUCTS(JP_P9SD_MFMA);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void jp_igemm_p9sd_kernel(const unsigned* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < M) epi.put(se, m, acc[i][j][r]);
+                if (m < M) epi.put(se, m, NS == 2 ? acc[i][j][r] * osc : acc[i][j][r]);
             }
         }
     }

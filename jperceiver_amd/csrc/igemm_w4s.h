@@ -19,13 +19,22 @@
 template <int TR>
 __global__ __launch_bounds__(512, 2) void jp_wgrad_w4s_kernel(const float* __restrict__ dy, const float* __restrict__ xh,
                                                              float* __restrict__ ws, int Cout, int Cx, int h2, int w2,
-                                                             int ntiles, int tiles_per_split, int dy_bytes) {
+                                                             int ntiles, int tiles_per_split, int dy_bytes,
+                                                             const float* __restrict__ gam, const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    float gsc = 1.f, xsc = 1.f, osc = 1.f;       // JP_NS == 2: operand scales, see jp_wgrad_w9s_kernel
+    if constexpr (NS == 2) {
+        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(gam[0])), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        gsc = jp_exp2i(kg_);
+        xsc = jp_exp2i(kx_);
+        osc = jp_exp2i(-kg_) * jp_exp2i(-kx_);
+    }
     constexpr int NT = 512, PR = TR + 2, PC = 34;
     constexpr int SLOTS = PR * PC, CBP = SLOTS * 64, SPL = 2 * CBP;
     constexpr int ITEMS = SLOTS * 16, NQ = (ITEMS + NT - 1) / NT;
     constexpr int KGR = TR * 2;
     static_assert(2 * SPL + ((TR + 1) * PC + 18) * 64 + 256 < 65536, "transpose-read immediates must fit 16 bits");
-    __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NS * SPL];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -80,14 +89,14 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w4s_kernel(const float* __res
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
             bbase[tx][rd] = cb * CBP + (ca * PC + 8 * lhi + rr) * 64 + ((Qq ^ ((tx + 4 * rd + rr) & 7)) * 8);
-    auto bread = [&](int r, int tx, int g, int s) -> jp_bf16x8 {
+    auto bread = [&](int r, int tx, int g, int s) -> jp_u32x4 {
         const int imm = s * SPL + ((g / 2 + r) * PC + 16 * (g % 2) + tx) * 64;
         const jp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx][0] + imm));
         const jp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx][1] + imm + 256));
         const jp_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(jp_bf16x8, v);
+        return __builtin_bit_cast(jp_u32x4, v);
     };
 
     // ---- staging (edge clamp): item e = t + NT*q -> (patch column, patch row, channel quad Qd)
@@ -114,13 +123,13 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w4s_kernel(const float* __res
             if (e >= ITEMS) continue;
             const int pcol = e % PC, rest = e / PC, prow = rest % PR, Qd = rest / PR;
             const int off = (Qd >> 3) * CBP + (prow * PC + pcol) * 64 + (((Qd & 7) ^ (pcol & 7)) * 8);
-            unsigned a0, a1, a2, b0, b1, b2;
-            jp_split3(rv[q][0], rv[q][1], a0, a1, a2);
-            jp_split3(rv[q][2], rv[q][3], b0, b1, b2);
+            unsigned a[3], b[3];
+            jp_split_ns(rv[q][0], rv[q][1], xsc, a);
+            jp_split_ns(rv[q][2], rv[q][3], xsc, b);
             typedef unsigned u2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u2*>(patch + off) = u2{a0, b0};
-            *reinterpret_cast<u2*>(patch + SPL + off) = u2{a1, b1};
-            *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a2, b2};
+            *reinterpret_cast<u2*>(patch + off) = u2{a[0], b[0]};
+            *reinterpret_cast<u2*>(patch + SPL + off) = u2{a[1], b[1]};
+            if constexpr (NS == 3) *reinterpret_cast<u2*>(patch + 2 * SPL + off) = u2{a[2], b[2]};
         }
     };
 
@@ -151,38 +160,32 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w4s_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const jp_u32x4 v = araw[g & 1][k];           // full-res columns 4k .. 4k+3: classes b = 0, 1, 0, 1
-                    unsigned s0, s1, s2;
-                    jp_split3(__uint_as_float(v[0]), __uint_as_float(v[2]), s0, s1, s2);
-                    sa[0][0][k] = s0; sa[0][1][k] = s1; sa[0][2][k] = s2;
-                    jp_split3(__uint_as_float(v[1]), __uint_as_float(v[3]), s0, s1, s2);
-                    sa[1][0][k] = s0; sa[1][1][k] = s1; sa[1][2][k] = s2;
+                    unsigned sq[3];
+                    jp_split_ns(__uint_as_float(v[0]), __uint_as_float(v[2]), gsc, sq);
+                    sa[0][0][k] = sq[0]; sa[0][1][k] = sq[1]; sa[0][2][k] = sq[2];
+                    jp_split_ns(__uint_as_float(v[1]), __uint_as_float(v[3]), gsc, sq);
+                    sa[1][0][k] = sq[0]; sa[1][1][k] = sq[1]; sa[1][2][k] = sq[2];
                 }
                 // the 6 distinct B fragments (r, tx = b + s), read one ahead of their MFMAs
-                jp_bf16x8 bq[2][3];
+                jp_u32x4 bq[2][3];
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_) bq[0][s_] = bread(0, 0, g, s_);
+                for (int s_ = 0; s_ < NS; ++s_) bq[0][s_] = bread(0, 0, g, s_);
 #pragma unroll
                 for (int f = 0; f < 6; ++f) {
                     const int r = f / 3, tx = f % 3;
                     if (f + 1 < 6) {
 #pragma unroll
-                        for (int s_ = 0; s_ < 3; ++s_) bq[(f + 1) & 1][s_] = bread((f + 1) / 3, (f + 1) % 3, g, s_);
+                        for (int s_ = 0; s_ < NS; ++s_) bq[(f + 1) & 1][s_] = bread((f + 1) / 3, (f + 1) % 3, g, s_);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const jp_bf16x8 b0 = bq[f & 1][0], b1 = bq[f & 1][1], b2 = bq[f & 1][2];
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const int s = tx - b;
                         if (s < 0 || s > 1) continue;
-                        const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[b][0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[b][1]),
-                                        a2 = __builtin_bit_cast(jp_bf16x8, sa[b][2]);
                         jp_f32x16& c = acc[b][r][s];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+#define JP_W4S_MFMA(SA_, SB_) c = jp_mfma_bf16_sw<false>(sa[b][SA_], bq[f & 1][SB_], c)
+                        JP_SPLIT_PRODUCTS(JP_W4S_MFMA);
+#undef JP_W4S_MFMA
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w4s_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < Cout) wz[(long)m * Np + n] = acc[b][r_][s][r];
+            if (m < Cout) wz[(long)m * Np + n] = NS == 2 ? acc[b][r_][s][r] * osc : acc[b][r_][s][r];
         }
     }
 }

@@ -108,6 +108,14 @@ extern "C" int jp_amax(const float* x, long n, float* out, void* stream) {
     if (rc != JP_OK) return rc;
     JP_LAUNCH_CHECK();
 }
+// as jp_amax, but *out is not zeroed first: it must hold 0 (or an earlier maximum to extend) -- callers that hand out slots of a
+// buffer they zero once save a memset per reduction
+extern "C" int jp_amax_into(const float* x, long n, float* out, void* stream) {
+    JP_CHECK_ARG(out && (x || n == 0) && n >= 0, "amax_into: bad arguments");
+    const int rc = launch_amax(x, n, out, static_cast<hipStream_t>(stream), false);
+    if (rc != JP_OK) return rc;
+    JP_LAUNCH_CHECK();
+}
 extern "C" int jp_amax_hint(const float* tensor, const float* amax) {
     JP_CHECK_ARG(tensor && amax, "amax_hint: null pointer");
     JP_CHECK_ARG(g_nh < MAXH, "amax_hint: more than 8 hints pending (jp_amax_hint_clear after the call they are for)");

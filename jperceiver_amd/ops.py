@@ -332,9 +332,31 @@ def _amax_of(v) -> torch.Tensor | None:
         if v.amax is None:
             v.amax = _amax_of(v.t)
         return v.amax
-    out = torch.empty(1, device=v.device, dtype=torch.float32)
-    call("jp_amax", v, v.numel(), out)
+    out = _amax_slot(v.device)
+    call("jp_amax_into", v, v.numel(), out)
     return out
+
+
+_AMAX_POOL = {}
+
+
+def amax_pool_reset():
+    """Forget the zeroed slot pools (before and after a graph capture: a pool zeroed inside one capture must not serve another)."""
+    _AMAX_POOL.clear()
+
+
+def _amax_slot(dev) -> torch.Tensor:
+    """One zeroed float of a pool that is zeroed 4096 slots at a time (one fill instead of a memset per reduction).  A pool belongs to
+    the stream it was zeroed on -- and to the graph capture it was zeroed in: a captured step replays the fill with the reductions."""
+    st = torch.cuda.current_stream(dev)
+    key = (dev.index, st.cuda_stream, torch.cuda.is_current_stream_capturing())
+    ent = _AMAX_POOL.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        if len(_AMAX_POOL) > 64:
+            _AMAX_POOL.clear()
+        ent = _AMAX_POOL[key] = [torch.zeros(4096, device=dev, dtype=torch.float32), 0]
+    ent[1] += 1
+    return ent[0][ent[1] - 1:ent[1]]
 
 
 class _amax_hints:
