@@ -17,7 +17,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
                  events inside the library, on the stream it is launched on (jp_profile_*); dominant = the kernel
                  instantiation with the largest summed duration.
                  A kernel is priced on the pipe it runs on: EXECUTED MFMA FLOPs / time against 2.5 PFLOP/s (dense bf16) for the
-                 split-product patch kernels (P9S / W9S / P9US: 6 bf16 products per fp32 product), against 157.3 TFLOP/s for
+                 split-product patch kernels (P9S / W9S / P9US ...: 3 fp16 products per fp32 product since round 5, 6 bf16 products in a
+                 -DJP_NS=3 build; the dense 16-bit MFMA peak is the same for both), against 157.3 TFLOP/s for
                  the exact-fp32 MFMA kernels.  Step-level figures ride along: step_fp32_equiv_tflops = 1.63 TFLOP*B / t_step,
                  achieved_hbm = (9.7 GB*B + 2.3 GB) / t_step, and per-pipe aggregates of all igemm kernels.
   families     — per-kernel-family time / rate table of that step (also written to $JP_BENCH_TABLE or
@@ -41,6 +42,34 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+ARITHMETIC = {
+    2: "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 3 fp16-MFMA products a0 b0 + a0 b1 + a1 b0 of "
+       "two-way fp16 splits of both operands, each operand tensor scaled by the power of two that puts its largest magnitude into [2^14, 2^15) "
+       "(igemm_p9s.h:jp_split2h, scale.hip): operands carried to 2^-23 relative for elements within 2^-17 of their tensor's largest, 2^-40 of "
+       "that largest below; the term left out is <= 2^-22 |a b|.  Measured error vs float64: 1.0-1.3 x the exact-fp32 MFMA kernels' on layer "
+       "data (tests/test_split_accuracy_gpu.py, tools/split_study.py: the split error is 3-4 x below the fp32 accumulation's own rounding). "
+       "Inf / NaN / |x| >= 2^100 inputs: NaN in the outputs that read them.  A -DJP_NS=3 build keeps the exact 3-way bf16 splits (6 products); "
+       "JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
+    3: "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 6 bf16-MFMA "
+       "products of exact 3-way bf16 operand splits (igemm_p9s.h): error vs float64 <= the fp32 FMA chain's "
+       "(tests/test_split_accuracy_gpu.py) on FINITE inputs (an Inf input yields NaN where fp32 arithmetic yields Inf: "
+       "Inf - bf16(Inf), and Inf x a zero residual split); JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
+}
+
+
+def _scheme():
+    """2: the library forms fp32 products from two fp16 splits per operand (3 matrix products), 3: three bf16 splits (6 products)."""
+    from jperceiver_amd import ops
+    return ops.split_scheme()
+
+
+SIX_TAGS = ("p7s_tag", "w9s2_tag", "p1l_tag")       # split kernels that still run the six-product bf16 scheme
+
+
+def _products(tag):
+    return 6.0 if (_scheme() == 3 or any(k in tag for k in SIX_TAGS)) else 3.0
+
 
 PEAK_FP32_TF, PEAK_BF16_TF, PEAK_HBM_TBS = 157.3, 2500.0, 8.0     # dense fp32-MFMA / dense bf16-MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
 SPLIT_TAGS = ("p1l_tag", "p9sm_tag", "p9sw_tag", "p9s_tag", "w9s_tag", "p9us2_tag", "w1s_tag", "p9sd_tag", "w4s_tag", "p9s2d_tag", "p9s2f_tag", "w9s2_tag", "p9sx2_tag", "p7s_tag")     # kernels on the bf16 pipe: 6 bf16 MFMA products per fp32 product (igemm_p9s.h)
@@ -303,10 +332,7 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 6 bf16-MFMA "
-                          "products of exact 3-way bf16 operand splits (igemm_p9s.h): error vs float64 <= the fp32 FMA chain's "
-                          "(tests/test_split_accuracy_gpu.py) on FINITE inputs (an Inf input yields NaN where fp32 arithmetic yields Inf: "
-                          "Inf - bf16(Inf), and Inf x a zero residual split); JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
+            "arithmetic": ARITHMETIC[_scheme()],
             "workload_note": "random-init network: its disparity is pixel noise, so the CGT warp kernels' gathers are L2-miss-bound here "
                              "(cgt_warp_bwd: 6.3 x its algorithmic bytes, 2.3 x / 1.3 x slower than on a smooth disparity, DESIGN 4.5); "
                              "the photometric family is overstated by ~1 ms per step against a trained network",
@@ -547,7 +573,7 @@ def measure_roofline(runner, batch, B, t_step, rank):
         tag = buf.value.decode()
         split = any(k in tag for k in SPLIT_TAGS)
         # [tag, executed MFMA FLOPs, ms, algorithmic FLOPs, algorithmic bytes, fp32-equivalent executed FLOPs]
-        recs.append([tag, fl.value, msv.value, 0.0, 0.0, fl.value / 6.0 if split else fl.value])
+        recs.append([tag, fl.value, msv.value, 0.0, 0.0, fl.value / _products(tag) if split else fl.value])
     fam = collections.OrderedDict()
     by_name = {}
     conv_alg = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
@@ -627,15 +653,20 @@ def measure_roofline(runner, batch, B, t_step, rank):
     hbm_ms = sum(v["ms"] for k, v in fam.items() if not k.startswith("conv "))
     # the step against the bound that binds it now: every fp32 convolution FLOP of the step (1.63 TFLOP per
     # image-step) costs 6 bf16-MFMA FLOPs when formed from exact operand splits, priced at the 2.5 PF dense bf16 peak
-    step_bound = 1.63e12 * B * 6 / t_step / (PEAK_BF16_TF * 1e12)
+    NP = 3 if _scheme() == 2 else 6
+    step_bound = 1.63e12 * B * NP / t_step / (PEAK_BF16_TF * 1e12)
     # key order: the driver's parser keeps a bounded set of scalars -- the step-level figures come right after `frac`
     roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic,
-            "step_bf16_bound_frac": round(step_bound, 4),
+            "step_bf16_bound_frac": round(step_bound, 4), "products_per_fp32_product": NP,
+            # rounds 3-5a priced the step against SIX products per fp32 product (31.3 ms at B = 8): the same step on that scale
+            "step_six_product_bound_frac": round(1.63e12 * B * 6 / t_step / (PEAK_BF16_TF * 1e12), 4),
             "bf16_pipe_frac": round(bf16_frac, 4), "fp32_pipe_frac": round(f32_frac, 4),
             "fp32_pipe_ms": round(ms_f32, 2), "bf16_pipe_ms": round(ms_split, 2), "hbm_kernels_ms": round(hbm_ms, 2),
             "kernel": name + " — by-time dominant igemm instantiation of the step",
-            "pipe": ("bf16 MFMA, fp32 products as 6 bf16 products of 3-way operand splits (fp32 in/out/accumulate)" if dom_split
+            "pipe": (("fp16 MFMA (dense 16-bit peak 2.5 PF), fp32 products as 3 fp16 products of 2-way splits of power-of-two-scaled operands "
+                      "(fp32 in/out/accumulate)" if _products(dom_tag) == 3.0 else
+                      "bf16 MFMA, fp32 products as 6 bf16 products of 3-way operand splits (fp32 in/out/accumulate)") if dom_split
                      else "fp32 MFMA (exact)"),
             "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
             "total_ms_per_step": round(dom["ms"], 3),

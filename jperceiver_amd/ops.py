@@ -334,7 +334,26 @@ def _amax_of(v) -> torch.Tensor | None:
         return v.amax
     out = _amax_slot(v.device)
     call("jp_amax_into", v, v.numel(), out)
+    if _AMAX_LOG is not None:
+        import traceback
+        fr = [f for f in traceback.extract_stack(limit=12) if "ops.py" not in f.filename]
+        key = (tuple(v.shape), fr[-1].name + ":" + str(fr[-1].lineno) if fr else "?")
+        _AMAX_LOG[key] = _AMAX_LOG.get(key, 0) + 1
     return out
+
+
+import os as _os
+_AMAX_LOG = {} if _os.environ.get("JP_AMAX_LOG") else None
+if _AMAX_LOG is not None:
+    import atexit
+
+    def _dump():
+        rows = sorted(_AMAX_LOG.items(), key=lambda kv: -kv[1] * int(np.prod(kv[0][0])))
+        tot = sum(c * int(np.prod(k[0])) * 4 for k, c in rows)
+        print(f"[amax log] {sum(c for _, c in rows)} reductions, {tot / 1e9:.2f} GB")
+        for (shape, where), c in rows[:40]:
+            print(f"[amax log] {c:4d} x {str(shape):28s} {c * int(np.prod(shape)) * 4 / 1e6:9.1f} MB  {where}")
+    atexit.register(_dump)
 
 
 _AMAX_POOL = {}
