@@ -79,7 +79,9 @@ __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return
 __device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return fmaf(-mean, sc, beta); }
 
 __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* __restrict__ residual,
-                                              float* __restrict__ y, float sc, float sh, size_t base, int HW, int relu) {
+                                              float* __restrict__ y, float sc, float sh, size_t base, int HW, int relu,
+                                              unsigned* __restrict__ amax = nullptr) {
+    float mx = 0.f;                      // largest |y| this thread wrote (jp_amax_out)
     if ((HW & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x + base);
         const float4* r4 = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
@@ -90,6 +92,7 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
             if (r4) { const float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             y4[i] = v;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
     } else {
         for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
@@ -97,8 +100,10 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
             if (residual) v += residual[base + i];
             if (relu) v = fmaxf(v, 0.f);
             y[base + i] = v;
+            mx = fmaxf(mx, fabsf(v));
         }
     }
+    jp_block_amax_commit(mx, amax);
 }
 
 // y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ), statistics from the stats kernel's partial sums
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ residual, float* __restrict__ y,
                                                        int C, int HW, int relu, double count, float momentum, float eps,
-                                                       int n_updates, int S) {
+                                                       int n_updates, int S, unsigned* __restrict__ amax) {
     __shared__ double tot[2];
     const int nc = blockIdx.y;  // n*C + c
     const int c = nc % C;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
     }
     const float sc = invstd * gamma[c];
     const float sh = bn_shift(beta[c], mean, sc);
-    bn_apply_body(x, residual, y, sc, sh, (size_t)nc * HW, HW, relu);
+    bn_apply_body(x, residual, y, sc, sh, (size_t)nc * HW, HW, relu, amax);
 }
 
 // eval mode: y = relu?( (x-running_mean)/sqrt(running_var+eps)*gamma + beta (+ residual) )
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            const double* __restrict__ sums, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C, int HW, double count,
-                                                           int relu, int acc_param_grads, int S) {
+                                                           int relu, int acc_param_grads, int S, unsigned* __restrict__ amax) {
+    float mx = 0.f;                      // largest |dx| this thread wrote (jp_amax_out)
     const int nc = blockIdx.y;
     const int c = nc % C;
     const float mu = mean[c], is = invstd[c], g = gamma[c];
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             JP_BN_APP1(d.x, a.x, yy.x, o.x, r.x) JP_BN_APP1(d.y, a.y, yy.y, o.y, r.y)
             JP_BN_APP1(d.z, a.z, yy.z, o.z, r.z) JP_BN_APP1(d.w, a.w, yy.w, o.w, r.w)
             o4[i] = o;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             if (r4) r4[i] = r;
         }
     } else {
@@ -266,9 +273,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             float o, r;
             JP_BN_APP1(dy[base + i], x[base + i], y[base + i], o, r)
             dx[base + i] = o;
+            mx = fmaxf(mx, fabsf(o));
             if (dres) dres[base + i] = r;
         }
     }
+    jp_block_amax_commit(mx, amax);
 #undef JP_BN_APP1
 }
 
@@ -532,7 +541,8 @@ extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* 
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
     const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, ws, save_mean, save_invstd, running_mean,
-                       running_var, gamma, beta, residual, y, C, HW, relu, (double)N * HW, momentum, eps, n_updates, N * CH);
+                       running_var, gamma, beta, residual, y, C, HW, relu, (double)N * HW, momentum, eps, n_updates, N * CH,
+                       jp_take_amax_out());
     JP_LAUNCH_CHECK();
 }
 
@@ -549,7 +559,7 @@ extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, 
                        beta, ws, C, HW, CH, chunk, relu);
     const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, gamma,
-                       beta, ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH);
+                       beta, ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH, jp_take_amax_out());
     JP_LAUNCH_CHECK();
 }
 

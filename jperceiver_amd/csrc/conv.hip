@@ -617,6 +617,7 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     float* y;
     const float* bias;
     int Cout, OHW, act;
+    unsigned* amax = nullptr;           // != nullptr: the patch kernels report max |y| here (jp_amax_out)
     __device__ __forceinline__ St col(int p) const {
         int img = p / OHW;
         return (size_t)img * Cout * OHW + (p - img * OHW);
@@ -624,6 +625,18 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     __device__ __forceinline__ void put(St base, int m, float v) const {
         if (bias) v += bias[m];
         y[base + (size_t)m * OHW] = jp_act(v, act);
+    }
+    __device__ __forceinline__ float put_get(St base, int m, float v) const {       // put, returning the stored value
+        if (bias) v += bias[m];
+        const float r = jp_act(v, act);
+        y[base + (size_t)m * OHW] = r;
+        return r;
+    }
+    __device__ __forceinline__ float put4_get(St base, int m, float4 v) const {     // put4, returning the largest stored magnitude
+        const float b = bias ? bias[m] : 0.f;
+        const float4 r = make_float4(jp_act(v.x + b, act), jp_act(v.y + b, act), jp_act(v.z + b, act), jp_act(v.w + b, act));
+        *reinterpret_cast<float4*>(y + base + (size_t)m * OHW) = r;
+        return fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
     // four consecutive pixels of channel m (16-byte aligned: the patch kernels' tiles start at multiples of 32 pixels)
     __device__ __forceinline__ void put4(St base, int m, float4 v) const {
@@ -2297,6 +2310,7 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * H * W, st) : nullptr;
+    if constexpr (JP_NS == 2 && jp_has_amax<E>::value) e.amax = jp_take_amax_out();       // (every kernel below reports it)
     if constexpr (TAPS == 1) {
         const long ntiles = (long)N * (H / 4) * (W / 32), xb = (long)N * red * H * W * 4;
         if (bmt == 256 && mt_off == 0 && p1l_enabled() && rows % 256 == 0 && red % 128 == 0 && H % 4 == 0 && W % 32 == 0 && xb < (1L << 31) &&
@@ -2792,6 +2806,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             // profiles/r04_p9us_*.log, r05_p9us2_*.log.)
             const float* xam = JP_NS == 2 ? jp_amax_of3(x0, (long)N * c0 * H * W, x1, (long)N * c1 * (H / 2) * (W / 2), x2,
                                                         c2 ? (long)N * c2 * H * W : 0L, st) : nullptr;
+            e.amax = jp_take_amax_out();
             jp_prof_before(p9us2_tag<FwdEpi>(), JP_NPROD * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
             hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
                                reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W, xam);

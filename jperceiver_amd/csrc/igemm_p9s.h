@@ -78,10 +78,6 @@ __device__ __forceinline__ int jp_scale_exp(float amax) {
     const int k = 14 - ((int)(u >> 23) - 127);
     return u == 0 ? 0 : min(126, k);
 }
-__host__ __device__ __forceinline__ unsigned jp_amag(unsigned bits) {
-    const unsigned u = bits & 0x7fffffffu;
-    return u >= (227u << 23) ? 0u : u;          // |x| >= 2^100, Inf, NaN: not part of the scale
-}
 __device__ __forceinline__ float jp_exp2i(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 // products of a K step, smallest terms first: M_(split of A, split of B)
 #if JP_NS == 2
@@ -121,6 +117,12 @@ template <class E, class = void>
 struct jp_has_put4 : std::false_type {};
 template <class E>
 struct jp_has_put4<E, std::void_t<decltype(&E::put4)>> : std::true_type {};
+// Epilogues with an `amax` member (FwdEpi) can report the largest magnitude of what they store (put_get / put4_get return it):
+// the next convolution's operand scale without another pass over the tensor (jp_amax_out, scale.hip).
+template <class E, class = void>
+struct jp_has_amax : std::false_type {};
+template <class E>
+struct jp_has_amax<E, std::void_t<decltype(&E::put_get)>> : std::true_type {};
 template <bool SWAP>
 __device__ __forceinline__ jp_f32x16 jp_mfma_bf16_sw(jp_u32x4 a, jp_u32x4 b, jp_f32x16 c) {
 #if JP_NS == 2
@@ -160,7 +162,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     // JP_NS == 2: operand scales.  Input: from its largest magnitude *xam (jp_amax_of, scale.hip); weights: the pack's header
     float xsc = 1.f, osc = 1.f;
     if constexpr (NS == 2) {
-        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
         xsc = jp_exp2i(kx);
         osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
         wp += JP_PACK_HDR;
@@ -437,6 +439,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= osc;
     }
+    float omx = 0.f;                     // largest |stored value| of this lane (epilogues that report it)
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if constexpr (VEC) {
         // transposed tile: col = output channel, row = pixel -> register quad k holds pixels 8k + 4*lhi + {0..3} of the row
@@ -450,8 +453,11 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 const int m = m0 + wm * 64 + i * 32 + l31;
                 if (m >= M) continue;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    epi.put4(se + 8 * k, m, make_float4(acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]));
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v4 = make_float4(acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]);
+                    if constexpr (jp_has_amax<Epi>::value) omx = fmaxf(omx, epi.put4_get(se + 8 * k, m, v4));
+                    else epi.put4(se + 8 * k, m, v4);
+                }
             }
         }
     } else {
@@ -465,11 +471,13 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < M) epi.put(se, m, acc[i][j][r]);
+                if constexpr (jp_has_amax<Epi>::value) { if (m < M) omx = fmaxf(omx, fabsf(epi.put_get(se, m, acc[i][j][r]))); }
+                else { if (m < M) epi.put(se, m, acc[i][j][r]); }
             }
         }
     }
     }
+    if constexpr (jp_has_amax<Epi>::value) jp_wave_amax_commit(omx, epi.amax);
 #ifdef P9S_TRACE
     JP_TR(35);
     if (TAPS == 1 && tr_on)

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void jp_igemm_p9s2d_kernel(const u
     constexpr int NS = JP_NS;
     float xsc = 1.f, osc = 1.f;
     if constexpr (NS == 2) {    // operand scales, see jp_igemm_p9s_body
-        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
         xsc = jp_exp2i(kx);
         osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
         wp += JP_PACK_HDR;

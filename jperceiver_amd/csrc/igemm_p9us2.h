@@ -46,7 +46,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
     // magnitude over all of them (*xam, jp_amax_of3), the weights' from the pack header of the first segment (all segments carry the same)
     float xsc = 1.f, osc = 1.f;
     if constexpr (NS == 2) {
-        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
         xsc = jp_exp2i(kx);
         osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
         wp += JP_PACK_HDR;
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int m0 = mt * 128;
+    float omx = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int p = img * (int)HW + (y0 + py + 2 * j) * W + x0c + 2 * l31 + px;
@@ -400,10 +401,13 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < M) epi.put(se, m, NS == 2 ? acc[i][j][r] * osc : acc[i][j][r]);
+                const float v = NS == 2 ? acc[i][j][r] * osc : acc[i][j][r];
+                if constexpr (jp_has_amax<Epi>::value) { if (m < M) omx = fmaxf(omx, fabsf(epi.put_get(se, m, v))); }
+                else { if (m < M) epi.put(se, m, v); }
             }
         }
     }
+    if constexpr (jp_has_amax<Epi>::value) jp_wave_amax_commit(omx, epi.amax);
 #ifdef P9S_TRACE
     if (tr_on && (wave & 3) < 2)
         for (int i = 0; i < 16; ++i) jp_p9s_trace[((wave >> 2) * 2 + (wave & 3)) * 16 + i] = trc_[i];

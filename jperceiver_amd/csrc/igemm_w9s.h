@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
     // JP_NS == 2: power-of-two scales of dY and X from their largest magnitudes (scale.hip); the sums are scaled back on the way out
     float gsc = 1.f, xsc = 1.f, osc = 1.f;
     if constexpr (NS == 2) {
-        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(gam[0])), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(gam))), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
         gsc = jp_exp2i(kg_);
         xsc = jp_exp2i(kx_);
         osc = jp_exp2i(-kg_) * jp_exp2i(-kx_);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w1s_kernel(const float* __res
     constexpr int NS = JP_NS;
     float gsc = 1.f, xsc = 1.f, osc = 1.f;       // JP_NS == 2: operand scales, see jp_wgrad_w9s_kernel
     if constexpr (NS == 2) {
-        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(gam[0])), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(xam[0]));
+        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(gam))), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
         gsc = jp_exp2i(kg_);
         xsc = jp_exp2i(kx_);
         osc = jp_exp2i(-kg_) * jp_exp2i(-kx_);

@@ -80,6 +80,55 @@ __device__ __forceinline__ double jp_block_sum_d(double v, double* sm /*>=4*/) {
     return r;
 }
 
+// ---- operand scales of the fp16 split kernels (scale.hip): "largest ordinary magnitude" of a tensor as the bit pattern of a float.
+// Inf / NaN and finite magnitudes of 2^100 and more do not take part (they overflow fp16 under the scale of the rest: NaN outputs).
+__host__ __device__ __forceinline__ unsigned jp_amag(unsigned bits) {
+    const unsigned u = bits & 0x7fffffffu;
+    return u >= (227u << 23) ? 0u : u;
+}
+// A magnitude SLOT is JP_AMAX_WAYS words, JP_AMAX_STRIDE words (one 64-byte line) apart: producers spread their atomicMax over the ways
+// (a million same-address device-scope atomics cost 11 ns each -- measured: they made bn_apply 18 x slower; a "skip if the slot already
+// holds as much" check needs a device-scope load per workgroup, which doubled the kernel's time), consumers take the maximum of the ways.
+constexpr int JP_AMAX_WAYS = 32, JP_AMAX_STRIDE = 16, JP_AMAX_SLOT = JP_AMAX_WAYS * JP_AMAX_STRIDE;     // 512 floats = 2 KB
+__device__ __forceinline__ unsigned jp_amax_way() {
+    return ((blockIdx.x + 5u * blockIdx.y + 11u * blockIdx.z + (threadIdx.x >> 6)) & (JP_AMAX_WAYS - 1)) * JP_AMAX_STRIDE;
+}
+// consumer side: the slot's value (uniform over the wave)
+__device__ __forceinline__ float jp_slot_amax(const float* __restrict__ slot) {
+    const int lane = threadIdx.x & 63;
+    unsigned m = lane < JP_AMAX_WAYS ? __float_as_uint(slot[lane * JP_AMAX_STRIDE]) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    return __uint_as_float(m);
+}
+// producer side: every wave folds its lanes' running maximum `mx` (of |stored value|) and commits it with one non-returning atomicMax
+// (nothing waits for it).  `out` == nullptr: nothing asked for it.
+__device__ __forceinline__ void jp_wave_amax_commit(float mx, unsigned* out) {
+    if (!out) return;
+    unsigned m = jp_amag(__float_as_uint(mx));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + jp_amax_way(), m);
+}
+// the same for a whole workgroup of <= 16 waves (one atomic per workgroup; every thread of the workgroup must call it)
+__device__ __forceinline__ void jp_block_amax_commit(float mx, unsigned* out) {
+    if (!out) return;                                   // (uniform: a kernel argument)
+    __shared__ unsigned jp_bam_[16];
+    unsigned m = jp_amag(__float_as_uint(mx));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) jp_bam_[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; ++i) m = max(m, jp_bam_[i]);
+        if (m) atomicMax(out + jp_amax_way(), m);
+    }
+}
+// The caller's request "write the largest magnitude of the tensor the NEXT supporting entry point produces to this slot"
+// (jp_amax_out, scale.hip): an entry point that fuses the reduction into its kernel takes it (-> nullptr if none is pending).
+unsigned* jp_take_amax_out();
+
 // reflect index for ReflectionPad (pad < n): -1 -> 1, n -> n-2
 __device__ __forceinline__ int jp_reflect(int i, int n) {
     if (i < 0) i = -i;

@@ -654,28 +654,37 @@ __device__ __forceinline__ float act_bwd1(float d, float v, int act) {
     return d;
 }
 __global__ __launch_bounds__(TPB) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                      float* __restrict__ dx, long n, int act) {
+                                                      float* __restrict__ dx, long n, int act, unsigned* __restrict__ amax) {
+    float mx = 0.f;                      // largest |dx| this thread wrote (jp_amax_out)
     ew_loop(n, al16(dy, y, dx),
             [&](long i) {
                 const float4 d = JP_F4(dy)[i], v = JP_F4(y)[i];
-                JP_F4W(dx)[i] = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act),
-                                            act_bwd1(d.w, v.w, act));
+                const float4 o = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act),
+                                             act_bwd1(d.w, v.w, act));
+                JP_F4W(dx)[i] = o;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             },
-            [&](long i) { dx[i] = act_bwd1(dy[i], y[i], act); });
+            [&](long i) {
+                const float o = act_bwd1(dy[i], y[i], act);
+                dx[i] = o;
+                mx = fmaxf(mx, fabsf(o));
+            });
+    jp_block_amax_commit(mx, amax);
 }
 
 // activation backward + bias gradient in ONE pass over (N, C, HW): dx = dy * act'(y), dbias[c] += sum dx.  Replaces act_bwd followed
 // by channel_sum (a second read of dx) for the convolutions that carry both a bias and an activation (Conv3x3 blocks, layers.py:147-167).
 // grid (C, N * CH): block = one chunk of one (n, c) plane; fp32 short runs -> double, one float atomic per block (as channel_sum).
 __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
-                                                           float* __restrict__ dbias, int C, int HW, int CH, int chunk, int act) {
+                                                           float* __restrict__ dbias, int C, int HW, int CH, int chunk, int act,
+                                                           unsigned* __restrict__ amax) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
     const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
     const int beg = ck * chunk, end = min(HW, beg + chunk);
     const size_t base = ((size_t)n * C + c) * HW;
     double s = 0.0;
-    float fs = 0.f;
+    float fs = 0.f, mx = 0.f;
     int run = 0;
     if (((HW | chunk) & 3) == 0) {
         const float4* d4 = reinterpret_cast<const float4*>(dy + base);
@@ -685,6 +694,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restri
             const float4 d = d4[i], v = y4[i];
             const float4 o = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act), act_bwd1(d.w, v.w, act));
             o4[i] = o;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             fs += (o.x + o.y) + (o.z + o.w);
             if (++run == 8) { s += fs; fs = 0.f; run = 0; }
         }
@@ -692,10 +702,12 @@ __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restri
         for (int i = beg + threadIdx.x; i < end; i += TPB) {
             const float o = act_bwd1(dy[base + i], y[base + i], act);
             dx[base + i] = o;
+            mx = fmaxf(mx, fabsf(o));
             fs += o;
             if (++run == 32) { s += fs; fs = 0.f; run = 0; }
         }
     }
+    jp_block_amax_commit(mx, amax);
     s += fs;
     s = jp_block_sum_d(s, sm);
     if (threadIdx.x == 0) atomicAdd(&dbias[c], (float)s);
@@ -1170,7 +1182,7 @@ extern "C" int jp_act_fwd(const float* x, float* y, long n, int act, void* strea
 extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, int act, void* stream) {
     JP_CHECK_ARG(dy && y && dx && n > 0, "act_bwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, dy, y, dx, n, act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, dy, y, dx, n, act, jp_take_amax_out());
     JP_LAUNCH_CHECK();
 }
 
@@ -1185,7 +1197,7 @@ extern "C" int jp_act_bwd_bias(const float* dy, const float* y, float* dx, float
     chunk = (chunk + 3) & ~3;                       // chunks start on 16-byte boundaries when HW allows vector accesses
     const int CH = (HW + chunk - 1) / chunk;
     JP_CHECK_ARG((long)N * CH <= 65535, "act_bwd_bias: too many chunks");
-    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, y, dx, dbias, C, HW, CH, chunk, act);
+    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, y, dx, dbias, C, HW, CH, chunk, act, jp_take_amax_out());
     JP_LAUNCH_CHECK();
 }
 

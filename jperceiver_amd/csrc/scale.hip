@@ -31,13 +31,13 @@ __global__ __launch_bounds__(TPB) void amax_kernel(const float* __restrict__ x, 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < TPB / 64; ++i) m = max(m, sm[i]);
-        if (m) atomicMax(out, m);         // a maximum: the result does not depend on the order the blocks arrive in
+        if (m) atomicMax(out + jp_amax_way(), m);       // a maximum: the result does not depend on the order the blocks arrive in
     }
 }
 
 int launch_amax(const float* x, long n, float* out, hipStream_t st, bool zero) {
     if (zero) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+        hipError_t e = hipMemsetAsync(out, 0, JP_AMAX_SLOT * sizeof(float), st);
         if (e != hipSuccess) { jp_set_last_error(hipGetErrorString(e)); return (int)e; }
     }
     if (n > 0) {
@@ -50,7 +50,7 @@ int launch_amax(const float* x, long n, float* out, hipStream_t st, bool zero) {
 // slots of library-launched reductions: a ring per device, one slot per call.  A slot is reused RING calls later -- several training
 // steps of launches; the host cannot run that far ahead of the device (the step reads its loss back), and a captured graph owns the
 // slots it was captured with for as long as launches outside it number fewer than RING between two replays of the same node.
-constexpr int RING = 1 << 15, MAXDEV = 16;
+constexpr int RING = 1 << 12, MAXDEV = 16;      // slots of JP_AMAX_SLOT floats (8 MB per device)
 float* g_ring[MAXDEV] = {};
 std::atomic<unsigned> g_next{0};
 float* next_slot() {
@@ -58,12 +58,14 @@ float* next_slot() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
     if (!g_ring[dev]) {
         float* p = nullptr;
-        if (hipMalloc(&p, RING * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMalloc(&p, (size_t)RING * JP_AMAX_SLOT * sizeof(float)) != hipSuccess) return nullptr;
         g_ring[dev] = p;
     }
-    return g_ring[dev] + (g_next.fetch_add(1) % RING);
+    return g_ring[dev] + (size_t)(g_next.fetch_add(1) % RING) * JP_AMAX_SLOT;
 }
 
+thread_local unsigned* g_amax_out = nullptr;       // jp_amax_out: pending request; taken by the next supporting entry point
+thread_local int g_amax_out_done = 0;
 struct Hint { const float* t; const float* a; };
 constexpr int MAXH = 8;
 thread_local Hint g_hint[MAXH];
@@ -74,6 +76,12 @@ const float* find_hint(const float* x) {
     return nullptr;
 }
 }  // namespace
+
+unsigned* jp_take_amax_out() {
+    unsigned* p = g_amax_out;
+    if (p) { g_amax_out = nullptr; g_amax_out_done = 1; }
+    return p;
+}
 
 const float* jp_amax_of(const float* x, long n, hipStream_t st) {
     if (const float* h = find_hint(x)) return h;
@@ -102,6 +110,7 @@ const float* jp_amax_of3(const float* x0, long n0, const float* x1, long n1, con
 }
 
 // ---- C ABI (include/jperceiver_hip.h)
+extern "C" int jp_amax_slot_floats(void) { return JP_AMAX_SLOT; }
 extern "C" int jp_amax(const float* x, long n, float* out, void* stream) {
     JP_CHECK_ARG(out && (x || n == 0) && n >= 0, "amax: bad arguments");
     const int rc = launch_amax(x, n, out, static_cast<hipStream_t>(stream), true);
@@ -115,6 +124,22 @@ extern "C" int jp_amax_into(const float* x, long n, float* out, void* stream) {
     const int rc = launch_amax(x, n, out, static_cast<hipStream_t>(stream), false);
     if (rc != JP_OK) return rc;
     JP_LAUNCH_CHECK();
+}
+// "the next entry point that can, folds max |what it writes| into *slot" (max with what the slot holds: pre-zeroed by the caller).
+// Supporting entry points: jp_conv2d_fwd* when a patch kernel runs the layer (y), jp_bn_train_fwd (y), jp_bn_train_bwd (dx),
+// jp_act_bwd / jp_act_bwd_bias (dx).  jp_amax_out_done() -> 1 if the request was taken since jp_amax_out, and drops it otherwise:
+// call it right after the entry point the request was meant for.
+extern "C" int jp_amax_out(float* slot) {
+    JP_CHECK_ARG(slot, "amax_out: null pointer");
+    g_amax_out = reinterpret_cast<unsigned*>(slot);
+    g_amax_out_done = 0;
+    return JP_OK;
+}
+extern "C" int jp_amax_out_done(void) {
+    const int d = g_amax_out_done;
+    g_amax_out = nullptr;
+    g_amax_out_done = 0;
+    return d;
 }
 extern "C" int jp_amax_hint(const float* tensor, const float* amax) {
     JP_CHECK_ARG(tensor && amax, "amax_hint: null pointer");

@@ -21,25 +21,32 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 class Var:
     """A device tensor plus its (lazily allocated) gradient buffer.  `p`: the nn.Parameter a weight Var was made from
     (ops.param) -- conv weights of parameters get persistent packed copies (PackRegistry), raw tensors do not."""
-    __slots__ = ("t", "g", "rg", "p", "amax")
+    __slots__ = ("t", "g", "rg", "p", "amax", "gamax")
 
     def __init__(self, t: torch.Tensor, rg: bool = False, g: torch.Tensor | None = None, p=None):
         self.t, self.rg, self.g, self.p = t, rg, g, p
-        self.amax = None        # device scalar max|t| once a convolution asked for it (_amax_of; fp16 split kernels' operand scale)
+        # device scalars for the fp16 split kernels' operand scales: max|t| (or an upper bound: what the producer reported / a bound
+        # handed through a max-pool or an activation; reduced on first request otherwise, _amax_of) and max|g| while g is exactly
+        # what ONE producer wrote (dropped as soon as anything is accumulated into g)
+        self.amax = None
+        self.gamax = None
 
     def grad_buf(self):
         """-> (buffer, accumulate flag) for kernels that can either write or add."""
+        self.gamax = None
         if self.g is None:
             self.g = torch.empty_like(self.t)
             return self.g, 0
         return self.g, 1
 
-    def add_grad(self, d: torch.Tensor):
-        """d must be a fresh tensor owned by the caller."""
+    def add_grad(self, d: torch.Tensor, amax: torch.Tensor | None = None):
+        """d must be a fresh tensor owned by the caller (amax: device scalar max|d| if its producer reported it)."""
         if self.g is None:
             self.g = d
+            self.gamax = amax
         else:
             call("jp_axpby", self.g, d, self.g, d.numel(), 1.0, 1.0)
+            self.gamax = None
 
     @property
     def shape(self):
@@ -365,17 +372,28 @@ def amax_pool_reset():
 
 
 def _amax_slot(dev) -> torch.Tensor:
-    """One zeroed float of a pool that is zeroed 4096 slots at a time (one fill instead of a memset per reduction).  A pool belongs to
-    the stream it was zeroed on -- and to the graph capture it was zeroed in: a captured step replays the fill with the reductions."""
+    """One zeroed magnitude slot (jp_amax_slot_floats floats) of a pool that is zeroed 1024 slots at a time (one fill instead of a memset
+    per reduction).  A pool belongs to the stream it was zeroed on -- and to the graph capture it was zeroed in: a captured step replays
+    the fill with the reductions."""
+    SF = _slot_floats()
     st = torch.cuda.current_stream(dev)
     key = (dev.index, st.cuda_stream, torch.cuda.is_current_stream_capturing())
     ent = _AMAX_POOL.get(key)
-    if ent is None or ent[1] >= ent[0].numel():
+    if ent is None or ent[1] >= 1024:
         if len(_AMAX_POOL) > 64:
             _AMAX_POOL.clear()
-        ent = _AMAX_POOL[key] = [torch.zeros(4096, device=dev, dtype=torch.float32), 0]
+        ent = _AMAX_POOL[key] = [torch.zeros(1024 * SF, device=dev, dtype=torch.float32), 0]
     ent[1] += 1
-    return ent[0][ent[1] - 1:ent[1]]
+    return ent[0][(ent[1] - 1) * SF:ent[1] * SF]
+
+
+_SLOT_FLOATS = []
+
+
+def _slot_floats() -> int:
+    if not _SLOT_FLOATS:
+        _SLOT_FLOATS.append(int(_jplib().fn["jp_amax_slot_floats"]()))
+    return _SLOT_FLOATS[0]
 
 
 class _amax_hints:
@@ -396,6 +414,28 @@ class _amax_hints:
     def __exit__(self, *exc):
         if self.pairs:
             _jplib().fn["jp_amax_hint_clear"]()
+        return False
+
+
+class _amax_out:
+    """with _amax_out(dev) as ao: <one entry point>  ->  ao.amax = device scalar max|tensor that entry point wrote| if its kernel
+    folded the reduction in (jp_amax_out), else None.  Several calls may share one request object (`again`): the slot takes the
+    maximum over all of them, and `amax` stays None unless every one of them reported."""
+
+    def __init__(self, dev, on=True):
+        self.slot = _amax_slot(dev) if (on and split_scheme() == 2) else None
+        self.amax = None
+        self._ok = self.slot is not None
+
+    def __enter__(self):
+        if self.slot is not None:
+            _jplib().fn["jp_amax_out"](self.slot.data_ptr())
+        return self
+
+    def __exit__(self, *exc):
+        if self.slot is not None:
+            self._ok = bool(_jplib().fn["jp_amax_out_done"]()) and self._ok and exc[0] is None
+            self.amax = self.slot if self._ok else None
         return False
 
 
@@ -444,27 +484,31 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
     sig = (tuple(s3[1::3]), tuple(s3[2::3]), N, H, W, stride, pad, pad_mode)
     big = Cin >= 32 and Cout >= 32            # (the few-channel layers run direct kernels without operand scales)
     x_hints = [(v.t, _amax_of(v)) for v, _ in srcs] if big else []
-    with _amax_hints(*x_hints):
+    with _amax_hints(*x_hints), _amax_out(y.device, big) as y_am:
         _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
                    (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act), (ws_s,))
     del ws_s
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
+    out.amax = y_am.amax          # max|y| from the kernel's epilogue when a patch kernel ran the layer: the next convolution's scale
 
     def bwd():
         if out.g is None:
             return
         dy = out.g
+        dy_am = out.gamax             # what the producer of this gradient reported (BatchNorm backward), if nothing was added since
         bias_done = False
         if act != ACT_NONE:
             d2 = torch.empty_like(dy)
-            if b is not None and b.rg and Cout <= 65535:
-                # activation backward and bias gradient in one pass (the bias gradient is a sum over the tensor this pass writes)
-                call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act)
-                bias_done = True
-            else:
-                call("jp_act_bwd", dy, y, d2, dy.numel(), act)
-            dy = d2
-        dy_hint = (dy, _amax_of(dy)) if big else (None, None)      # on the tape's stream, before the wgrad stream forks off it
+            with _amax_out(dy.device, big) as ao:
+                if b is not None and b.rg and Cout <= 65535:
+                    # activation backward and bias gradient in one pass (the bias gradient is a sum over the tensor this pass writes)
+                    call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act)
+                    bias_done = True
+                else:
+                    call("jp_act_bwd", dy, y, d2, dy.numel(), act)
+            dy, dy_am = d2, ao.amax
+        # (reduced here, on the tape's stream, before the wgrad stream forks off it, unless its producer reported it)
+        dy_hint = (dy, dy_am if dy_am is not None else _amax_of(dy)) if big else (None, None)
 
         def param_grads():
             with _amax_hints(dy_hint, *x_hints):
@@ -601,12 +645,15 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
     mean = _new((groups, C), x.t)
     invstd = _new((groups, C), x.t)
     nbw = int(_jplib().fn["jp_bn_ws_doubles"](Ng, C, H * W))
+    y_am = _amax_out(y.device, C >= 32)       # max|y| out of the apply kernel: the next convolution's operand scale
     for g in range(groups):
         sl = slice(g * Ng, (g + 1) * Ng)
         ws = _new((nbw,), x.t, torch.float64)
-        call("jp_bn_train_fwd", x.t[sl], gamma.t, beta.t, residual.t[sl] if residual is not None else None, y[sl], running_mean,
-             running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates)
+        with y_am:
+            call("jp_bn_train_fwd", x.t[sl], gamma.t, beta.t, residual.t[sl] if residual is not None else None, y[sl], running_mean,
+                 running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates)
     out = Var(y, x.rg or gamma.rg or (residual is not None and residual.rg))
+    out.amax = y_am.amax
 
     def bwd():
         if out.g is None:
@@ -614,15 +661,17 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
         dx = torch.empty_like(x.t)
         need_res = residual is not None and residual.rg
         dres = torch.empty_like(x.t) if need_res else None
+        dx_am = _amax_out(dx.device, C >= 32)     # max|dx| out of the apply kernel: the scale of the convolution backward it feeds
         for g in range(groups):
             sl = slice(g * Ng, (g + 1) * Ng)
             ws2 = _new((nbw,), x.t, torch.float64)
             # residual-free ReLU layers: the kernel recomputes the mask from x (fmaf(x, sc, sh) > 0, bit-identical to the
             # forward's) instead of reading y
-            call("jp_bn_train_bwd", out.g[sl], x.t[sl], y[sl] if (relu and residual is not None) else None, gamma.t, beta.t,
-                 mean[g], invstd[g], dx[sl], dres[sl] if need_res else None, gamma.g, beta.g, ws2, Ng, C, H * W, int(relu), 1)
+            with dx_am:
+                call("jp_bn_train_bwd", out.g[sl], x.t[sl], y[sl] if (relu and residual is not None) else None, gamma.t, beta.t,
+                     mean[g], invstd[g], dx[sl], dres[sl] if need_res else None, gamma.g, beta.g, ws2, Ng, C, H * W, int(relu), 1)
         if x.rg:
-            x.add_grad(dx)
+            x.add_grad(dx, dx_am.amax)
         if need_res:
             residual.add_grad(dres)
         out.g = None
@@ -706,6 +755,7 @@ def maxpool(x: Var, k, s, p, bwd_addend=None) -> Var:
     idx = _new((N, C, OH, OW), x.t, torch.uint8)
     call("jp_maxpool_fwd", x.t, y, idx, N * C, H, W, k, s, p)
     out = Var(y, x.rg)
+    out.amax = x.amax             # |max over a window| <= max|x|: an upper bound is all an operand scale needs
 
     def bwd():
         if out.g is None:
@@ -823,6 +873,8 @@ def act(x: Var, kind) -> Var:
     y = torch.empty_like(x.t)
     call("jp_act_fwd", x.t, y, y.numel(), kind)
     out = Var(y, x.rg)
+    if kind in (ACT_RELU, ACT_LEAKY):
+        out.amax = x.amax         # |act(x)| <= |x|: still an upper bound
 
     def bwd():
         if out.g is None:
