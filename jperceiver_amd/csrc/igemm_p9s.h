@@ -1,6 +1,10 @@
 // "P9S" patch kernel: the P9 convolution (3x3 stride-1 pad-1 forward / dgrad main pass, and 1x1) with every fp32 product
-// formed on the BF16 matrix pipe from exact three-way splits of both operands -- fp32 in, fp32 out, fp32 accumulate,
-// fp32-equivalent accuracy, at 6/16 of the fp32-MFMA issue cost.
+// formed on the 16-bit matrix pipe from splits of both operands -- fp32 in, fp32 out, fp32 accumulate, fp32-grade accuracy.
+// Two arithmetic schemes share the kernel bodies (JP_NS below): since the second half of round 5 the default is TWO fp16 splits of
+// power-of-two-scaled operands and THREE products (jp_split2h; DESIGN 4.6b has the error model and the measurements) -- the
+// six-product kernels had reached the power wall of the matrix pipe, so the only way on was fewer products.  What
+// follows describes the round-3 scheme (JP_NS == 3: three bf16 splits, six products, exact operands), which -DJP_NS=3 still builds
+// and the 7x7 stem / stride-2 weight-gradient kernels still use.
 //
 // Why.  gfx950 has no TF32/xf32 path and its fp32 MFMA runs at the fp32 VECTOR rate (157 TF), 1/16 of the bf16 MFMA rate
 // (2.5 PF dense).  An fp32 value v is the sum of three bf16 values to within 2^-25 |v|:
