@@ -142,7 +142,10 @@ __device__ __forceinline__ jp_f32x16 jp_mfma_bf16_sw(jp_u32x4 a, jp_u32x4 b, jp_
 #endif
 }
 
-constexpr int P9S_AHEAD = 1;          // steps of weight prefetch (register ring of P9S_AHEAD + 1 slots)
+constexpr int P9S_AHEAD = 2;          // steps of slack behind every M tile's weight stream in the pack: the deepest prefetch of any kernel
+#ifndef P9S_AH3
+#define P9S_AH3 2                     // steps of weight prefetch of the 3x3 kernels in the three-product build (measured: tools/ubench/p9s_bench.hip)
+#endif
 
 // WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
 // TAPS = 9 (3x3, one-pixel halo) or 1 (1x1).  KGS = 16-channel groups per stage.
@@ -292,7 +295,12 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
     // ---- weight stream of this M tile: step u (global over stages) = [split][k-half][row] x 16 B; lane (l31, lhi) of row
     // block i reads [s][lhi][wm*64 + i*32 + l31].  SGPR buffer resource + constant per-lane offset + scalar step offset.
     constexpr int SBYTES = NS * 2 * BMT * 16;                 // bytes per step
-    constexpr int RING = P9S_AHEAD + 1;
+    // steps of weight prefetch (register ring of AH + 1 slots).  One step ahead was a whole step of 12-24 MFMAs x 2 waves when a product
+    // cost six MFMAs; with three it is 400-800 cycles, less than a loaded L2 round trip: the 3x3 kernels (9 steps per stage: the ring slot
+    // of a step is its index mod 3 in every stage) request two steps ahead
+    constexpr int AH = (NS == 2 && TAPS == 9 && KGS == 1) ? P9S_AH3 : 1;
+    constexpr int RING = AH + 1;
+    static_assert(AH <= P9S_AHEAD && (RING == 2 || STEPS % RING == 0), "ring slot of a step must not depend on the stage");
     const long tile_bytes = ((long)NST * STEPS + P9S_AHEAD) * SBYTES;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(wp)) + (long)(mt + mt_off) * tile_bytes, 0, (int)tile_bytes, 0x00020000);
@@ -306,7 +314,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * BMT * 16), step_bytes, 0);
     };
 #pragma unroll
-    for (int d = 0; d < P9S_AHEAD; ++d) aload(d, (s_begin * STEPS + d) * SBYTES);
+    for (int d = 0; d < AH; ++d) aload(d, (s_begin * STEPS + d) * SBYTES);
     const jp_u32x4* bp = patch + (lhi * PR + wn * NJ) * COLS + l31;
 
     if constexpr (ROWB) {
@@ -333,7 +341,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             bload(BUF, 0, 0);
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) {
-                aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+                aload((PAR * STEPS + u + AH) % RING, ab + (u + AH) * SBYTES);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     if (j + 1 < NJ) bload(BUF, j + 1, u);
@@ -352,7 +360,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             }
             __syncthreads();
         };
-        static_assert(RING == 2, "two stage parities <-> two ring phases");
+        static_assert(RING == 2 || STEPS % RING == 0, "two stage parities <-> two ring phases (or none)");
         gload(0, s_begin);
         if (DB) {
             lstore(0, 0);
@@ -397,7 +405,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             for (int u = 0; u < STEPS; ++u) {
                 // operands of step u + 1 are requested before the MFMAs of step u issue: weights of step u + AHEAD (the stream
                 // continues into the next stage; the pack carries AHEAD steps of slack), B fragments of step u + 1
-                aload((PAR * STEPS + u + P9S_AHEAD) % RING, ab + (u + P9S_AHEAD) * SBYTES);
+                aload((PAR * STEPS + u + AH) % RING, ab + (u + AH) * SBYTES);
                 if (u + 1 < STEPS) bload(BUF, (u + 1) & 1, u + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // the six products with split index sum <= 2, smallest terms first; consecutive MFMAs go to different accumulators
@@ -416,7 +424,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             JP_TR(5 + 4 * (stage & 7));
             __syncthreads();
         };
-        static_assert(RING == 2, "two stage parities <-> two ring phases");
+        static_assert(RING == 2 || STEPS % RING == 0, "two stage parities <-> two ring phases (or none)");
         gload(0, s_begin);
         JP_TR(1);
         if (DB) {

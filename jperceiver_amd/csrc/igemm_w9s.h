@@ -31,6 +31,9 @@ typedef short jp_s16x8 __attribute__((ext_vector_type(8)));
 #ifndef W9S_DB
 #define W9S_DB 1
 #endif
+#ifndef W9S_LA
+#define W9S_LA 2           // taps of look-ahead of the transpose reads in the three-product build (1: as the six-product stream)
+#endif
 // NCB = 32-channel INPUT blocks per workgroup: 2 (128 output x 64 input channels, rounds 3) or 1 (256 output x 32 input channels,
 // round 4).  The kernel is VALU-issue-sensitive (timing probes, profiles/r04_w9s_probes.log: dropping the 44-VALU dY split per K
 // group is worth 8 %, dropping the patch staging 12.6 %) and the patch staging -- address arithmetic + split of every staged X
@@ -226,7 +229,10 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
         }
     };
     typedef short jp_s16x4_ __attribute__((ext_vector_type(4)));
-    jp_s16x4_ bh[2][NS][2];                              // [tap parity][split][pixel half] transpose-read results
+    // transpose-read results [fragment set][split][pixel half]; a tap's fragments are requested LA taps ahead.  Six products per tap
+    // (192 pipe cycles) cover the LDS latency from one tap ahead; three products (96 cycles) do not: two ahead (W9S_LA), three sets
+    constexpr int LA = NS == 2 ? W9S_LA : 1, NSET = LA + 1;
+    jp_s16x4_ bh[NSET][NS][2];
     auto bread_half = [&](int ty, int tx, int g, int s, int h) -> jp_s16x4_ {
         const int imm = s * SPL + ((g / 2 + ty) * PC + 16 * (g % 2) + tx) * 64;
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -254,9 +260,11 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
             tile_org(T + 2, img, y0, x0);
             const int tbnn = (img * Cout) * (int)HW + y0 * W + x0;
 #pragma unroll
-            for (int s_ = 0; s_ < NS; ++s_)
+            for (int q0 = 0; q0 < LA; ++q0)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) bh[0][s_][h] = bread_half(0, 0, 0, s_, h);
+                for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) bh[q0 % NSET][s_][h] = bread_half(q0 / 3, q0 % 3, 0, s_, h);
 #pragma unroll
             for (int gi = 0; gi < KGW; ++gi) {
                 const int g = gi, cur = gi & 1;
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
                 else aload(cur, tbnn, kg * KGW + gi + 2 - 2 * KGW);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int tp = (9 * gi + tap) & 1;               // fragment set of this tap (9 taps per K group: the parity runs on)
+                    const int tq = 9 * gi + tap;                     // tap counter of the tile: fragment set tq % NSET, requested at tap tq - LA
+                    const int tp = tq % NSET, tn = (tq + LA) % NSET, gn = (tq + LA) / 9, tapn = (tq + LA) % 9;
 #pragma unroll
                     for (int m = 0; m < NPROD; ++m) {
                         // the products with split index sum <= NS - 1, smallest terms first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0) | (1,0) (0,1) (0,0)
@@ -278,8 +287,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s_kernel(const float* __res
 #pragma unroll
                         for (int rd = 0; rd < 2 * NS; ++rd) {
                             if ((NS == 3 ? rd : (rd < 2 ? 0 : rd - 1)) != m) continue;
-                            if (tap + 1 < 9) bh[tp ^ 1][rd >> 1][rd & 1] = bread_half((tap + 1) / 3, (tap + 1) % 3, g, rd >> 1, rd & 1);
-                            else if (gi + 1 < KGW) bh[tp ^ 1][rd >> 1][rd & 1] = bread_half(0, 0, g + 1, rd >> 1, rd & 1);
+                            if (gn < KGW) bh[tn][rd >> 1][rd & 1] = bread_half(tapn / 3, tapn % 3, gn, rd >> 1, rd & 1);
                         }
                         // ... and, spread over the K group, the pieces of the next K group's dY split
                         {
