@@ -47,8 +47,9 @@ ARITHMETIC = {
     2: "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 3 fp16-MFMA products a0 b0 + a0 b1 + a1 b0 of "
        "two-way fp16 splits of both operands, each operand tensor scaled by the power of two that puts its largest magnitude into [2^14, 2^15) "
        "(igemm_p9s.h:jp_split2h, scale.hip): operands carried to 2^-23 relative for elements within 2^-17 of their tensor's largest, 2^-40 of "
-       "that largest below; the term left out is <= 2^-22 |a b|.  Measured error vs float64: 1.0-1.3 x the exact-fp32 MFMA kernels' on layer "
-       "data (tests/test_split_accuracy_gpu.py, tools/split_study.py: the split error is 3-4 x below the fp32 accumulation's own rounding). "
+       "that largest below; the term left out is <= 2^-22 |a b|.  Measured error vs float64: 0.62-1.00 x the exact-fp32 MFMA kernels' on 48 "
+       "layer x pass cases (profiles/r05_fp16x2_accuracy_vs_f64.md; tests/test_split_accuracy_gpu.py holds <= 1.25 x; tools/split_study.py: "
+       "the split error is 3-4 x below the fp32 accumulation's own rounding). "
        "Inf / NaN / |x| >= 2^100 inputs: NaN in the outputs that read them.  A -DJP_NS=3 build keeps the exact 3-way bf16 splits (6 products); "
        "JP_P9S=0 JP_W9S=0 JP_P9US=0 selects the exact-fp32 MFMA kernels",
     3: "fp32 in / out / accumulate everywhere; the patch convolutions form each fp32 product as 6 bf16-MFMA "
