@@ -497,11 +497,15 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #endif
 }
 
+#ifndef P9S_OCC1
+#define P9S_OCC1 1         // 1: the 8-wave 1x1 kernels with <= 128 registers (two workgroups per CU) in the three-product build
+#endif
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
-__global__ __launch_bounds__(64 * WM * WN, NJ <= 2 ? 2 : 1) void jp_igemm_p9s_kernel(
+__global__ __launch_bounds__(64 * WM * WN, (P9S_OCC1 && JP_NS == 2 && TAPS == 1 && WM * WN == 8) ? 4 : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,
     const float* __restrict__ xam) {
-    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1>(wp, x, epi, M, C, NST, H, W, mt_off, xam);
+    jp_igemm_p9s_body<WM, WN, NJ, REFLECT, REV, Epi, TAPS, KGS, 1, false, (P9S_OCC1 && JP_NS == 2 && TAPS == 1 && WM * WN == 8)>(
+        wp, x, epi, M, C, NST, H, W, mt_off, xam);
 }
 // "wide" tiles (round 4): NJ = 4 pixel rows per wave (8 rows x 32 columns per workgroup with WN = 2), B fragments re-read row
 // by row (ROWB): a wave's weight fragments serve twice the pixels, i.e. half the L2 -> CU weight-stream bytes per MFMA, and a 3x3
