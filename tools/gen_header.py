@@ -16,16 +16,38 @@ GROUPS = [
      "(jp_conv2d_ws_floats) and whether it already holds this layer's pack (1) or must be packed by this call (0); packs recorded with "
      "jp_pack_record_begin/end can be refreshed for the whole model by one jp_pack_replay launch per step (job table in device memory; every job's `begin` is the running sum of the totals rounded up to a multiple of 4, "
      "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements).  "
-     "ARITHMETIC: fp32 in / out / accumulate.  The patch kernels (3x3, 1x1, 7x7 stem, iconv; JP_P9S / JP_W9S / JP_P9US / JP_P9SD / JP_P9S2 / JP_P7S, "
-     "default on) form each fp32 product on the bf16 matrix pipe as 6 bf16 products of exact 3-way bf16 splits of both operands "
-     "(csrc/igemm_p9s.h:33-45): error vs float64 <= the fp32 FMA chain's for finite inputs with 2^-109 <= |x| <= 3.3895e38 (the "
-     "largest bf16).  RANGE EDGES (tests/test_split_accuracy_gpu.py::test_split_range_edges_match_documented_behaviour): a NaN or "
-     "+-Inf input makes exactly the outputs that read it non-finite, as in an fp32 convolution, but an Inf input yields NaN (not "
-     "+-Inf: Inf - bf16(Inf) = NaN in the residual splits); a finite input with |x| > 3.3895e38 (top 0.4 % of the fp32 range) "
-     "rounds to Inf in its high split and is treated like Inf; for |x| < 2^-109 the low splits fall into the bf16 subnormal "
-     "range and flush: relative accuracy degrades towards 2^-9 (absolute error < 2^-126 |w|).  JP_P9S=0 JP_W9S=0 JP_P9US=0 "
-     "JP_P9SD=0 JP_P9S2=0 selects the exact-fp32 MFMA kernels, which have none of these edges.",
+     "ARITHMETIC: fp32 in / out / accumulate.  The patch kernels (3x3, 1x1, iconv; JP_P9S / JP_W9S / JP_P9US / JP_P9SD / JP_P9S2, default on) "
+     "form each fp32 product on the 16-bit matrix pipe.  Default build (JP_NS = 2, jp_split_scheme() == 2): 3 fp16 products a0 b0 + a0 b1 + a1 b0 "
+     "of two-way fp16 splits of both operands, each operand TENSOR scaled by the power of two that puts its largest magnitude into "
+     "[2^14, 2^15) (csrc/igemm_p9s.h:jp_split2h, csrc/scale.hip; magnitudes: the jp_amax* group below).  Operands are carried to 2^-23 "
+     "relative for elements within 2^-17 of their tensor's largest, to 2^-40 OF THAT LARGEST below; the term left out is <= 2^-22 |a b|.  "
+     "Measured against float64 on layer data the rms error is 0.62-1.00 x the exact-fp32 MFMA kernels' (profiles/r05_fp16x2_accuracy_vs_f64.md; "
+     "tests/test_split_accuracy_gpu.py holds it to 1.25 x and every output to 2^-19 sum|a||b|; tools/split_study.py: the split error is 3-4 x "
+     "below the fp32 accumulation's own rounding).  It is an error relative to the tensor's largest magnitude, not to each element: outputs "
+     "that depend only on values > 2^29 below their tensor's largest lose relative precision.  RANGE EDGES "
+     "(test_split_range_edges_match_documented_behaviour): Inf / NaN inputs and finite ones with |x| >= 2^100 take no part in the scale and "
+     "make exactly the outputs that read them NaN (an fp32 convolution yields +-Inf for an Inf input); everything else is bit-identical to "
+     "the run without them.  Tensors of tiny values are lifted by their scale (2^-120 inputs: full accuracy).  The 7x7 stem and the stride-2 "
+     "weight gradient (JP_P7S, W9S2) and a -DJP_NS=3 build use 6 bf16 products of exact 3-way bf16 splits (csrc/igemm_p9s.h:jp_split3: error "
+     "<= the fp32 FMA chain's for 2^-109 <= |x| <= 3.3895e38; Inf -> NaN).  JP_P9S=0 JP_W9S=0 JP_P9US=0 JP_P9SD=0 JP_P9S2=0 selects the "
+     "exact-fp32 MFMA kernels, which have none of these edges.",
      ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
+    ("Operand scales of the fp16 split kernels (csrc/scale.hip, csrc/igemm_p9s.h:jp_split2h) -- no counterpart in the reference: plumbing of "
+     "the arithmetic above.  A kernel that forms its fp32 products from two fp16 splits per operand reads the operand tensor's largest "
+     "magnitude from device memory.  A magnitude lives in a SLOT of jp_amax_slot_floats() floats (512: 32 words one cache line apart -- "
+     "producers spread their atomics over them, the kernels take the maximum; every `out` / `amax` / `slot` below is one).  The conv entry "
+     "points reduce it themselves (one extra read of the tensor per call) unless the caller registered a hint: jp_amax writes max |x[0..n)| "
+     "(Inf / NaN / |x| >= 2^100 excluded) to *out (jp_amax_into: max(*out, that) -- *out pre-zeroed by the caller, no memset); "
+     "jp_amax_hint(tensor, amax) tells the NEXT conv calls of this thread that `amax` (from jp_amax on this stream or an earlier one it is "
+     "ordered after) holds the largest magnitude of the operand that starts at `tensor`; jp_amax_hint_clear drops the pending hints (at most 8).  "
+     "A hint that is too SMALL overflows fp16 (Inf / NaN outputs); one that is too large only costs precision.  jp_amax_out(slot): the next "
+     "entry point of this thread that fuses the reduction into its kernel folds max |tensor it writes| into *slot (pre-zeroed by the caller) "
+     "-- jp_conv2d_fwd* when a patch kernel runs the layer (y), jp_bn_train_fwd (y), jp_bn_train_bwd (dx), jp_act_bwd / jp_act_bwd_bias (dx); "
+     "jp_amax_out_done() right after that call: 1 = the slot is being written, 0 = the entry point did not take it (request dropped).  "
+     "jp_split_scheme: 2 = this build's patch kernels use the fp16 two-way split (hints are read), 3 = the bf16 three-way split (no operand "
+     "scales; hints are ignored).",
+     ["jp_amax_slot_floats", "jp_amax", "jp_amax_into", "jp_amax_hint", "jp_amax_hint_clear", "jp_amax_out", "jp_amax_out_done",
+      "jp_split_scheme"]),
     ("Train-mode BatchNorm2d (+fused residual add / ReLU) — " + R + "resnet.py:21-24,41-45,92; " + R + "layout_model.py:146,152. "
      "ws = jp_bn_ws_doubles(N, C, HW) doubles of caller scratch.  n_updates = number of momentum updates of the running stats (2 for the layout "
      "branch the reference evaluates twice, " + R + "net.py:73-74).  jp_bn_relu_pool_*: the ResNet stem tail bn1 -> relu -> MaxPool2d(3, 2, 1) ("
