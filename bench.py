@@ -65,7 +65,7 @@ def _scheme():
     return ops.split_scheme()
 
 
-SIX_TAGS = ("p7s_tag", "w9s2_tag", "p1l_tag")       # split kernels that still run the six-product bf16 scheme
+SIX_TAGS = ("p1l_tag",)       # split kernels that still run the six-product bf16 scheme
 
 
 def _products(tag):

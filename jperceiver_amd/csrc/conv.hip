@@ -174,8 +174,8 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
             const int Cout = p[0], Cin = p[1];
             const int w4 = (int)(i & 3), m = (int)((i >> 2) & 63), khalf = (int)((i >> 8) & 1);
             const long t = i >> 9;
-            const int sp = (int)(t % 3);
-            const long U = t / 3;
+            const int sp = (int)(t % JP_NS);
+            const long U = t / JP_NS;
             const int c = (int)(U >> 2), ky = 2 * (int)(U & 3) + khalf;
             float v[2];
 #pragma unroll
@@ -183,9 +183,9 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
                 const int kx = 2 * w4 + k;
                 v[k] = (c < Cin && m < Cout && ky < 7 && kx < 7) ? w[(((size_t)m * Cin + c) * 7 + ky) * 7 + kx] : 0.f;
             }
-            unsigned s0, s1, s2;
-            jp_split3(v[0], v[1], s0, s1, s2);
-            return __uint_as_float(sp == 0 ? s0 : (sp == 1 ? s1 : s2));
+            unsigned sq[3];
+            jp_split_ns(v[0], v[1], sc, sq);
+            return __uint_as_float(sp == 0 ? sq[0] : (sp == 1 ? sq[1] : sq[2]));
         }
         case PACK_SPLITUPD: {  // p = Cout, Cin, c_off, Cx: dgrad weights of the upsampled iconv segment as bf16 three-way splits in the
                                // fragment order of the P9SD kernel (igemm_p9sd.h): [M tile of 128 rows c][step = (16-channel stage
@@ -270,11 +270,11 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ w
 // Split packs of the fp16 two-way scheme (JP_NS == 2) start with a header {s, 1 / s, 0, 0}: s = the power of two that puts the weight
 // tensor's largest magnitude into [2^14, 2^15) (jp_scale_exp); the fragments hold the splits of s * w.  pack_scale_kernel writes the
 // headers (one workgroup per job) BEFORE the pack kernels of the same stream read them.
-__device__ __forceinline__ int pack_hdr(int mode) { return (mode == PACK_SPLIT || mode == PACK_SPLITUPD) ? JP_PACK_HDR : 0; }
+__device__ __forceinline__ int pack_hdr(int mode) { return (mode == PACK_SPLIT || mode == PACK_SPLITUPD || mode == PACK_SPLIT7) ? JP_PACK_HDR : 0; }
 // the weight scale a split pack's elements are multiplied by: PACK_SPLIT's own header; PACK_SPLITSEG: the bank's header, p[5] words back
 __device__ __forceinline__ float pack_scale_of(const JpPackJob& j) {
     if (!JP_PACK_HDR) return 1.f;
-    if (j.mode == PACK_SPLIT || j.mode == PACK_SPLITUPD) return j.wp[0];
+    if (j.mode == PACK_SPLIT || j.mode == PACK_SPLITUPD || j.mode == PACK_SPLIT7) return j.wp[0];
     if (j.mode == PACK_SPLITSEG) return *(j.wp - j.p[5]);
     return 1.f;
 }
@@ -285,8 +285,9 @@ constexpr int PSL = 32;
 __device__ __forceinline__ float* pack_scale_hdr(const JpPackJob& j, long* n) {
     const bool seg = j.mode == PACK_SPLITSEG && j.p[2] == 0;          // the bank's first segment owns the bank's header
     const bool upd = j.mode == PACK_SPLITUPD;                         // (pre-summed slot weights of the whole tensor: x 4 bound, like seg)
-    if (!JP_PACK_HDR || !(j.mode == PACK_SPLIT || seg || upd)) return nullptr;
-    *n = (long)j.p[0] * j.p[1] * ((seg || upd) ? 9 : j.p[4]);
+    const bool s7 = j.mode == PACK_SPLIT7;
+    if (!JP_PACK_HDR || !(j.mode == PACK_SPLIT || seg || upd || s7)) return nullptr;
+    *n = (long)j.p[0] * j.p[1] * ((seg || upd) ? 9 : (s7 ? 49 : j.p[4]));
     return seg ? j.wp - j.p[5] : j.wp;
 }
 __device__ __forceinline__ void pack_scale_zero(const JpPackJob& j) {
@@ -310,7 +311,7 @@ __device__ __forceinline__ void pack_scale_finish(const JpPackJob& j) {
     float* hdr = pack_scale_hdr(j, &n);
     if (!hdr || threadIdx.x) return;
     // (iconv banks: the upsampled segment's elements are sums of up to four taps -- pack_slot_sum -- and all segments share one scale)
-    const int k = jp_scale_exp(hdr[2] * (j.mode != PACK_SPLIT ? 4.f : 1.f));
+    const int k = jp_scale_exp(hdr[2] * ((j.mode == PACK_SPLITSEG || j.mode == PACK_SPLITUPD) ? 4.f : 1.f));
     hdr[0] = jp_exp2i(k);
     hdr[1] = jp_exp2i(-k);
     hdr[2] = hdr[3] = 0.f;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(64) void pack_scale_finish_kernel(const JpPackJob* 
         long n;
         float* hdr = pack_scale_hdr(jobs[q], &n);
         if (hdr) {
-            const int k = jp_scale_exp(hdr[2] * (jobs[q].mode != PACK_SPLIT ? 4.f : 1.f));
+            const int k = jp_scale_exp(hdr[2] * ((jobs[q].mode == PACK_SPLITSEG || jobs[q].mode == PACK_SPLITUPD) ? 4.f : 1.f));
             hdr[0] = jp_exp2i(k);
             hdr[1] = jp_exp2i(-k);
             hdr[2] = hdr[3] = 0.f;
@@ -520,7 +521,7 @@ void do_pack(int mode, const float* w, float* wp, long total, int p0, int p1, in
         if (g_pack_rec_n < g_pack_rec_cap) g_pack_rec[g_pack_rec_n] = j;
         ++g_pack_rec_n;      // counted even when the buffer is full: jp_pack_record_end reports the overflow
     }
-    if (JP_PACK_HDR && (mode == PACK_SPLIT || mode == PACK_SPLITUPD || (mode == PACK_SPLITSEG && p2 == 0))) {
+    if (JP_PACK_HDR && (mode == PACK_SPLIT || mode == PACK_SPLITUPD || mode == PACK_SPLIT7 || (mode == PACK_SPLITSEG && p2 == 0))) {
         hipLaunchKernelGGL(pack_scale_zero_one_kernel, dim3(1), dim3(64), 0, st, j);
         hipLaunchKernelGGL(pack_scale_reduce_one_kernel, dim3(PSL), dim3(256), 0, st, j);
         hipLaunchKernelGGL(pack_scale_finish_one_kernel, dim3(1), dim3(64), 0, st, j);
@@ -2507,15 +2508,17 @@ const char* w9s2_tag() { return __PRETTY_FUNCTION__; }
 static void launch_w9s2(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
                         const W9S2Plan& p, hipStream_t st) {
     const int dyb = (int)((long)N * Cout * (H / 2) * (W / 2) * 4), xb = (int)((long)N * Cx * H * W * 4);
-    const double fl = 6.0 * 2.0 * Cout * 9.0 * Cm * (double)N * (H / 2) * (W / 2);
+    const float* gam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * (H / 2) * (W / 2), st) : nullptr;
+    const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * Cx * H * W, st) : nullptr;
+    const double fl = JP_NPROD * 2.0 * Cout * 9.0 * Cm * (double)N * (H / 2) * (W / 2);
     if (p.kg == 2) {
         jp_prof_before(w9s2_tag<2>(), fl, st);
         hipLaunchKernelGGL((jp_wgrad_w9s2_kernel<2>), dim3(Cm / 32, 1, p.splits), dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
-                           p.ntiles, p.tps, dyb, xb);
+                           p.ntiles, p.tps, dyb, xb, gam, xam);
     } else {
         jp_prof_before(w9s2_tag<1>(), fl, st);
         hipLaunchKernelGGL((jp_wgrad_w9s2_kernel<1>), dim3(Cm / 32, Cout / 256, p.splits), dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm,
-                           H, W, p.ntiles, p.tps, dyb, xb);
+                           H, W, p.ntiles, p.tps, dyb, xb, gam, xam);
     }
     jp_prof_after(st);
 }
@@ -2758,13 +2761,14 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
         if (KH == 7 && stride == 2 && pad == 3 && (Cin == 3 || Cin == 6) && p9s_enabled() && p9s2_enabled() && JP_ENV_ON("JP_P7S") && H == 2 * OH && W == 2 * OW &&
             OH % 8 == 0 && OW % 32 == 0 && (long)Cin * H * W * 4 < (1L << 31)) {
             // P7S stem kernel (igemm_p7s.h): split-bf16 products, the whole K of a tile staged once
-            const long tot = (4L * Cin + 1) * 1536;
+            const long tot = (4L * Cin + 1) * (JP_NS * 512) + JP_PACK_HDR;
             if (!ws_state) do_pack(PACK_SPLIT7, w, ws, tot, Cout, Cin, 0, 0, 0, 0, st);
             const int ntiles = N * (OH / 8) * (OW / 32);
             const unsigned* wq = reinterpret_cast<const unsigned*>(ws);
-            jp_prof_before(Cin == 3 ? p7s_tag<3, FwdEpi>() : p7s_tag<6, FwdEpi>(), 6.0 * 2.0 * 64 * (double)npix * 64.0 * Cin, st);
-            if (Cin == 3) hipLaunchKernelGGL((jp_igemm_p7s_kernel<3, FwdEpi>), dim3(ntiles), dim3(256), 0, st, wq, x0, e, Cout, OH, OW, ntiles);
-            else hipLaunchKernelGGL((jp_igemm_p7s_kernel<6, FwdEpi>), dim3(ntiles), dim3(256), 0, st, wq, x0, e, Cout, OH, OW, ntiles);
+            const float* xam = JP_NS == 2 ? jp_amax_of(x0, (long)N * Cin * H * W, st) : nullptr;
+            jp_prof_before(Cin == 3 ? p7s_tag<3, FwdEpi>() : p7s_tag<6, FwdEpi>(), JP_NPROD * 2.0 * 64 * (double)npix * 64.0 * Cin, st);
+            if (Cin == 3) hipLaunchKernelGGL((jp_igemm_p7s_kernel<3, FwdEpi>), dim3(ntiles), dim3(256), 0, st, wq, x0, e, Cout, OH, OW, ntiles, xam);
+            else hipLaunchKernelGGL((jp_igemm_p7s_kernel<6, FwdEpi>), dim3(ntiles), dim3(256), 0, st, wq, x0, e, Cout, OH, OW, ntiles, xam);
             jp_prof_after(st);
             JP_LAUNCH_CHECK();
         }

@@ -16,15 +16,23 @@
 #endif
 template <int CIN, class Epi>
 __global__ __launch_bounds__(256, P7S_OCC) void jp_igemm_p7s_kernel(const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi,
-                                                              int M, int OH, int OW, int ntiles) {
+                                                              int M, int OH, int OW, int ntiles, const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    float xsc = 1.f, osc = 1.f;
+    if constexpr (NS == 2) {    // operand scales, see jp_igemm_p9s_body (the pack's header: PACK_SPLIT7)
+        const int kx = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
+        xsc = jp_exp2i(kx);
+        osc = jp_exp2i(-kx) * __uint_as_float(__builtin_amdgcn_readfirstlane(wp[1]));
+        wp += JP_PACK_HDR;
+    }
     constexpr int NT = 256, NJ = 2, TR = 8;
     constexpr int STEPS = 4 * CIN;                                 // two of the 8 (padded) tap rows of a channel per step
     constexpr int PRW = 2 * TR + 6, PDW = 35, PITCH = 36;          // patch rows per channel, dwords per row, row pitch (dwords)
     constexpr int SPLW = CIN * PRW * PITCH;                        // dwords per split plane
     constexpr int RPP = NT / PITCH, KP = (PRW + RPP - 1) / RPP;    // patch rows per staging pass (7), passes per channel (4)
     constexpr int NQ = CIN * KP;
-    constexpr int SBYTES = 3 * 2 * 64 * 16;
-    __shared__ unsigned patch[3 * SPLW];
+    constexpr int SBYTES = NS * 2 * 64 * 16;
+    __shared__ unsigned patch[NS * SPLW];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wn = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -75,12 +83,12 @@ __global__ __launch_bounds__(256, P7S_OCC) void jp_igemm_p7s_kernel(const unsign
             if (r0 + RPP * k >= PRW) continue;
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
-                unsigned s0, s1, s2;
-                jp_split3(rv[c * KP + k][0], rv[c * KP + k][1], s0, s1, s2);
+                unsigned sq[3];
+                jp_split_ns(rv[c * KP + k][0], rv[c * KP + k][1], xsc, sq);
                 unsigned* o = lbase + (c * PRW + RPP * k) * PITCH;
-                o[0] = s0;
-                o[SPLW] = s1;
-                o[2 * SPLW] = s2;
+                o[0] = sq[0];
+                o[SPLW] = sq[1];
+                if constexpr (NS == 3) o[2 * SPLW] = sq[2];
             }
         }
     };
@@ -88,24 +96,24 @@ __global__ __launch_bounds__(256, P7S_OCC) void jp_igemm_p7s_kernel(const unsign
     // ---- weights: [step][split][k-half][64 rows] x 16 B
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(wp), 0, (STEPS + 1) * SBYTES, 0x00020000);
     const int avo = (lhi * 64 + l31) * 16;
-    jp_u32x4 ra[2][2][3];
+    jp_u32x4 ra[2][2][NS];
     auto aload = [&](int slot, int step) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NS; ++s)
                 ra[slot][i][s] = __builtin_amdgcn_raw_buffer_load_b128(wrs, avo + i * 512 + s * (2 * 64 * 16), step * SBYTES, 0);
     };
     // ---- B: step u = (channel c = u / 4, tap rows ky = 2*(u % 4) + lhi); LDS dword of that patch row for output row j of this wave:
     // (c*PRW + 2*(2wn + j) + ky) * PITCH + l31 -- one lane base, everything else compile-time
     const unsigned* bpl = patch + (4 * wn + lhi) * PITCH + l31;
-    jp_u32x4 rb[2][NJ][3];
+    jp_u32x4 rb[2][NJ][NS];
     auto bload = [&](int slot, int u) {
         const int d0 = ((u / 4) * PRW + 2 * (u % 4)) * PITCH;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 const unsigned* r = bpl + d0 + s * SPLW + (2 * j) * PITCH;
                 rb[slot][j][s] = jp_u32x4{r[0], r[1], r[2], r[3]};
             }
@@ -132,14 +140,8 @@ __global__ __launch_bounds__(256, P7S_OCC) void jp_igemm_p7s_kernel(const unsign
         __builtin_amdgcn_sched_barrier(0);
 #define JP_P7S_MFMA(SA_, SB_)                                                                                            \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)                         \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(jp_bf16x8, ra[u & 1][i][SA_]),            \
-                                                            __builtin_bit_cast(jp_bf16x8, rb[u & 1][j][SB_]), acc[i][j], 0, 0, 0)
-        JP_P7S_MFMA(2, 0);
-        JP_P7S_MFMA(1, 1);
-        JP_P7S_MFMA(0, 2);
-        JP_P7S_MFMA(1, 0);
-        JP_P7S_MFMA(0, 1);
-        JP_P7S_MFMA(0, 0);
+        acc[i][j] = jp_mfma_bf16_sw<false>(ra[u & 1][i][SA_], rb[u & 1][j][SB_], acc[i][j])
+        JP_SPLIT_PRODUCTS(JP_P7S_MFMA);
 #undef JP_P7S_MFMA
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, P7S_OCC) void jp_igemm_p7s_kernel(const unsign
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < M) epi.put(se, m, acc[i][j][r]);
+                if (m < M) epi.put(se, m, NS == 2 ? acc[i][j][r] * osc : acc[i][j][r]);
             }
         }
     }

@@ -22,7 +22,16 @@
 template <int KG>
 __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ ws, int Cout, int Cx, int Cm, int H, int W,
-                                                              int ntiles, int tiles_per_split, int dy_bytes, int x_bytes) {
+                                                              int ntiles, int tiles_per_split, int dy_bytes, int x_bytes,
+                                                              const float* __restrict__ gam, const float* __restrict__ xam) {
+    constexpr int NS = JP_NS;
+    float gsc = 1.f, xsc = 1.f, osc = 1.f;       // JP_NS == 2: operand scales, see jp_wgrad_w9s_kernel
+    if constexpr (NS == 2) {
+        const int kg_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(gam))), kx_ = __builtin_amdgcn_readfirstlane(jp_scale_exp(jp_slot_amax(xam)));
+        gsc = jp_exp2i(kg_);
+        xsc = jp_exp2i(kx_);
+        osc = jp_exp2i(-kg_) * jp_exp2i(-kx_);
+    }
     constexpr int NT = 512, TR = 2;
     constexpr int PRX = 2 * TR + 1, PCX = 65;      // patch rows / columns in input pixels
     constexpr int PRP = TR + 1, PCP = 34;          // rows / row pitch of one parity plane
@@ -32,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __re
     constexpr int KGR = TR * 2;                    // K groups (16 output pixels) per tile
     constexpr int MB = 8 / KG, KGW = KGR / KG;     // 32-channel output blocks per M tile; K groups per wave and tile
     static_assert(KG == 1 || KG == 2, "one or two K groups");
-    __shared__ __attribute__((aligned(16))) unsigned char patch[3 * SPL];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NS * SPL];
 
     const int OH = H >> 1, OW = W >> 1;
     const int t = threadIdx.x, lane = t & 63;
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __re
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
             bbase[txs][rd] = (kg * (KGW / 2) * PCP + 8 * lhi + rr) * 64 + ((Qq ^ ((txs + 4 * rd + rr) & 7)) * 8);
-    auto bread = [&](int ty, int tx, int g, int s) -> jp_bf16x8 {
+    auto bread = [&](int ty, int tx, int g, int s) -> jp_u32x4 {
         const int plane = (ty & 1) * 2 + (tx & 1);
         const int imm = s * SPL + (plane * PSL + (g / 2 + (ty >> 1)) * PCP + 16 * (g % 2) + (tx >> 1)) * 64;
         const jp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __re
         const jp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (jp_s16x4 __attribute__((address_space(3)))*)(patch + bbase[tx >> 1][1] + imm + 256));
         const jp_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(jp_bf16x8, v);
+        return __builtin_bit_cast(jp_u32x4, v);
     };
 
     // ---- staging: item e = t + NT*q -> (patch column, patch row, channel quad); lanes run along the patch columns (a wave's
@@ -136,13 +145,13 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __re
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (ilds[q] < 0) continue;
-            unsigned a0, a1, a2, b0, b1, b2;
-            jp_split3(rv[q][0], rv[q][1], a0, a1, a2);
-            jp_split3(rv[q][2], rv[q][3], b0, b1, b2);
+            unsigned a[3], b[3];
+            jp_split_ns(rv[q][0], rv[q][1], xsc, a);
+            jp_split_ns(rv[q][2], rv[q][3], xsc, b);
             typedef unsigned u2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u2*>(patch + ilds[q]) = u2{a0, b0};
-            *reinterpret_cast<u2*>(patch + SPL + ilds[q]) = u2{a1, b1};
-            *reinterpret_cast<u2*>(patch + 2 * SPL + ilds[q]) = u2{a2, b2};
+            *reinterpret_cast<u2*>(patch + ilds[q]) = u2{a[0], b[0]};
+            *reinterpret_cast<u2*>(patch + SPL + ilds[q]) = u2{a[1], b[1]};
+            if constexpr (NS == 3) *reinterpret_cast<u2*>(patch + 2 * SPL + ilds[q]) = u2{a[2], b[2]};
         }
     };
 
@@ -174,32 +183,26 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __re
                     const jp_u32x4 lo = araw[gi & 1][0], hi = araw[gi & 1][1];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        unsigned s0, s1, s2;
-                        jp_split3(__uint_as_float(lo[2 * k]), __uint_as_float(lo[2 * k + 1]), s0, s1, s2);
-                        sa[0][k] = s0; sa[1][k] = s1; sa[2][k] = s2;
-                        jp_split3(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), s0, s1, s2);
-                        sa[0][2 + k] = s0; sa[1][2 + k] = s1; sa[2][2 + k] = s2;
+                        unsigned sq[3];
+                        jp_split_ns(__uint_as_float(lo[2 * k]), __uint_as_float(lo[2 * k + 1]), gsc, sq);
+                        sa[0][k] = sq[0]; sa[1][k] = sq[1]; sa[2][k] = sq[2];
+                        jp_split_ns(__uint_as_float(hi[2 * k]), __uint_as_float(hi[2 * k + 1]), gsc, sq);
+                        sa[0][2 + k] = sq[0]; sa[1][2 + k] = sq[1]; sa[2][2 + k] = sq[2];
                     }
                 }
-                jp_bf16x8 bq[2][3];
+                jp_u32x4 bq[2][3];
 #pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_) bq[0][s_] = bread(0, 0, g, s_);
-                const jp_bf16x8 a0 = __builtin_bit_cast(jp_bf16x8, sa[0]), a1 = __builtin_bit_cast(jp_bf16x8, sa[1]),
-                                a2 = __builtin_bit_cast(jp_bf16x8, sa[2]);
+                for (int s_ = 0; s_ < NS; ++s_) bq[0][s_] = bread(0, 0, g, s_);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     if (tap + 1 < 9) {
 #pragma unroll
-                        for (int s_ = 0; s_ < 3; ++s_) bq[(tap + 1) & 1][s_] = bread((tap + 1) / 3, (tap + 1) % 3, g, s_);
+                        for (int s_ = 0; s_ < NS; ++s_) bq[(tap + 1) & 1][s_] = bread((tap + 1) / 3, (tap + 1) % 3, g, s_);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const jp_bf16x8 b0 = bq[tap & 1][0], b1 = bq[tap & 1][1], b2 = bq[tap & 1][2];
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tap], 0, 0, 0);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tap], 0, 0, 0);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tap], 0, 0, 0);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tap], 0, 0, 0);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tap], 0, 0, 0);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tap], 0, 0, 0);
+#define JP_W9S2_MFMA(SA_, SB_) acc[tap] = jp_mfma_bf16_sw<false>(sa[SA_], bq[tap & 1][SB_], acc[tap])
+                    JP_SPLIT_PRODUCTS(JP_W9S2_MFMA);
+#undef JP_W9S2_MFMA
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void jp_wgrad_w9s2_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < Cout) wz[(long)m * Np + n] = acc[tap][r];
+            if (m < Cout) wz[(long)m * Np + n] = NS == 2 ? acc[tap][r] * osc : acc[tap][r];
         }
     }
 }

@@ -16,7 +16,7 @@ GROUPS = [
      "(jp_conv2d_ws_floats) and whether it already holds this layer's pack (1) or must be packed by this call (0); packs recorded with "
      "jp_pack_record_begin/end can be refreshed for the whole model by one jp_pack_replay launch per step (job table in device memory; every job's `begin` is the running sum of the totals rounded up to a multiple of 4, "
      "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements).  "
-     "ARITHMETIC: fp32 in / out / accumulate.  The patch kernels (3x3, 1x1, iconv; JP_P9S / JP_W9S / JP_P9US / JP_P9SD / JP_P9S2, default on) "
+     "ARITHMETIC: fp32 in / out / accumulate.  The patch kernels (3x3, 1x1, 7x7 stem, iconv; JP_P9S / JP_W9S / JP_P9US / JP_P9SD / JP_P9S2 / JP_P7S, default on) "
      "form each fp32 product on the 16-bit matrix pipe.  Default build (JP_NS = 2, jp_split_scheme() == 2): 3 fp16 products a0 b0 + a0 b1 + a1 b0 "
      "of two-way fp16 splits of both operands, each operand TENSOR scaled by the power of two that puts its largest magnitude into "
      "[2^14, 2^15) (csrc/igemm_p9s.h:jp_split2h, csrc/scale.hip; magnitudes: the jp_amax* group below).  Operands are carried to 2^-23 "
