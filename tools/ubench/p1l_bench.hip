@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include "igemm_p1l.h"
+#if JP_NS != 3
+#error "the persistent 1x1 kernel reads the three-plane bf16 pack: build this harness with -DJP_NS=3"
+#endif
 struct FwdEpi {
     typedef size_t St;
     float* y; const float* bias; int Cout, OHW, act;
@@ -48,7 +51,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps; ++r) {
         float ms0, ms1;
         hipEventRecord(a);
-        hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, false, false, FwdEpi, 1, 2>), dim3(ntiles, M / 256, 1), dim3(512), 0, 0, wp, x, e0, M, C, NST, H, W, 0);
+        hipLaunchKernelGGL((jp_igemm_p9s_kernel<4, 2, 2, false, false, FwdEpi, 1, 2>), dim3(ntiles, M / 256, 1), dim3(512), 0, 0, wp, x, e0, M, C, NST, H, W, 0, (const float*)nullptr);   // (JP_NS == 3 build only: no operand scales)
         hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms0, a, b);
         hipEventRecord(a);
         hipLaunchKernelGGL((jp_conv1x1_p1l_kernel<FwdEpi>), dim3((ntiles + tpw - 1) / tpw, M / 256, 1), dim3(512), 0, 0, wp, x, e1, M, C, NST, H, W, ntiles, tpw, (int)(nx * 4));

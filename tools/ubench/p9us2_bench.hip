@@ -32,18 +32,21 @@ int main(int argc, char** argv) {
     const int N = 8, H = 256, W = 256, C0 = 256, C1 = 256, C2 = 1, M = 256, MT = M / 128;
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     const size_t n0 = (size_t)N * C0 * H * W, n1 = (size_t)N * C1 * (H / 2) * (W / 2), n2 = (size_t)N * C2 * H * W, ny = (size_t)N * M * H * W;
-    const size_t SB = 3 * 2 * 128 * 16;
+    const size_t SB = JP_NS * 2 * 128 * 16;
     const size_t wbytes = (size_t)MT * (C0 / 16) * 9 * SB + 4 * (size_t)MT * (C1 / 16) * 4 * SB + (size_t)MT * 9 * SB + SB;
     float *x0, *x1, *x2, *y, *bias; unsigned* wp;
     hipMalloc(&x0, n0 * 4); hipMalloc(&x1, n1 * 4); hipMalloc(&x2, n2 * 4); hipMalloc(&y, ny * 4); hipMalloc(&wp, wbytes); hipMalloc(&bias, M * 4);
     fill<<<4096, 256>>>((unsigned*)x0, n0, 1u, 1); fill<<<4096, 256>>>((unsigned*)x1, n1, 2u, 1); fill<<<4096, 256>>>((unsigned*)x2, n2, 3u, 1);
     fill<<<4096, 256>>>(wp, wbytes / 4, 4u, 0); fill<<<16, 256>>>((unsigned*)bias, M, 5u, 1);
     FwdEpi e{y, bias, M, H * W, 2};
+    float* am; hipMalloc(&am, JP_AMAX_SLOT * 4); hipMemset(am, 0, JP_AMAX_SLOT * 4);      // largest |x| of the sources (JP_NS == 2): the fill is in [-2, 2)
+    { const float two = 2.f; hipMemcpy(am, &two, 4, hipMemcpyHostToDevice); }
+    { const float hdr[4] = {1.f, 1.f, 0.f, 0.f}; hipMemcpy(wp, hdr, 16, hipMemcpyHostToDevice); }     // pack header {scale, 1 / scale} (JP_NS == 2)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const double flops = 6.0 * 2.0 * M * (double)N * H * W * (9.0 * C0 + 4.0 * C1 + 9.0 * 16);
+    const double flops = (JP_NS == 2 ? 3.0 : 6.0) * 2.0 * M * (double)N * H * W * (9.0 * C0 + 4.0 * C1 + 9.0 * 16);
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, 0, wp, x0, x1, x2, e, M, C0, C1, C2, H, W);
+        hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, 0, wp, x0, x1, x2, e, M, C0, C1, C2, H, W, am);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (r >= 2) printf("%s %.3f ms  %.0f TF executed\n", argv[0], ms, flops / ms / 1e9);
