@@ -389,9 +389,13 @@ __global__ __launch_bounds__(256) void pack_replay_kernel(const JpPackJob* __res
             }
             *reinterpret_cast<float4*>(j.wp + i) = v;
         } else {
+            // (split packs with a scale header -- PACK_SPLITUPD, PACK_SPLIT7: the header words belong to the pack_scale kernels, the
+            // elements count from behind it and are the splits of scale * w)
+            const int hdr = pack_hdr(j.mode);
+            const float sc = hdr ? pack_scale_of(j) : 1.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i + k < j.total) j.wp[i + k] = pack_elem(j.mode, j.w, i + k, j.p);
+                if (i + k >= hdr && i + k < j.total) j.wp[i + k] = pack_elem(j.mode, j.w, i + k - hdr, j.p, sc);
         }
     }
 }

@@ -14,7 +14,8 @@ from jperceiver_amd.apis import build_optimizer                                #
 from oracle import jp_oracle as J                                              # noqa: E402  (option dict only)
 
 
-@pytest.mark.parametrize("ty,HW,B", [("static", 256, 2), ("Argo_both", 512, 1)])
+# (the 1024^2 case: the iconv dgrad kernel of the upsampled segment -- its own headered pack, PACK_SPLITUPD -- only runs on maps that large)
+@pytest.mark.parametrize("ty,HW,B", [("static", 256, 2), ("Argo_both", 512, 1), ("static", 1024, 2)])
 def test_replayed_packs_equal_first_use_packs(ty, HW, B):
     FR = [0, -1, 1]
     opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type=ty,
