@@ -34,6 +34,7 @@ import ctypes
 import json
 import os
 import re
+import subprocess
 import sys
 import time
 
@@ -258,6 +259,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-exact-build", action="store_true",
+                    help="skip timing the -DJP_NS=3 build of the library (csrc/libjperceiver_hip_ns3.so: exact three-way bf16 splits, six products)")
+    ap.add_argument("--secondary-only", action="store_true",
+                    help="time only the labelled 1024(W)x320(H) secondary workload (for rocprofv3 passes over that shape) and print its block")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -288,6 +293,9 @@ def main():
 
     cfg = CONFIGS[args.config]
     B, HW, frames = (args.batch or cfg["B"]), args.hw, cfg["frames"]
+    if args.secondary_only:
+        print(json.dumps({"secondary": secondary_figure(dev, B, log, steps=args.steps, warmup=args.warmup)}), flush=True)
+        return
     optd = make_opt(B, HW, HW, frames, cfg["type"], cfg["split"], loss_sum=cfg["loss_sum"], **cfg.get("extra", {}))
     # more than one rank: only on request (--graph on: graph A | eager exchange | graph B, apis/trainer.py); `auto` calibrates per
     # process, and the ranks must not choose differently
@@ -327,6 +335,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (oracle) ...")
         cpu = cpu_baseline(HW, cfg)
+    exact = None
+    if rank == 0 and world == 1 and not args.no_exact_build and not os.environ.get("JP_LIB_PATH"):
+        exact = exact_build_figure(args, log)
     if rank == 0:
         line = {
             "metric": f"train images/sec (full train step, synthetic {len(frames)}-frame batches)", "value": round(value, 3),
@@ -342,13 +353,36 @@ def main():
                        "config_index": args.config, "global_batch": B * world,
                        "parallelism": f"dp{world}", "loss": float(out["log_vars"]["loss"]),
                        "step_graph": bool(use_graph), "step_graph_calibration": calib},
-            "roofline": roof, "cpu_baseline": cpu, "families": fam, "secondary": sec,
+            "roofline": roof, "cpu_baseline": cpu, "families": fam, "secondary": sec, "exact_build": exact,
         }
         if multi is not None:
             line["multi_gpu"] = multi
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def exact_build_figure(args, log, steps=5, warmup=2):
+    """The SAME workload on the -DJP_NS=3 build of the same tree (make ns3: every fp32 product of the patch kernels = 6 bf16 products
+    of exact three-way operand splits, no per-tensor operand scales -- the arithmetic of rounds 3-4), so that the driver's
+    record carries both arithmetics: `value` above is the default build's three fp16 products of power-of-two-scaled two-way splits
+    (DESIGN 4.6b).  Timed in a child process (the library is chosen at load time, JP_LIB_PATH)."""
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "jperceiver_amd", "csrc", "libjperceiver_hip_ns3.so")
+    if not os.path.exists(so):
+        return {"skipped": "csrc/libjperceiver_hip_ns3.so not built (make -C jperceiver_amd/csrc ns3)"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--config", str(args.config),
+           "--hw", str(args.hw), "--graph", args.graph, "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--no-exact-build"]
+    if args.batch:
+        cmd += ["--batch", str(args.batch)]
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ, JP_LIB_PATH=so), capture_output=True, text=True, timeout=600)
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        res = {"arithmetic": line["arithmetic"], "library": "csrc/libjperceiver_hip_ns3.so (-DJP_NS=3)", "value": line["value"],
+               "unit": "images/s", "ms_per_step": line["ms_per_step"], "steps": steps, "warmup": warmup, "loss": line["config"]["loss"]}
+        log(f"exact build (-DJP_NS=3): {res['value']} images/s ({res['ms_per_step']} ms/step)")
+        return res
+    except Exception as e:     # the headline must not depend on the second library
+        return {"error": repr(e)}
 
 
 def secondary_figure(dev, B, log, steps=6, warmup=2):

@@ -81,7 +81,7 @@ __device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { re
 __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* __restrict__ residual,
                                               float* __restrict__ y, float sc, float sh, size_t base, int HW, int relu,
                                               unsigned* __restrict__ amax = nullptr) {
-    float mx = 0.f;                      // largest |y| this thread wrote (jp_amax_out)
+    float mx = 0.f;                      // largest |y| this thread wrote (-> amax_y)
     if ((HW & 3) == 0) {
         const float4* x4 = reinterpret_cast<const float4*>(x + base);
         const float4* r4 = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
             if (r4) { const float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             y4[i] = v;
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            mx = fmaxf(fmaxf(mx, fmaxf(jp_fmag(v.x), jp_fmag(v.y))), fmaxf(jp_fmag(v.z), jp_fmag(v.w)));
         }
     } else {
         for (int i = blockIdx.x * TPB + threadIdx.x; i < HW; i += gridDim.x * TPB) {
@@ -100,7 +100,7 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
             if (residual) v += residual[base + i];
             if (relu) v = fmaxf(v, 0.f);
             y[base + i] = v;
-            mx = fmaxf(mx, fabsf(v));
+            mx = fmaxf(mx, jp_fmag(v));
         }
     }
     jp_block_amax_commit(mx, amax);
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C, int HW, double count,
                                                            int relu, int acc_param_grads, int S, unsigned* __restrict__ amax) {
-    float mx = 0.f;                      // largest |dx| this thread wrote (jp_amax_out)
+    float mx = 0.f;                      // largest |dx| this thread wrote (-> amax_dx)
     const int nc = blockIdx.y;
     const int c = nc % C;
     const float mu = mean[c], is = invstd[c], g = gamma[c];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             JP_BN_APP1(d.x, a.x, yy.x, o.x, r.x) JP_BN_APP1(d.y, a.y, yy.y, o.y, r.y)
             JP_BN_APP1(d.z, a.z, yy.z, o.z, r.z) JP_BN_APP1(d.w, a.w, yy.w, o.w, r.w)
             o4[i] = o;
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            mx = fmaxf(fmaxf(mx, fmaxf(jp_fmag(o.x), jp_fmag(o.y))), fmaxf(jp_fmag(o.z), jp_fmag(o.w)));
             if (r4) r4[i] = r;
         }
     } else {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             float o, r;
             JP_BN_APP1(dy[base + i], x[base + i], y[base + i], o, r)
             dx[base + i] = o;
-            mx = fmaxf(mx, fabsf(o));
+            mx = fmaxf(mx, jp_fmag(o));
             if (dres) dres[base + i] = r;
         }
     }
@@ -532,7 +532,8 @@ extern "C" long jp_bn_ws_doubles(int N, int C, int HW) {
 extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                                float* y, float* running_mean, float* running_var, float* save_mean,
                                float* save_invstd, double* ws, int N, int C, int HW, float momentum, float eps,
-                               int relu, int n_updates, void* stream) {
+                               int relu, int n_updates, float* amax_y, void* stream) {
+    // amax_y: optional magnitude slot (jp_amax_slot_floats floats, see the header); the apply kernel folds max |y| into it
     JP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn_train_fwd: bad dims");
     hipStream_t st = (hipStream_t)stream;
@@ -542,14 +543,14 @@ extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* 
     const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, ws, save_mean, save_invstd, running_mean,
                        running_var, gamma, beta, residual, y, C, HW, relu, (double)N * HW, momentum, eps, n_updates, N * CH,
-                       jp_take_amax_out());
+                       reinterpret_cast<unsigned*>(amax_y));
     JP_LAUNCH_CHECK();
 }
 
 extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, float* dx, float* dres,
                                float* dgamma, float* dbeta, double* ws, int N, int C, int HW, int relu,
-                               int acc_param_grads, void* stream) {
+                               int acc_param_grads, float* amax_dx, void* stream) {
     JP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
     // y == NULL with relu: legal only for layers WITHOUT a residual input (the mask is recomputed from x)
     hipStream_t st = (hipStream_t)stream;
@@ -559,7 +560,8 @@ extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, 
                        beta, ws, C, HW, CH, chunk, relu);
     const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, dy, x, y, save_mean, save_invstd, gamma,
-                       beta, ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH, jp_take_amax_out());
+                       beta, ws, dx, dres, dgamma, dbeta, C, HW, (double)N * HW, relu, acc_param_grads, N * CH,
+                       reinterpret_cast<unsigned*>(amax_dx));
     JP_LAUNCH_CHECK();
 }
 

@@ -8,7 +8,7 @@ extern "C" void jp_set_last_error(const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* jp_last_error_string(void) { return g_err; }
-extern "C" int jp_abi_version(void) { return 2; }
+extern "C" int jp_abi_version(void) { return 3; }
 
 // ---- per-kernel HIP-event timing of the implicit-GEMM launches (bench.py's roofline leg).
 // Off by default: the launch helpers of conv.hip call jp_prof_before/after, which return at once unless a profile is

@@ -622,7 +622,7 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     float* y;
     const float* bias;
     int Cout, OHW, act;
-    unsigned* amax = nullptr;           // != nullptr: the patch kernels report max |y| here (jp_amax_out)
+    unsigned* amax = nullptr;           // != nullptr: the patch kernels report max |y| here (the entry point's amax_y)
     __device__ __forceinline__ St col(int p) const {
         int img = p / OHW;
         return (size_t)img * Cout * OHW + (p - img * OHW);
@@ -641,7 +641,7 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
         const float b = bias ? bias[m] : 0.f;
         const float4 r = make_float4(jp_act(v.x + b, act), jp_act(v.y + b, act), jp_act(v.z + b, act), jp_act(v.w + b, act));
         *reinterpret_cast<float4*>(y + base + (size_t)m * OHW) = r;
-        return fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w)));
+        return fmaxf(fmaxf(jp_fmag(r.x), jp_fmag(r.y)), fmaxf(jp_fmag(r.z), jp_fmag(r.w)));
     }
     // four consecutive pixels of channel m (16-byte aligned: the patch kernels' tiles start at multiples of 32 pixels)
     __device__ __forceinline__ void put4(St base, int m, float4 v) const {
@@ -2310,12 +2310,12 @@ inline int jp_num_cus() {
     return n;
 }
 template <bool REFLECT, bool REV, class E, int TAPS>
-void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off, int bmt) {
+void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, const JpCall& st, int mt_off, int bmt) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const int NST = red / (16 * KGS);
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * H * W, st) : nullptr;
-    if constexpr (JP_NS == 2 && jp_has_amax<E>::value) e.amax = jp_take_amax_out();       // (every kernel below reports it)
+    if constexpr (JP_NS == 2 && jp_has_amax<E>::value) e.amax = jp_take_amax_out(st);       // (every kernel below reports it)
     if constexpr (TAPS == 1) {
         const long ntiles = (long)N * (H / 4) * (W / 32), xb = (long)N * red * H * W * 4;
         if (bmt == 256 && mt_off == 0 && p1l_enabled() && rows % 256 == 0 && red % 128 == 0 && H % 4 == 0 && W % 32 == 0 && xb < (1L << 31) &&
@@ -2378,7 +2378,7 @@ inline bool p1s2_ok(int rows, int red, int N, int OH, int OW) {
            (long)jp_cdiv(rows, p9_bmt(rows, 1, p9_ptiles(N, OH, OW))) * N * (OH / tr) * (OW / 32) >= 192;
 }
 template <class E>
-void launch_p1s2(const float* wp, const float* x, E e, int rows, int red, int N, int OH, int OW, hipStream_t st) {
+void launch_p1s2(const float* wp, const float* x, E e, int rows, int red, int N, int OH, int OW, const JpCall& st) {
     const int bmt = p9_bmt(rows, 1, p9_ptiles(N, OH, OW)), NST = red / 32;
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * (2L * OH) * (2L * OW), st) : nullptr;
@@ -2393,7 +2393,7 @@ void launch_p1s2(const float* wp, const float* x, E e, int rows, int red, int N,
     jp_prof_after(st);
 }
 template <bool REFLECT, bool REV, class E>
-void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st, int mt_off = 0,
+void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, const JpCall& st, int mt_off = 0,
                int bank_rows = -1) {
     const int NCH = jp_cdiv(red, 32);
     const int bmt = p9_bmt(bank_rows < 0 ? rows : bank_rows, 9, p9_ptiles(N, H, W));   // the M tile of the PACK (the bank's rows)
@@ -2414,7 +2414,7 @@ void launch_p9(const float* wp, const float* x, E e, int rows, int red, int N, i
 }
 // 1x1 stride-1 convolution / its dgrad through the same kernel (TAPS = 1, two channel chunks per stage)
 template <class E>
-void launch_p1(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st) {
+void launch_p1(const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, const JpCall& st) {
     const int NST = jp_cdiv(red, 64);
     const int bmt = p9_bmt(rows, 1, p9_ptiles(N, H, W));
     if (p9s_enabled()) { launch_p9s<false, false, E, 1>(wp, x, e, rows, red, N, H, W, st, 0, bmt); return; }
@@ -2510,7 +2510,7 @@ static inline bool w9s2_plan(int N, int Cm, int H, int W, int Cout, int KH, int 
 template <int KG>
 const char* w9s2_tag() { return __PRETTY_FUNCTION__; }
 static void launch_w9s2(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
-                        const W9S2Plan& p, hipStream_t st) {
+                        const W9S2Plan& p, const JpCall& st) {
     const int dyb = (int)((long)N * Cout * (H / 2) * (W / 2) * 4), xb = (int)((long)N * Cx * H * W * 4);
     const float* gam = JP_NS == 2 ? jp_amax_of(dy, (long)N * Cout * (H / 2) * (W / 2), st) : nullptr;
     const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * Cx * H * W, st) : nullptr;
@@ -2532,7 +2532,7 @@ template <int TR, bool REFLECT, int KG, int NCB = 2>
 const char* w9s_tag() { return __PRETTY_FUNCTION__; }
 template <bool REFLECT>
 static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx, int Cm, int H, int W, int Cout,
-                      const W9Plan& p, hipStream_t st) {
+                      const W9Plan& p, const JpCall& st) {
     if (p.split_mfma) {
         // executed FLOPs: 6 bf16 MFMA products per fp32 product
         const int dyb = (int)((long)N * Cout * H * W * 4);
@@ -2599,7 +2599,7 @@ template <int CIN>
 const char* w7_tag() { return __PRETTY_FUNCTION__; }
 template <int CIN>
 static void launch_w7(const float* dy, const float* x, float* dw, float* ws, int N, int H, int W, const W7Plan& p,
-                      hipStream_t st) {
+                      const JpCall& st) {
     jp_prof_before(w7_tag<CIN>(), 2.0 * 64 * 49.0 * CIN * (double)N * (H / 2) * (W / 2), st);
     hipLaunchKernelGGL((jp_wgrad_w7_kernel<CIN>), dim3(p.splits), dim3(640), 0, st, dy, x, ws, H, W, p.ntiles, p.tps,
                        (int)((long)N * 64 * (H / 2) * (W / 2) * 4));
@@ -2735,8 +2735,11 @@ extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
 extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
                                   const float* x2, int c2, int up2, const float* w, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int KH, int stride, int pad, int pad_mode, int act,
-                                  float* ws, int ws_state, float* split_ws, void* stream) {
+                                  float* ws, int ws_state, float* split_ws, const float* amax_x0, const float* amax_x1,
+                                  const float* amax_x2, float* amax_y, int* amax_y_done, float* amax_ws, void* stream) {
     // ws_state: 0 = pack the weights into ws now; 1 = ws already holds this layer's pack (refreshed by jp_pack_replay)
+    // amax_*: operand magnitudes of the fp16 split kernels, see the header (all may be NULL when amax_ws is given)
+    if (amax_y_done) *amax_y_done = 0;
     JP_CHECK_ARG(x0 && w && y, "conv2d_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && c0 > 0 && stride >= 1, "conv2d_fwd: bad dims");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && (pad >= H || pad >= W)), "conv2d_fwd: reflect pad >= size");
@@ -2744,7 +2747,17 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW;
     JP_CHECK_ARG(npix < (1L << 31) && (long)N * Cin * H * W < (1L << 31) * 2, "conv2d_fwd: tensor too large");
-    hipStream_t st = (hipStream_t)stream;
+    // (a multi-source call always needs the scratch: the kernel reads ONE magnitude, the largest of the sources', folded into amax_ws)
+    JP_CHECK_ARG(JP_NS != 2 || amax_ws || (amax_x0 && !c1 && !c2),
+                 "conv2d_fwd"": every operand magnitude (amax_*) or amax_ws (jp_conv2d_amax_ws_floats floats of scratch) must be given");
+    JpAmaxCtx ax;
+    ax.know(x0, amax_x0);
+    ax.know(x1, amax_x1);
+    ax.know(x2, amax_x2);
+    ax.ws = amax_ws;
+    ax.out = reinterpret_cast<unsigned*>(amax_y);
+    const JpAmaxDone done_flag{amax_y_done, &ax};
+    const JpCall st((hipStream_t)stream, &ax);
     FwdEpi e{y, bias, Cout, OH * OW, act};
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
         jp_up_head_fwd(x0, w, bias, y, N, c0, H / 2, W / 2, act, st);
@@ -2814,7 +2827,7 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
             // profiles/r04_p9us_*.log, r05_p9us2_*.log.)
             const float* xam = JP_NS == 2 ? jp_amax_of3(x0, (long)N * c0 * H * W, x1, (long)N * c1 * (H / 2) * (W / 2), x2,
                                                         c2 ? (long)N * c2 * H * W : 0L, st) : nullptr;
-            e.amax = jp_take_amax_out();
+            e.amax = jp_take_amax_out(st);
             jp_prof_before(p9us2_tag<FwdEpi>(), JP_NPROD * 2.0 * Cout * (double)npix * (9.0 * c0 + 4.0 * c1 + 9.0 * (c2 ? 16 : 0)), st);
             hipLaunchKernelGGL((jp_igemm_p9us2_kernel<FwdEpi>), dim3(N * (H / 4) * (W / 64), MT, 1), dim3(512), 0, st,
                                reinterpret_cast<const unsigned*>(ws), x0, x1, x2, e, Cout, c0, c1, c2, H, W, xam);
@@ -2985,9 +2998,10 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
 
 extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
                              int W, int Cout, int KH, int stride, int pad, int pad_mode, int act, float* ws,
-                             int ws_state, float* split_ws, void* stream) {
+                             int ws_state, float* split_ws, const float* amax_x, float* amax_y, int* amax_y_done, float* amax_ws,
+                             void* stream) {
     return jp_conv2d_fwd_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, w, bias, y, N, H, W, Cout, KH, stride, pad,
-                              pad_mode, act, ws, ws_state, split_ws, stream);
+                              pad_mode, act, ws, ws_state, split_ws, amax_x, nullptr, nullptr, amax_y, amax_y_done, amax_ws, stream);
 }
 
 // same for jp_conv2d_dgrad's `split_ws`
@@ -3025,7 +3039,7 @@ extern "C" long jp_conv2d_fwd_split_floats(int N, int Cin, int H, int W, int Cou
 // reflection border pass of a dgrad (rows of `a` = the C input channels of this call): through caller scratch when there is some
 // (K slices stored coalesced, one fixed-order fold into dx), else the read-modify-write epilogue
 static void border_pass(const PackA& a, const float* dy, float* dx, int C, int Cp, int Kp, int Cout, int N, int H, int W,
-                        float* split_ws, hipStream_t st) {
+                        float* split_ws, const JpCall& st) {
     const int Nb = N * (2 * W + 2 * H);
     DgradBorderB<3> bb{dy, Cp, Nb, H, W, Cout};
     const long btiles = (long)jp_cdiv(C, C <= 64 ? 64 : 128) * jp_cdiv(Nb, C <= 64 ? 256 : 128);
@@ -3050,14 +3064,18 @@ static void border_pass(const PackA& a, const float* dy, float* dx, int C, int C
 
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
                                int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, int ws_state,
-                               float* split_ws, void* stream) {
+                               float* split_ws, const float* amax_dy, float* amax_ws, void* stream) {
     JP_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && !(KH == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2)),
                  "conv2d_dgrad: reflect mode supports 3x3 stride 1 pad 1 only");
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * H * W;
     JP_CHECK_ARG(npix < (1L << 31), "conv2d_dgrad: tensor too large");
-    hipStream_t st = (hipStream_t)stream;
+    JP_CHECK_ARG(JP_NS != 2 || amax_ws || amax_dy, "conv2d_dgrad"": every operand magnitude (amax_*) or amax_ws (jp_conv2d_amax_ws_floats floats of scratch) must be given");
+    JpAmaxCtx ax;
+    ax.know(dy, amax_dy);
+    ax.ws = amax_ws;
+    const JpCall st((hipStream_t)stream, &ax);
     if (jp_c16_ok(Cin, Cout, KH, stride, pad, pad_mode, H, W)) {
         jp_c16_dgrad(dy, w, dx, 0, N, Cin, Cout, H, W, accumulate, st);
         JP_LAUNCH_CHECK();
@@ -3234,7 +3252,7 @@ extern "C" long jp_conv2d_dgrad_src3_split_floats(int c0, int up0, int c1, int u
 extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
                                     int c1, int up1, int acc1, float* dx2, int c2, int up2, int acc2, int N, int H, int W,
                                     int Cout, int KH, int stride, int pad, int pad_mode, float* ws, int ws_state,
-                                    float* split_ws, void* stream) {
+                                    float* split_ws, const float* amax_dy, float* amax_ws, void* stream) {
     // split_ws: optional scratch of jp_conv2d_dgrad_src3_split_floats floats for the border passes (NULL: read-modify-write epilogue)
     JP_CHECK_ARG(dy && w, "conv2d_dgrad_src3: null pointer");
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
@@ -3244,7 +3262,11 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
     JP_CHECK_ARG(ws != nullptr, "conv2d_dgrad_src3: null scratch");
     JP_CHECK_ARG(dgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode),
                  "conv2d_dgrad_src3: shape not supported (check jp_conv2d_dgrad_src3_ok)");
-    hipStream_t st = (hipStream_t)stream;
+    JP_CHECK_ARG(JP_NS != 2 || amax_ws || amax_dy, "conv2d_dgrad_src3"": every operand magnitude (amax_*) or amax_ws (jp_conv2d_amax_ws_floats floats of scratch) must be given");
+    JpAmaxCtx ax;
+    ax.know(dy, amax_dy);
+    ax.ws = amax_ws;
+    const JpCall st((hipStream_t)stream, &ax);
     const int Cin = c0 + c1 + c2, Cp = pad32(Cout), Kp = 9 * Cp;
     const long npix = (long)N * H * W;
     float* dxs[3] = {dx0, dx1, dx2};
@@ -3328,7 +3350,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
 // dw_ctot input channels.  Sub-range calls (dw_coff > 0 or fewer channels than dw_ctot) must be single-source.
 static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
                       const float* dy, float* dw, int N, int H, int W, int Cout, int KH, int stride, int pad,
-                      int pad_mode, float* ws, long ws_floats, hipStream_t st, int dw_ctot, int dw_coff) {
+                      int pad_mode, float* ws, long ws_floats, const JpCall& st, int dw_ctot, int dw_coff) {
     const int Cin = c0 + c1 + c2;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW;
@@ -3584,9 +3606,18 @@ static bool wgrad_segments_ok(int c0, int up0, int c1, int up1, int c2, int up2,
 extern "C" int jp_conv2d_wgrad_src3(const float* x0, int c0, int up0, const float* x1, int c1, int up1,
                                     const float* x2, int c2, int up2, const float* dy, float* dw, int N, int H, int W,
                                     int Cout, int KH, int stride, int pad, int pad_mode, int accumulate,
-                                    float* ws, long ws_floats, void* stream) {
+                                    float* ws, long ws_floats, const float* amax_x0, const float* amax_x1, const float* amax_x2,
+                                    const float* amax_dy, float* amax_ws, void* stream) {
     JP_CHECK_ARG(x0 && dy && dw, "conv2d_wgrad: null pointer");
-    hipStream_t st = (hipStream_t)stream;
+    JP_CHECK_ARG(JP_NS != 2 || amax_ws || (amax_dy && amax_x0 && (!c1 || amax_x1) && (!c2 || amax_x2)),
+                 "conv2d_wgrad"": every operand magnitude (amax_*) or amax_ws (jp_conv2d_amax_ws_floats floats of scratch) must be given");
+    JpAmaxCtx ax;
+    ax.know(x0, amax_x0);
+    ax.know(x1, amax_x1);
+    ax.know(x2, amax_x2);
+    ax.know(dy, amax_dy);
+    ax.ws = amax_ws;
+    const JpCall st((hipStream_t)stream, &ax);
     const int Cin = c0 + c1 + c2;
     if (!accumulate) JP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * KH * KH, st));
     if (ws && wgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode)) {
@@ -3667,9 +3698,9 @@ extern "C" long jp_conv2d_wgrad_src3_ws_floats(int c0, int up0, int c1, int up1,
 
 extern "C" int jp_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
                                int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, long ws_floats,
-                               void* stream) {
+                               const float* amax_x, const float* amax_dy, float* amax_ws, void* stream) {
     return jp_conv2d_wgrad_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, dy, dw, N, H, W, Cout, KH, stride, pad,
-                                pad_mode, accumulate, ws, ws_floats, stream);
+                                pad_mode, accumulate, ws, ws_floats, amax_x, nullptr, nullptr, amax_dy, amax_ws, stream);
 }
 
 // floats of optional caller scratch with which jp_conv2d_wgrad[_src3] merges its split-K partial tiles through a

@@ -55,7 +55,7 @@ template <int WM, int WN, bool REFLECT, bool REV, class E, int TAPS>
 const char* p9sm_tag() { return __PRETTY_FUNCTION__; }
 
 template <bool REFLECT, bool REV, class E, int TAPS>
-void launch(const JpP9smPlan& p, const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, hipStream_t st) {
+void launch(const JpP9smPlan& p, const float* wp, const float* x, E e, int rows, int red, int N, int H, int W, const JpCall& st) {
     constexpr int KGS = TAPS == 9 ? 1 : 2;
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     // executed FLOPs (6 bf16 products per fp32 product) of the tiles as launched, padding included
@@ -75,7 +75,7 @@ void launch(const JpP9smPlan& p, const float* wp, const float* x, E e, int rows,
 
 template <bool REFLECT, bool REV, int TAPS>
 void launch_epi(const JpP9smPlan& p, const float* wp, const float* x, float* out, const float* bias, int act, int accumulate,
-                float* part, int rows, int red, int N, int H, int W, hipStream_t st) {
+                float* part, int rows, int red, int N, int H, int W, const JpCall& st) {
     if (p.splits > 1) {
         SmSliceEpi e{part, rows, N * H * W, 0};
         launch<REFLECT, REV, SmSliceEpi, TAPS>(p, wp, x, e, rows, red, N, H, W, st);
@@ -117,7 +117,7 @@ bool jp_p9sm_plan(int rows, int red, int N, int H, int W, int khw, JpP9smPlan* p
 // forward (rev = 0: y = act(conv(x) + bias)) or dgrad main pass (rev = 1: taps mirrored, zero fill, dx (= or +=)); with
 // plan.splits > 1 the partial tiles go to `part` (plan.part_floats floats) and the CALLER folds them.
 void jp_p9sm_launch(const JpP9smPlan& p, const float* wp, const float* x, float* out, const float* bias, int act, int accumulate,
-                    float* part, int rows, int red, int N, int H, int W, int khw, int reflect, int rev, hipStream_t st) {
+                    float* part, int rows, int red, int N, int H, int W, int khw, int reflect, int rev, const JpCall& st) {
     if (khw == 1 && rev && p.splits == 1) {
         SmDgradEpi e{out, rows, H * W, accumulate, 0};
         launch<false, true, SmDgradEpi, 1>(p, wp, x, e, rows, red, N, H, W, st);

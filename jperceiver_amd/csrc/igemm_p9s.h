@@ -483,7 +483,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if constexpr (jp_has_amax<Epi>::value) { if (m < M) omx = fmaxf(omx, fabsf(epi.put_get(se, m, acc[i][j][r]))); }
+                if constexpr (jp_has_amax<Epi>::value) { if (m < M) omx = fmaxf(omx, jp_fmag(epi.put_get(se, m, acc[i][j][r]))); }
                 else { if (m < M) epi.put(se, m, acc[i][j][r]); }
             }
         }

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void jp_igemm_p9us2_kernel(const unsigned* 
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const float v = NS == 2 ? acc[i][j][r] * osc : acc[i][j][r];
-                if constexpr (jp_has_amax<Epi>::value) { if (m < M) omx = fmaxf(omx, fabsf(epi.put_get(se, m, v))); }
+                if constexpr (jp_has_amax<Epi>::value) { if (m < M) omx = fmaxf(omx, jp_fmag(epi.put_get(se, m, v))); }
                 else { if (m < M) epi.put(se, m, v); }
             }
         }

@@ -86,6 +86,12 @@ __host__ __device__ __forceinline__ unsigned jp_amag(unsigned bits) {
     const unsigned u = bits & 0x7fffffffu;
     return u >= (227u << 23) ? 0u : u;
 }
+// the same filter on a value, for producers that keep a running float maximum PER ELEMENT (a lane that filtered only its final maximum
+// would drop every ordinary value it saw together with one Inf): |v|, or 0 when v is NaN / Inf / >= 2^100
+__device__ __forceinline__ float jp_fmag(float v) {
+    const float a = fabsf(v);
+    return a < 0x1p100f ? a : 0.f;
+}
 // A magnitude SLOT is JP_AMAX_WAYS words, JP_AMAX_STRIDE words (one 64-byte line) apart: producers spread their atomicMax over the ways
 // (a million same-address device-scope atomics cost 11 ns each -- measured: they made bn_apply 18 x slower; a "skip if the slot already
 // holds as much" check needs a device-scope load per workgroup, which doubled the kernel's time), consumers take the maximum of the ways.
@@ -125,10 +131,6 @@ __device__ __forceinline__ void jp_block_amax_commit(float mx, unsigned* out) {
         if (m) atomicMax(out + jp_amax_way(), m);
     }
 }
-// The caller's request "write the largest magnitude of the tensor the NEXT supporting entry point produces to this slot"
-// (jp_amax_out, scale.hip): an entry point that fuses the reduction into its kernel takes it (-> nullptr if none is pending).
-unsigned* jp_take_amax_out();
-
 // reflect index for ReflectionPad (pad < n): -1 -> 1, n -> n-2
 __device__ __forceinline__ int jp_reflect(int i, int n) {
     if (i < 0) i = -i;

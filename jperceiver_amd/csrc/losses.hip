@@ -198,41 +198,72 @@ __global__ __launch_bounds__(TPB) void scale_fwd_kernel(const float* __restrict_
     }
 }
 
-// ddisp_s += scale*gout/count * d/d disp   (scatter through the 4 bilinear taps; fp32 atomics)
+// ddisp_s (+)= scale*gout/count * d/d disp, as a GATHER (round 6; the round-1 kernel scattered through the four bilinear taps with
+// fp32 atomics -- the first order-dependent sum of the backward, inherited by every depth gradient: profiles/r05_step_repro.log).
+// One thread per disparity pixel (ys, xs): the label pixels whose interpolation reads it are those whose bil_src() row is ys or ys - 1
+// (and likewise in x) -- a window found by inverting bil_src conservatively and then TESTED with bil_src itself, so forward and
+// backward agree on every tap; contributions are added in a fixed (y, x) order: bit-reproducible.
+__device__ __forceinline__ void bil_window(int r, float scale, int in, int out, int& lo, int& hi) {
+    // targets o with src(o) = (o + 0.5) * scale - 0.5 in (r - 1, r + 1), widened by one on both sides; the clamps of bil_src (src < 0 ->
+    // 0, i0 <= in - 1) only move taps towards the border rows, which the widened window of the border rows covers
+    lo = (int)floorf(((float)r - 0.5f) / scale - 0.5f) - 1;
+    hi = (int)ceilf(((float)r + 1.5f) / scale - 0.5f) + 1;
+    if (r == 0) lo = 0;
+    if (r >= in - 1) hi = out - 1;
+    lo = max(lo, 0);
+    hi = min(hi, out - 1);
+}
 __global__ __launch_bounds__(TPB) void scale_bwd_kernel(const float* __restrict__ disp, int hs, int ws,
                                                         const float* __restrict__ label,
                                                         const double* __restrict__ acc,
                                                         const float* __restrict__ gout, float scale,
                                                         float* __restrict__ ddisp, int FH, int FW, float min_disp,
-                                                        float max_disp, int y_lo, int y_hi, int x_lo, int x_hi) {
+                                                        float max_disp, int y_lo, int y_hi, int x_lo, int x_hi, int accumulate) {
     const int b = blockIdx.y;
     const float* d = disp + (size_t)b * hs * ws;
     float* dd = ddisp + (size_t)b * hs * ws;
     const float* lb = label + (size_t)b * FH * FW;
     const float sy = (float)hs / (float)FH, sx = (float)ws / (float)FW;
     const float cnt = (float)acc[1];
-    if (!(cnt > 0.f)) return;
-    const float go = scale * (gout ? gout[0] : 1.f) / cnt;
+    const float go = cnt > 0.f ? scale * (gout ? gout[0] : 1.f) / cnt : 0.f;
     const float rng = max_disp - min_disp;
-    for (int p = blockIdx.x * TPB + threadIdx.x; p < FH * FW; p += gridDim.x * TPB) {
-        const float gt = lb[p];
-        const int y = p / FW, x = p - y * FW;
-        if (!(gt > 0.f) || y < y_lo || y >= y_hi || x < x_lo || x >= x_hi) continue;
-        int y0, y1, x0, x1;
-        float wy, wx;
-        bil_src(y, sy, hs, y0, y1, wy);
-        bil_src(x, sx, ws, x0, x1, wx);
-        const float a = 1.f / (min_disp + rng * d[y0 * ws + x0]);
-        const float bq = 1.f / (min_disp + rng * d[y0 * ws + x1]);
-        const float c = 1.f / (min_disp + rng * d[y1 * ws + x0]);
-        const float e = 1.f / (min_disp + rng * d[y1 * ws + x1]);
-        const float pr = (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * c + wx * e);
-        if (!(pr >= 1e-3f && pr <= 80.f)) continue;            // clamp passes no gradient outside
-        const float gp = go * sgn(pr - gt) / gt;
-        atomicAdd(&dd[y0 * ws + x0], gp * (1.f - wy) * (1.f - wx) * (-rng * a * a));
-        atomicAdd(&dd[y0 * ws + x1], gp * (1.f - wy) * wx * (-rng * bq * bq));
-        atomicAdd(&dd[y1 * ws + x0], gp * wy * (1.f - wx) * (-rng * c * c));
-        atomicAdd(&dd[y1 * ws + x1], gp * wy * wx * (-rng * e * e));
+    for (int q = blockIdx.x * TPB + threadIdx.x; q < hs * ws; q += gridDim.x * TPB) {
+        const int ys = q / ws, xs = q - ys * ws;
+        float sum = 0.f;
+        if (cnt > 0.f) {
+            const float dq = 1.f / (min_disp + rng * d[q]);
+            const float dpr = -rng * dq * dq;                 // d (1 / disp-to-depth) / d disp at this pixel
+            int ty0, ty1, tx0, tx1;
+            bil_window(ys, sy, hs, FH, ty0, ty1);
+            bil_window(xs, sx, ws, FW, tx0, tx1);
+            ty0 = max(ty0, y_lo); ty1 = min(ty1, y_hi - 1);
+            tx0 = max(tx0, x_lo); tx1 = min(tx1, x_hi - 1);
+            for (int y = ty0; y <= ty1; ++y) {
+                int y0, y1;
+                float wy;
+                bil_src(y, sy, hs, y0, y1, wy);
+                // weight of source row ys in target row y (y0 == y1 at the last row: both taps land on it)
+                const float wrow = (y0 == ys ? 1.f - wy : 0.f) + (y1 == ys ? wy : 0.f);
+                if (y0 != ys && y1 != ys) continue;
+                for (int x = tx0; x <= tx1; ++x) {
+                    int x0, x1;
+                    float wx;
+                    bil_src(x, sx, ws, x0, x1, wx);
+                    if (x0 != xs && x1 != xs) continue;
+                    const float gt = lb[(size_t)y * FW + x];
+                    if (!(gt > 0.f)) continue;
+                    const float a = 1.f / (min_disp + rng * d[y0 * ws + x0]);
+                    const float bq = 1.f / (min_disp + rng * d[y0 * ws + x1]);
+                    const float c = 1.f / (min_disp + rng * d[y1 * ws + x0]);
+                    const float e = 1.f / (min_disp + rng * d[y1 * ws + x1]);
+                    const float pr = (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * c + wx * e);
+                    if (!(pr >= 1e-3f && pr <= 80.f)) continue;            // clamp passes no gradient outside
+                    const float wcol = (x0 == xs ? 1.f - wx : 0.f) + (x1 == xs ? wx : 0.f);
+                    sum += go * sgn(pr - gt) / gt * wrow * wcol * dpr;
+                }
+            }
+        }
+        dd[q] = accumulate ? dd[q] + sum : sum;
     }
 }
 
@@ -534,10 +565,9 @@ extern "C" int jp_scale_loss_bwd(const float* disp, int hs, int ws, const float*
                                  int accumulate, void* stream) {
     JP_CHECK_ARG(disp && label && acc && ddisp && B > 0, "scale_loss_bwd: bad args");
     JP_ST;
-    if (!accumulate) JP_HIP(hipMemsetAsync(ddisp, 0, sizeof(float) * (size_t)B * hs * ws, st));
-    hipLaunchKernelGGL(scale_bwd_kernel, dim3(std::min(jp_cdiv((long)FH * FW, TPB), 2048), B), dim3(TPB), 0, st, disp, hs,
+    hipLaunchKernelGGL(scale_bwd_kernel, dim3(std::min(jp_cdiv((long)hs * ws, TPB), 2048), B), dim3(TPB), 0, st, disp, hs,
                        ws, label, acc, gout, scale, ddisp, FH, FW, 1.f / max_depth, 1.f / min_depth, y_lo, y_hi, x_lo,
-                       x_hi);
+                       x_hi, accumulate);
     JP_LAUNCH_CHECK();
 }
 

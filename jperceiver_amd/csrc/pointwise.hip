@@ -301,8 +301,9 @@ __global__ __launch_bounds__(TPB) void maxpool5_rows_fwd_kernel(const float* __r
 template <int L>
 __global__ __launch_bounds__(TPB) void maxpool5_rows_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                                 float* __restrict__ dx, const float* __restrict__ addend,
-                                                                int NC, int H, int RB, int bands) {
+                                                                int NC, int H, int RB, int bands, unsigned* __restrict__ amax) {
     constexpr int G = 64 / L, W = 4 * L;
+    float mx = 0.f;                                       // largest stored magnitude (the next dgrad's operand scale)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / L, lir = lane % L;
     const long unit = ((long)blockIdx.x * 4 + wave) * G + grp;
@@ -374,8 +375,10 @@ __global__ __launch_bounds__(TPB) void maxpool5_rows_bwd_kernel(const float* __r
             }
             if (ap) { const float4 a = ap[(long)r * L]; o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
             op[(long)r * L] = make_float4(o[0], o[1], o[2], o[3]);
+            mx = fmaxf(fmaxf(mx, fmaxf(jp_fmag(o[0]), jp_fmag(o[1]))), fmaxf(jp_fmag(o[2]), jp_fmag(o[3])));
         }
     }
+    jp_wave_amax_commit(mx, amax);
 }
 
 // ------------------------------------------------------------------ 3x3 stride-2 pad-1 max pool backward (the ResNet stem)
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(TPB) void maxpool3s2_bwd_kernel(const float* __rest
 
 template <int L>
 static void launch_pool5_rows(bool fwd, const float* a, float* out, uint8_t* idx, const uint8_t* cidx, const float* addend,
-                              int NC, int H, hipStream_t st) {
+                              int NC, int H, hipStream_t st, unsigned* amax) {
     // band height: enough (plane, band) units for >= ~16 waves per CU (a wave has one row load in flight) -- 4 halo rows per band
     const int G = 64 / L;
     int RB = H <= 64 ? H : 64;
@@ -452,18 +455,18 @@ static void launch_pool5_rows(bool fwd, const float* a, float* out, uint8_t* idx
     const long units = (long)NC * bands;
     const dim3 grid((unsigned)jp_cdiv(units, 4L * G));
     if (fwd) hipLaunchKernelGGL((maxpool5_rows_fwd_kernel<L>), grid, dim3(TPB), 0, st, a, out, idx, NC, H, RB, bands);
-    else hipLaunchKernelGGL((maxpool5_rows_bwd_kernel<L>), grid, dim3(TPB), 0, st, a, cidx, out, addend, NC, H, RB, bands);
+    else hipLaunchKernelGGL((maxpool5_rows_bwd_kernel<L>), grid, dim3(TPB), 0, st, a, cidx, out, addend, NC, H, RB, bands, amax);
 }
 static bool pool5_rows_ok(int k, int s, int p, int W) {
     return k == 5 && s == 1 && p == 2 && (W == 32 || W == 64 || W == 128 || W == 256);
 }
 static void pool5_rows(bool fwd, const float* a, float* out, uint8_t* idx, const uint8_t* cidx, const float* addend, int NC,
-                       int H, int W, hipStream_t st) {
+                       int H, int W, hipStream_t st, unsigned* amax = nullptr) {
     switch (W) {
-        case 32: launch_pool5_rows<8>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
-        case 64: launch_pool5_rows<16>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
-        case 128: launch_pool5_rows<32>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
-        default: launch_pool5_rows<64>(fwd, a, out, idx, cidx, addend, NC, H, st); break;
+        case 32: launch_pool5_rows<8>(fwd, a, out, idx, cidx, addend, NC, H, st, amax); break;
+        case 64: launch_pool5_rows<16>(fwd, a, out, idx, cidx, addend, NC, H, st, amax); break;
+        case 128: launch_pool5_rows<32>(fwd, a, out, idx, cidx, addend, NC, H, st, amax); break;
+        default: launch_pool5_rows<64>(fwd, a, out, idx, cidx, addend, NC, H, st, amax); break;
     }
 }
 
@@ -655,19 +658,19 @@ __device__ __forceinline__ float act_bwd1(float d, float v, int act) {
 }
 __global__ __launch_bounds__(TPB) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       float* __restrict__ dx, long n, int act, unsigned* __restrict__ amax) {
-    float mx = 0.f;                      // largest |dx| this thread wrote (jp_amax_out)
+    float mx = 0.f;                      // largest |dx| this thread wrote (-> amax_dx)
     ew_loop(n, al16(dy, y, dx),
             [&](long i) {
                 const float4 d = JP_F4(dy)[i], v = JP_F4(y)[i];
                 const float4 o = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act),
                                              act_bwd1(d.w, v.w, act));
                 JP_F4W(dx)[i] = o;
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                mx = fmaxf(fmaxf(mx, fmaxf(jp_fmag(o.x), jp_fmag(o.y))), fmaxf(jp_fmag(o.z), jp_fmag(o.w)));
             },
             [&](long i) {
                 const float o = act_bwd1(dy[i], y[i], act);
                 dx[i] = o;
-                mx = fmaxf(mx, fabsf(o));
+                mx = fmaxf(mx, jp_fmag(o));
             });
     jp_block_amax_commit(mx, amax);
 }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restri
             const float4 d = d4[i], v = y4[i];
             const float4 o = make_float4(act_bwd1(d.x, v.x, act), act_bwd1(d.y, v.y, act), act_bwd1(d.z, v.z, act), act_bwd1(d.w, v.w, act));
             o4[i] = o;
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            mx = fmaxf(fmaxf(mx, fmaxf(jp_fmag(o.x), jp_fmag(o.y))), fmaxf(jp_fmag(o.z), jp_fmag(o.w)));
             fs += (o.x + o.y) + (o.z + o.w);
             if (++run == 8) { s += fs; fs = 0.f; run = 0; }
         }
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restri
         for (int i = beg + threadIdx.x; i < end; i += TPB) {
             const float o = act_bwd1(dy[base + i], y[base + i], act);
             dx[base + i] = o;
-            mx = fmaxf(mx, fabsf(o));
+            mx = fmaxf(mx, jp_fmag(o));
             fs += o;
             if (++run == 32) { s += fs; fs = 0.f; run = 0; }
         }
@@ -1070,31 +1073,33 @@ extern "C" int jp_maxpool_fwd(const float* x, float* y, uint8_t* idx, int NC, in
 
 // dx = (addend ? addend : 0) + scatter of dy through the saved argmax; `addend` (may be NULL, may not alias dx) lets a
 // residual branch's gradient be folded in without a separate accumulation pass (CRP chains, layers.py:193-198)
+extern "C" int jp_amax_into(const float* x, long n, float* out, void* stream);
+// amax_dx: optional magnitude slot (see the header) that receives max |dx| -- folded in by the 5x5 row kernel itself, by a reduction
+// pass behind the other kernels
 extern "C" int jp_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, const float* addend, int NC, int H,
-                              int W, int k, int s, int p, void* stream) {
+                              int W, int k, int s, int p, float* amax_dx, void* stream) {
     JP_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 65535 && k >= 1 && k <= 7 && s >= 1 && s <= 2, "maxpool_bwd: bad args");
     JP_ST;
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
     if (pool5_rows_ok(k, s, p, W)) {
-        pool5_rows(false, dy, dx, nullptr, idx, addend, NC, H, W, st);
+        pool5_rows(false, dy, dx, nullptr, idx, addend, NC, H, W, st, reinterpret_cast<unsigned*>(amax_dx));
         JP_LAUNCH_CHECK();
     }
     if (k == 5 && s == 1) {
         hipLaunchKernelGGL((maxpool_bwd_s1_kernel<5>), dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MPF_TH), NC), dim3(TPB), 0, st,
                            dy, idx, dx, addend, H, W, OH, OW, p);
-        JP_LAUNCH_CHECK();
-    }
-    if (k == 3 && s == 2 && p == 1 && H == 2 * OH && W == 2 * OW && OW % 2 == 0) {
+    } else if (k == 3 && s == 2 && p == 1 && H == 2 * OH && W == 2 * OW && OW % 2 == 0) {
         const int RB = OH >= 128 ? 32 : 8, bands = jp_cdiv(OH, RB);
         const long units = (long)NC * bands * (OW / 2);
         hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)jp_cdiv(units, (long)TPB)), dim3(TPB), 0, st, dy, idx, dx, addend,
                            units, OH, OW, RB, bands);
-        JP_LAUNCH_CHECK();
+    } else {
+        // outputs that can cover a 64x8 input tile
+        const int pw = (MP_TW + k - 2) / s + 2, ph = (MP_TH + k - 2) / s + 2;
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MP_TH), NC), dim3(TPB),
+                           2 * sizeof(float) * pw * ph, st, dy, idx, dx, addend, H, W, OH, OW, k, s, p, pw, ph);
     }
-    // outputs that can cover a 64x8 input tile
-    const int pw = (MP_TW + k - 2) / s + 2, ph = (MP_TH + k - 2) / s + 2;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(jp_cdiv(W, MP_TW), jp_cdiv(H, MP_TH), NC), dim3(TPB),
-                       2 * sizeof(float) * pw * ph, st, dy, idx, dx, addend, H, W, OH, OW, k, s, p, pw, ph);
+    if (amax_dx) return jp_amax_into(dx, (long)NC * H * W, amax_dx, stream);
     JP_LAUNCH_CHECK();
 }
 
@@ -1179,16 +1184,16 @@ extern "C" int jp_act_fwd(const float* x, float* y, long n, int act, void* strea
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, int act, void* stream) {
+extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float* amax_dx, void* stream) {
     JP_CHECK_ARG(dy && y && dx && n > 0, "act_bwd: bad args");
     JP_ST;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, dy, y, dx, n, act, jp_take_amax_out());
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, dy, y, dx, n, act, reinterpret_cast<unsigned*>(amax_dx));
     JP_LAUNCH_CHECK();
 }
 
 // dx = dy * act'(y) and dbias[c] += sum over (n, hw) of dx, one pass (dbias is accumulated into: zero it for a fresh gradient)
 extern "C" int jp_act_bwd_bias(const float* dy, const float* y, float* dx, float* dbias, int N, int C, int HW, int act,
-                               void* stream) {
+                               float* amax_dx, void* stream) {
     JP_CHECK_ARG(dy && y && dx && dbias && N > 0 && C > 0 && HW > 0 && C <= 65535, "act_bwd_bias: bad args");
     JP_ST;
     int ch = std::max(1, 2048 / std::max(1, N * C));
@@ -1197,7 +1202,8 @@ extern "C" int jp_act_bwd_bias(const float* dy, const float* y, float* dx, float
     chunk = (chunk + 3) & ~3;                       // chunks start on 16-byte boundaries when HW allows vector accesses
     const int CH = (HW + chunk - 1) / chunk;
     JP_CHECK_ARG((long)N * CH <= 65535, "act_bwd_bias: too many chunks");
-    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, y, dx, dbias, C, HW, CH, chunk, act, jp_take_amax_out());
+    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, y, dx, dbias, C, HW, CH, chunk, act,
+                       reinterpret_cast<unsigned*>(amax_dx));
     JP_LAUNCH_CHECK();
 }
 

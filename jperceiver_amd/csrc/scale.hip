@@ -1,7 +1,6 @@
 // Largest-magnitude reductions for the operand scales of the fp16 split kernels (scale.h).
 #include "scale.h"
 #include "igemm_p9s.h"
-#include <atomic>
 #include <cstdint>
 
 namespace {
@@ -47,65 +46,61 @@ int launch_amax(const float* x, long n, float* out, hipStream_t st, bool zero) {
     return JP_OK;
 }
 
-// slots of library-launched reductions: a ring per device, one slot per call.  A slot is reused RING calls later -- several training
-// steps of launches; the host cannot run that far ahead of the device (the step reads its loss back), and a captured graph owns the
-// slots it was captured with for as long as launches outside it number fewer than RING between two replays of the same node.
-constexpr int RING = 1 << 12, MAXDEV = 16;      // slots of JP_AMAX_SLOT floats (8 MB per device)
-float* g_ring[MAXDEV] = {};
-std::atomic<unsigned> g_next{0};
-float* next_slot() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
-    if (!g_ring[dev]) {
-        float* p = nullptr;
-        if (hipMalloc(&p, (size_t)RING * JP_AMAX_SLOT * sizeof(float)) != hipSuccess) return nullptr;
-        g_ring[dev] = p;
-    }
-    return g_ring[dev] + (size_t)(g_next.fetch_add(1) % RING) * JP_AMAX_SLOT;
+// max of up to three slots into `dst` (way by way): the iconv kernels read ONE magnitude for their three channel segments
+__global__ __launch_bounds__(64) void amax_fold_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ s0,
+                                                       const unsigned* __restrict__ s1, const unsigned* __restrict__ s2, int keep) {
+    const int i = threadIdx.x;
+    if (i >= JP_AMAX_WAYS) return;
+    unsigned m = keep ? dst[i * JP_AMAX_STRIDE] : 0u;
+    if (s0) m = max(m, s0[i * JP_AMAX_STRIDE]);
+    if (s1) m = max(m, s1[i * JP_AMAX_STRIDE]);
+    if (s2) m = max(m, s2[i * JP_AMAX_STRIDE]);
+    dst[i * JP_AMAX_STRIDE] = m;
 }
 
-thread_local unsigned* g_amax_out = nullptr;       // jp_amax_out: pending request; taken by the next supporting entry point
-thread_local int g_amax_out_done = 0;
-struct Hint { const float* t; const float* a; };
-constexpr int MAXH = 8;
-thread_local Hint g_hint[MAXH];
-thread_local int g_nh = 0;
-const float* find_hint(const float* x) {
-    for (int i = 0; i < g_nh; ++i)
-        if (g_hint[i].t == x) return g_hint[i].a;
-    return nullptr;
+float* next_ws_slot(const JpCall& c) {
+    if (!c.ax || !c.ax->ws || c.ax->ws_used >= JP_AMAX_WS_SLOTS) {
+        jp_set_last_error("conv: an operand's magnitude was not passed (amax_x / amax_dy) and amax_ws is NULL or used up -- pass "
+                          "jp_conv2d_amax_ws_floats() floats of scratch");
+        return nullptr;
+    }
+    return c.ax->ws + (size_t)(c.ax->ws_used++) * JP_AMAX_SLOT;
 }
 }  // namespace
 
-unsigned* jp_take_amax_out() {
-    unsigned* p = g_amax_out;
-    if (p) { g_amax_out = nullptr; g_amax_out_done = 1; }
-    return p;
-}
-
-const float* jp_amax_of(const float* x, long n, hipStream_t st) {
-    if (const float* h = find_hint(x)) return h;
-    float* s = next_slot();
-    if (!s) { jp_set_last_error("amax: no device slot"); return nullptr; }
-    if (launch_amax(x, n, s, st, true) != JP_OK) return nullptr;
+const float* jp_amax_of(const float* x, long n, const JpCall& c) {
+    if (c.ax)
+        if (const float* h = c.ax->find(x)) return h;
+    float* s = next_ws_slot(c);
+    if (!s) return nullptr;
+    if (launch_amax(x, n, s, c.st, true) != JP_OK) return nullptr;
+    c.ax->know(x, s);                   // (the weight-gradient entry points ask for dY once per source segment)
     return s;
 }
-const float* jp_amax_of3(const float* x0, long n0, const float* x1, long n1, const float* x2, long n2, hipStream_t st) {
+const float* jp_amax_of3(const float* x0, long n0, const float* x1, long n1, const float* x2, long n2, const JpCall& c) {
     const float* xs[3] = {x0, x1, x2};
     const long ns[3] = {n0, n1, n2};
-    int live = 0, last = -1;
+    const float* known[3] = {nullptr, nullptr, nullptr};
+    int live = 0, last = -1, nknown = 0;
     for (int i = 0; i < 3; ++i)
-        if (xs[i] && ns[i] > 0) { ++live; last = i; }
-    if (live == 1) return jp_amax_of(xs[last], ns[last], st);
-    float* s = next_slot();
-    if (!s) { jp_set_last_error("amax: no device slot"); return nullptr; }
-    bool zero = true;
+        if (xs[i] && ns[i] > 0) {
+            ++live;
+            last = i;
+            if (c.ax && (known[i] = c.ax->find(xs[i]))) ++nknown;
+        }
+    if (live == 1) return jp_amax_of(xs[last], ns[last], c);
+    float* s = next_ws_slot(c);
+    if (!s) return nullptr;
+    bool zero = true;                   // segments without a slot of their own are reduced into s, the known ones folded in behind them
     for (int i = 0; i < 3; ++i) {
-        if (!xs[i] || ns[i] <= 0) continue;
-        if (launch_amax(xs[i], ns[i], s, st, zero) != JP_OK) return nullptr;      // (a hinted segment is simply reduced again: rare, small)
+        if (!xs[i] || ns[i] <= 0 || known[i]) continue;
+        if (launch_amax(xs[i], ns[i], s, c.st, zero) != JP_OK) return nullptr;
         zero = false;
     }
-    if (zero && launch_amax(nullptr, 0, s, st, true) != JP_OK) return nullptr;
+    if (nknown || zero)
+        hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(64), 0, c.st, reinterpret_cast<unsigned*>(s),
+                           reinterpret_cast<const unsigned*>(known[0]), reinterpret_cast<const unsigned*>(known[1]),
+                           reinterpret_cast<const unsigned*>(known[2]), zero ? 0 : 1);
     return s;
 }
 
@@ -125,29 +120,4 @@ extern "C" int jp_amax_into(const float* x, long n, float* out, void* stream) {
     if (rc != JP_OK) return rc;
     JP_LAUNCH_CHECK();
 }
-// "the next entry point that can, folds max |what it writes| into *slot" (max with what the slot holds: pre-zeroed by the caller).
-// Supporting entry points: jp_conv2d_fwd* when a patch kernel runs the layer (y), jp_bn_train_fwd (y), jp_bn_train_bwd (dx),
-// jp_act_bwd / jp_act_bwd_bias (dx).  jp_amax_out_done() -> 1 if the request was taken since jp_amax_out, and drops it otherwise:
-// call it right after the entry point the request was meant for.
-extern "C" int jp_amax_out(float* slot) {
-    JP_CHECK_ARG(slot, "amax_out: null pointer");
-    g_amax_out = reinterpret_cast<unsigned*>(slot);
-    g_amax_out_done = 0;
-    return JP_OK;
-}
-extern "C" int jp_amax_out_done(void) {
-    const int d = g_amax_out_done;
-    g_amax_out = nullptr;
-    g_amax_out_done = 0;
-    return d;
-}
-extern "C" int jp_amax_hint(const float* tensor, const float* amax) {
-    JP_CHECK_ARG(tensor && amax, "amax_hint: null pointer");
-    JP_CHECK_ARG(g_nh < MAXH, "amax_hint: more than 8 hints pending (jp_amax_hint_clear after the call they are for)");
-    g_hint[g_nh++] = Hint{tensor, amax};
-    return JP_OK;
-}
-extern "C" int jp_amax_hint_clear(void) {
-    g_nh = 0;
-    return JP_OK;
-}
+extern "C" int jp_conv2d_amax_ws_floats(void) { return JP_AMAX_WS_SLOTS * JP_AMAX_SLOT; }

@@ -131,6 +131,7 @@ class CRPBlock(nn.Module):
             if out.g is None:
                 return
             G[0] = last.g = out.g
+            last.gamax = out.gamax        # (the same tensor: what its producer reported about it still holds)
             private.backward()
             G[0] = out.g = None
 

@@ -396,47 +396,36 @@ def _slot_floats() -> int:
     return _SLOT_FLOATS[0]
 
 
-class _amax_hints:
-    """with _amax_hints((tensor, amax), ...): the conv entry points called inside read the operands' largest magnitudes from
-    `amax` instead of reducing them again (jp_amax_hint; pairs with amax None are skipped)."""
-
-    def __init__(self, *pairs):
-        self.pairs = [(t, a) for t, a in pairs if a is not None and t is not None]
-
-    def __enter__(self):
-        if self.pairs:
-            f = _jplib().fn["jp_amax_hint"]
-            for t, a in self.pairs:
-                if f(t.data_ptr(), a.data_ptr()) != 0:
-                    raise RuntimeError(_jplib().last_error())
-        return self
-
-    def __exit__(self, *exc):
-        if self.pairs:
-            _jplib().fn["jp_amax_hint_clear"]()
-        return False
+def _amax_ws(dev, *amaxes):
+    """Caller scratch for the magnitudes a conv entry point has to reduce itself (`amax_ws`): None when every operand's
+    magnitude is handed over (or the library has no operand scales), else jp_conv2d_amax_ws_floats floats."""
+    if split_scheme() != 2 or all(a is not None for a in amaxes):
+        return None
+    SF, n = _slot_floats(), _ws_slots()
+    st = torch.cuda.current_stream(dev)
+    key = ("ws", dev.index, st.cuda_stream, torch.cuda.is_current_stream_capturing())
+    ent = _AMAX_POOL.get(key)
+    if ent is None:
+        # one scratch per stream: the calls of a stream run in order, so the next call may overwrite what the last one reduced
+        ent = _AMAX_POOL[key] = [torch.empty(n * SF, device=dev, dtype=torch.float32), 0]
+    return ent[0]
 
 
-class _amax_out:
-    """with _amax_out(dev) as ao: <one entry point>  ->  ao.amax = device scalar max|tensor that entry point wrote| if its kernel
-    folded the reduction in (jp_amax_out), else None.  Several calls may share one request object (`again`): the slot takes the
-    maximum over all of them, and `amax` stays None unless every one of them reported."""
+_WS_SLOTS = []
 
-    def __init__(self, dev, on=True):
-        self.slot = _amax_slot(dev) if (on and split_scheme() == 2) else None
-        self.amax = None
-        self._ok = self.slot is not None
 
-    def __enter__(self):
-        if self.slot is not None:
-            _jplib().fn["jp_amax_out"](self.slot.data_ptr())
-        return self
+def _ws_slots() -> int:
+    if not _WS_SLOTS:
+        _WS_SLOTS.append(int(_jplib().fn["jp_conv2d_amax_ws_floats"]()) // _slot_floats())
+    return _WS_SLOTS[0]
 
-    def __exit__(self, *exc):
-        if self.slot is not None:
-            self._ok = bool(_jplib().fn["jp_amax_out_done"]()) and self._ok and exc[0] is None
-            self.amax = self.slot if self._ok else None
-        return False
+
+def _out_slot(dev, on=True):
+    """A zeroed slot for a producer's `amax_y` / `amax_dx` argument (None: the library has no operand scales / not wanted)."""
+    return _amax_slot(dev) if (on and split_scheme() == 2) else None
+
+
+import ctypes as _ct
 
 
 def _ws_floats(Cin, Cout, KH, which):
@@ -483,13 +472,18 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
     ws_s = _new((nsp,), w.t) if nsp else None      # fixed-order split-K reduction of small-grid layers
     sig = (tuple(s3[1::3]), tuple(s3[2::3]), N, H, W, stride, pad, pad_mode)
     big = Cin >= 32 and Cout >= 32            # (the few-channel layers run direct kernels without operand scales)
-    x_hints = [(v.t, _amax_of(v)) for v, _ in srcs] if big else []
-    with _amax_hints(*x_hints), _amax_out(y.device, big) as y_am:
-        _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
-                   (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act), (ws_s,))
+    # operand magnitudes of the fp16 split kernels (explicit arguments of the entry points, include/jperceiver_hip.h): one slot per
+    # source, reduced once per tensor (_amax_of) or reported by its producer; the few-channel layers leave it to the library
+    x_am = [(_amax_of(srcs[i][0]) if (big and i < len(srcs)) else None) for i in range(3)]
+    y_slot = _out_slot(y.device, big)
+    y_done = _ct.c_int(0)
+    _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
+               (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act),
+               (ws_s, *x_am, y_slot, _ct.addressof(y_done),
+                _amax_ws(y.device, *(x_am[:len(srcs)] if len(srcs) == 1 else (None,)))))     # (several sources: their slots are folded into the scratch)
     del ws_s
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
-    out.amax = y_am.amax          # max|y| from the kernel's epilogue when a patch kernel ran the layer: the next convolution's scale
+    out.amax = y_slot if y_done.value else None   # max|y| from the kernel's epilogue when a patch kernel ran the layer: the next convolution's scale
 
     def bwd():
         if out.g is None:
@@ -499,25 +493,25 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
         bias_done = False
         if act != ACT_NONE:
             d2 = torch.empty_like(dy)
-            with _amax_out(dy.device, big) as ao:
-                if b is not None and b.rg and Cout <= 65535:
-                    # activation backward and bias gradient in one pass (the bias gradient is a sum over the tensor this pass writes)
-                    call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act)
-                    bias_done = True
-                else:
-                    call("jp_act_bwd", dy, y, d2, dy.numel(), act)
-            dy, dy_am = d2, ao.amax
+            ao = _out_slot(dy.device, big)
+            if b is not None and b.rg and Cout <= 65535:
+                # activation backward and bias gradient in one pass (the bias gradient is a sum over the tensor this pass writes)
+                call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act, ao)
+                bias_done = True
+            else:
+                call("jp_act_bwd", dy, y, d2, dy.numel(), act, ao)
+            dy, dy_am = d2, ao
         # (reduced here, on the tape's stream, before the wgrad stream forks off it, unless its producer reported it)
-        dy_hint = (dy, dy_am if dy_am is not None else _amax_of(dy)) if big else (None, None)
+        if big and dy_am is None:
+            dy_am = _amax_of(dy)
+        elif not big:
+            dy_am = None
 
         def param_grads():
-            with _amax_hints(dy_hint, *x_hints):
-                _param_grads()
-
-        def _param_grads():
             if b is not None and b.rg and not bias_done:
                 call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
             if w.rg:
+                wg_am = (*x_am, dy_am, _amax_ws(dy.device, dy_am, *x_am[:len(srcs)]))
                 nms = 0
                 if len(srcs) > 1:
                     nms = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout,
@@ -527,13 +521,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 if up_head:     # disparity head on an upsampled source: upsample-aware direct kernel, nothing materialised
                     nup = 4 * N * H * W                     # 16 gathered dY sums per half-resolution pixel
                     ws_w = _new((nup,), dy)
-                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nup)
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nup, *wg_am)
                     del ws_w
                 elif nms:
                     # per-segment wgrad inside the library: full-resolution segments from their own tensors, the
                     # upsampled one in parity-class form -- no materialised concat
                     ws_w = _new((nms,), dy)
-                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nms)
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nms, *wg_am)
                     del ws_w
                 elif (len(srcs) > 1 or srcs[0][1]) and Cin >= 32:
                     # materialise the virtual upsample+concat once: the single-source wgrad gather is ~2x faster
@@ -548,8 +542,9 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                         c0 += C
                     nws = int(_jplib().fn["jp_conv2d_wgrad_ws_floats"](N, Cin, H, W, Cout, KH, stride, pad))
                     ws_w = _new((nws,), dy) if nws else None
+                    # (the concatenated copy's magnitude = the largest of its sources': the library folds the slots)
                     call("jp_conv2d_wgrad_src3", xc, Cin, 0, None, 0, 0, None, 0, 0, dy, w.g, N, H, W, Cout, KH, stride, pad,
-                         pad_mode, 1, ws_w, nws)
+                         pad_mode, 1, ws_w, nws, None, None, None, dy_am, _amax_ws(dy.device, None))
                     del xc, ws_w
                 else:
                     single = len(srcs) == 1 and not srcs[0][1]
@@ -559,7 +554,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                         nws = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W,
                                                                                  Cout, KH, stride, pad, pad_mode))
                     ws_w = _new((nws,), dy) if nws else None
-                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws)
+                    call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nws, *wg_am)
                     del ws_w
 
         # Parameter gradients are off the critical path (nothing in the backward chain reads them): they run on a
@@ -576,18 +571,18 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             dy.record_stream(wgs)
             for v, _ in srcs:
                 v.t.record_stream(wgs)
-            for _, a in (dy_hint, *x_hints):        # the operands' largest magnitudes are read on that stream too
+            for a in (dy_am, *x_am):                # the operands' largest magnitudes are read on that stream too
                 if a is not None:
                     a.record_stream(wgs)
         if any(v.rg for v, _ in srcs):
-          with _amax_hints(dy_hint):
+            dg_am = (dy_am, _amax_ws(dy.device, dy_am))
             nwd = _ws_floats(Cin, Cout, KH, 1) if Cout >= 16 else 0
             if len(srcs) == 1 and srcs[0][1] == 0:
                 g, acc = srcs[0][0].grad_buf()
                 nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
                 ws_s = _new((nsd,), dy) if nsd else None
                 _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
-                           (dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc), (ws_s,))
+                           (dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc), (ws_s, *dg_am))
                 del ws_s
             elif int(_jplib().fn["jp_conv2d_dgrad_src3_ok"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout, KH,
                                                            stride, pad, pad_mode)):
@@ -605,7 +600,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                                                                           N, H, W))
                 ws_s = _new((nsd,), dy) if nsd else None
                 _conv_call("jp_conv2d_dgrad_src3", w, "dgrad3", sig + rgs, nwd,
-                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode), (ws_s,))
+                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode), (ws_s, *dg_am))
                 del ws_s
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
@@ -614,7 +609,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
                 ws_s = _new((nsd,), dy) if nsd else None
                 _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
-                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (ws_s,))
+                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (ws_s, *dg_am))
                 del ws_s
                 c0 = 0
                 for v, u in srcs:
@@ -645,15 +640,14 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
     mean = _new((groups, C), x.t)
     invstd = _new((groups, C), x.t)
     nbw = int(_jplib().fn["jp_bn_ws_doubles"](Ng, C, H * W))
-    y_am = _amax_out(y.device, C >= 32)       # max|y| out of the apply kernel: the next convolution's operand scale
+    y_am = _out_slot(y.device, C >= 32)       # max|y| out of the apply kernel: the next convolution's operand scale
     for g in range(groups):
         sl = slice(g * Ng, (g + 1) * Ng)
         ws = _new((nbw,), x.t, torch.float64)
-        with y_am:
-            call("jp_bn_train_fwd", x.t[sl], gamma.t, beta.t, residual.t[sl] if residual is not None else None, y[sl], running_mean,
-                 running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates)
+        call("jp_bn_train_fwd", x.t[sl], gamma.t, beta.t, residual.t[sl] if residual is not None else None, y[sl], running_mean,
+             running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates, y_am)
     out = Var(y, x.rg or gamma.rg or (residual is not None and residual.rg))
-    out.amax = y_am.amax
+    out.amax = y_am
 
     def bwd():
         if out.g is None:
@@ -661,17 +655,17 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
         dx = torch.empty_like(x.t)
         need_res = residual is not None and residual.rg
         dres = torch.empty_like(x.t) if need_res else None
-        dx_am = _amax_out(dx.device, C >= 32)     # max|dx| out of the apply kernel: the scale of the convolution backward it feeds
+        dx_am = _out_slot(dx.device, C >= 32)     # max|dx| out of the apply kernel: the scale of the convolution backward it feeds
         for g in range(groups):
             sl = slice(g * Ng, (g + 1) * Ng)
             ws2 = _new((nbw,), x.t, torch.float64)
             # residual-free ReLU layers: the kernel recomputes the mask from x (fmaf(x, sc, sh) > 0, bit-identical to the
             # forward's) instead of reading y
-            with dx_am:
-                call("jp_bn_train_bwd", out.g[sl], x.t[sl], y[sl] if (relu and residual is not None) else None, gamma.t, beta.t,
-                     mean[g], invstd[g], dx[sl], dres[sl] if need_res else None, gamma.g, beta.g, ws2, Ng, C, H * W, int(relu), 1)
+            call("jp_bn_train_bwd", out.g[sl], x.t[sl], y[sl] if (relu and residual is not None) else None, gamma.t, beta.t,
+                 mean[g], invstd[g], dx[sl], dres[sl] if need_res else None, gamma.g, beta.g, ws2, Ng, C, H * W, int(relu), 1,
+                 dx_am)
         if x.rg:
-            x.add_grad(dx, dx_am.amax)
+            x.add_grad(dx, dx_am)
         if need_res:
             residual.add_grad(dres)
         out.g = None
@@ -761,8 +755,10 @@ def maxpool(x: Var, k, s, p, bwd_addend=None) -> Var:
         if out.g is None:
             return
         dx = torch.empty_like(x.t)
-        call("jp_maxpool_bwd", out.g, idx, dx, bwd_addend() if bwd_addend is not None else None, N * C, H, W, k, s, p)
-        x.add_grad(dx)
+        # CRP chains (5x5 stride 1): the gradient feeds a 1x1 convolution's dgrad / wgrad, the kernel reports its magnitude
+        dx_am = _out_slot(dx.device, k == 5 and s == 1 and C >= 32)
+        call("jp_maxpool_bwd", out.g, idx, dx, bwd_addend() if bwd_addend is not None else None, N * C, H, W, k, s, p, dx_am)
+        x.add_grad(dx, dx_am)
         out.g = None
 
     _rec(out.rg, bwd)
@@ -828,9 +824,11 @@ def add(a: Var, b: Var) -> Var:
                 continue
             if v.g is None:
                 v.g = _copy(g) if owned else g   # the first taker owns the buffer
+                v.gamax = out.gamax              # (same values: the producer's magnitude still holds)
                 owned = True
             else:
                 call("jp_axpby", v.g, g, v.g, g.numel(), 1.0, 1.0)
+                v.gamax = None                   # accumulated into: a magnitude reported for the first addend no longer bounds it
         out.g = None
 
     _rec(out.rg, bwd)
@@ -880,7 +878,7 @@ def act(x: Var, kind) -> Var:
         if out.g is None:
             return
         d = torch.empty_like(x.t)
-        call("jp_act_bwd", out.g, y, d, d.numel(), kind)
+        call("jp_act_bwd", out.g, y, d, d.numel(), kind, None)
         x.add_grad(d)
         out.g = None
 
@@ -935,7 +933,7 @@ def linear_act(x: Var, w: Var, b: Var, act_kind=ACT_RELU) -> Var:
         d = out.g
         if act_kind != ACT_NONE:
             d2 = torch.empty_like(d)
-            call("jp_act_bwd", d, y, d2, d.numel(), act_kind)
+            call("jp_act_bwd", d, y, d2, d.numel(), act_kind, None)
             d = d2
         if b.rg:
             call("jp_colsum", d, b.g, M, Nf, 1)

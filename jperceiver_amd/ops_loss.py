@@ -135,8 +135,10 @@ def view(x: Var, shape) -> Var:
         d = out.g.view(x.t.shape)
         if x.g is None:
             x.g = d
+            x.gamax = out.gamax       # same values, same magnitude
         else:
             call("jp_axpby", x.g, d, x.g, d.numel(), 1.0, 1.0)
+            x.gamax = None            # accumulated into: what a producer reported for the first addend no longer bounds it
         out.g = None
 
     _rec(out.rg, bwd)

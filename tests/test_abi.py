@@ -19,15 +19,44 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (jp_\w+)", out))
     assert exported == set(protos), (exported ^ set(protos))
-    assert L.fn["jp_abi_version"]() == 2
+    assert L.fn["jp_abi_version"]() == 3
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
-    rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, 0, None, None)
+    rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, 0, None, None, None, None, None, None)
     assert rc == -1 and "null" in L.last_error()
-    rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, 0, None, None)
+    rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, 0, None,
+                                 None, None, None)
     assert rc == -1
+    if L.fn["jp_split_scheme"]() == 2:
+        # ABI 3: an operand magnitude that is neither passed nor reducible (amax_ws == NULL) is a bad argument, not a hidden allocation
+        done = ctypes.c_int(7)
+        rc = L.fn["jp_conv2d_fwd"](ctypes.c_void_p(8), ctypes.c_void_p(8), None, ctypes.c_void_p(8), 1, 64, 32, 32, 64, 3, 1, 1, 0, 0, None, 0,
+                                   None, None, None, ctypes.addressof(done), None, None)
+        assert rc == -1 and "amax_ws" in L.last_error() and done.value == 0
+
+
+def test_library_owns_no_device_memory_and_no_cross_call_state():
+    """"the library never allocates or frees device memory ... stateless and re-entrant".  The sources may hold thread-local
+    data only for the error string, the opt-in pack recorder and the opt-in profiler; no hipMalloc / hipFree anywhere; and the ABI has no
+    entry point that parks an argument for a later call (the jp_amax_hint / jp_amax_out side channel of ABI version 2)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jperceiver_amd", "csrc")
+    allowed_tls = ("g_err", "g_pack_rec", "g_prof")
+    for f in sorted(os.listdir(root)):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        for ln, line in enumerate(open(os.path.join(root, f)), 1):
+            code = line.split("//")[0]
+            assert not re.search(r"\bhip(Malloc|Free|MallocAsync|FreeAsync|HostMalloc|MallocManaged)\b", code), f"{f}:{ln}: {line.strip()}"
+            if "thread_local" in code:
+                assert any(a in code for a in allowed_tls), f"{f}:{ln}: {line.strip()}"
+    protos = _lib.parse_header()
+    for gone in ("jp_amax_hint", "jp_amax_hint_clear", "jp_amax_out", "jp_amax_out_done"):
+        assert gone not in protos
+    for name in ("jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3"):
+        args = [a for _, a in protos[name][1]]
+        assert "amax_ws" in args and any(a.startswith("amax_") and a != "amax_ws" for a in args), name
 
 
 def test_call_refuses_cpu_tensors():

@@ -1,9 +1,12 @@
-"""Operand magnitudes of the fp16 split kernels (csrc/scale.hip) on a real MI355X, through the C ABI:
+"""Operand magnitudes of the fp16 split kernels (csrc/scale.hip) on a real MI355X, through the C ABI (version 3: every
+magnitude is an explicit argument of the entry point that reads or writes it):
   * jp_amax / jp_amax_into: the largest ORDINARY magnitude of a tensor (Inf / NaN / |x| >= 2^100 take no part), in a 32-way slot;
-  * jp_amax_hint: a convolution that is handed its operand's magnitude computes bit-for-bit what it computes when it reduces it itself;
-  * jp_amax_out: the producers that fold the reduction into their kernel (patch-kernel conv forward, BatchNorm forward / backward,
-    activation backward) report exactly max |what they wrote|; an entry point that cannot leaves the request untaken;
+  * amax_x: a convolution that is handed its operand's magnitude computes bit-for-bit what it computes when it reduces it itself into
+    the caller's amax_ws; with neither the call is refused;
+  * amax_y / amax_dx: the producers that fold the reduction into their kernel (patch-kernel conv forward, BatchNorm forward / backward,
+    activation backward, 5x5 max-pool backward) report exactly max |what they wrote|; a conv kernel that cannot says so (*amax_y_done);
   * the host mirror (ops.conv2d / batchnorm_train) ends up with the same step whether magnitudes come from producers or reductions."""
+import ctypes
 import pytest
 import torch
 
@@ -62,7 +65,11 @@ def test_amax_is_the_largest_ordinary_magnitude():
     assert _val(s) == 0.0
 
 
-def _conv_direct(x, w, hint=None, want_out=False):
+def _amax_ws():
+    return torch.full((int(lib().fn["jp_conv2d_amax_ws_floats"]()),), float("nan"), device=DEV)     # (need not be initialised)
+
+
+def _conv_direct(x, w, hint=None, want_out=False, amax_ws=True):
     N, Cin, H, W = x.shape
     Cout, _, KH, _ = w.shape
     L = lib()
@@ -71,16 +78,10 @@ def _conv_direct(x, w, hint=None, want_out=False):
     nsp = int(L.fn["jp_conv2d_fwd_split_floats"](N, Cin, H, W, Cout, KH, 1, KH // 2))
     sp = torch.empty(nsp, device=DEV) if nsp else None
     out_slot = _slot() if want_out else None
-    if hint is not None:
-        assert L.fn["jp_amax_hint"](x.data_ptr(), hint.data_ptr()) == 0
-    if want_out:
-        assert L.fn["jp_amax_out"](out_slot.data_ptr()) == 0
-    try:
-        call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, KH, 1, KH // 2, 0, 0, ws, 0, sp)
-    finally:
-        L.fn["jp_amax_hint_clear"]()
-        done = L.fn["jp_amax_out_done"]()
-    return y, out_slot, done
+    done = ctypes.c_int(-1)
+    call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, KH, 1, KH // 2, 0, 0, ws, 0, sp, hint, out_slot, ctypes.addressof(done),
+         _amax_ws() if amax_ws else None)
+    return y, out_slot, done.value
 
 
 @pytest.mark.parametrize("K", [3, 1])
@@ -92,20 +93,40 @@ def test_hinted_convolution_equals_self_reduced_and_reports_its_output(K):
     y0, _, _ = _conv_direct(x, w)
     s = _slot()
     call("jp_amax", x, x.numel(), s)
-    y1, out, done = _conv_direct(x, w, hint=s, want_out=True)
+    y1, out, done = _conv_direct(x, w, hint=s, want_out=True, amax_ws=False)      # every operand magnitude given: no scratch needed
     assert torch.equal(y0, y1)                      # the same scale either way -> the same bits
     if K == 3:
         assert done == 1                            # the 3x3 patch kernel reports; (the 128-channel 1x1 layer runs the generic engine: no report)
     if done:
         assert _val(out) == float(y1.abs().max())
     else:
-        assert _val(out) == 0.0
+        assert done == 0 and _val(out) == 0.0
     ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), padding=K // 2)
     assert float((y1.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
-    # a hint that is too LARGE only costs precision (16 x: four of the seventeen spare bits)
+    # a magnitude that is too LARGE only costs precision (16 x: four of the seventeen spare bits)
     s16 = s * 16.0
     y2, _, _ = _conv_direct(x, w, hint=s16)
     assert float((y2.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    # neither the operand's magnitude nor scratch to reduce it into: refused, nothing launched
+    from jperceiver_amd._lib import JPerceiverHipError
+    with pytest.raises(JPerceiverHipError, match="amax_ws"):
+        _conv_direct(x, w, amax_ws=False)
+
+
+def test_conv_entry_points_keep_no_state_between_calls():
+    """Two different tensors at the SAME address with different magnitudes, back to back: each call sees only its own arguments
+    (ABI version 2 kept hints by address in thread-local state; a stale one would mis-scale the second call)."""
+    _scheme2()
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(2, 128, 64, 128, generator=g)).to(DEV)
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(DEV)
+    s = _slot()
+    call("jp_amax", x, x.numel(), s)
+    y_small, _, _ = _conv_direct(x, w, hint=s)
+    x.mul_(4096.0)                                  # same address, 2^12 larger: a stale magnitude would overflow fp16
+    y_big, _, _ = _conv_direct(x, w)                # un-hinted: must reduce afresh
+    assert bool(torch.isfinite(y_big).all())
+    assert torch.equal(y_big, y_small * 4096.0)     # power-of-two scaling commutes with the whole arithmetic
 
 
 def test_amax_out_is_left_alone_by_kernels_that_cannot_report():
@@ -117,13 +138,41 @@ def test_amax_out_is_left_alone_by_kernels_that_cannot_report():
     y = torch.empty(2, 64, 32, 32, device=DEV)
     ws = torch.empty(int(L.fn["jp_conv2d_ws_floats"](3, 64, 7, 0)), device=DEV)
     slot = _slot()
-    L.fn["jp_amax_out"](slot.data_ptr())
-    call("jp_conv2d_fwd", x, w, None, y, 2, 3, 64, 64, 64, 7, 2, 3, 0, 0, ws, 0, None)
-    assert L.fn["jp_amax_out_done"]() == 0 and _val(slot) == 0.0
-    # ... and the dropped request does not reach a later entry point
+    done = ctypes.c_int(-1)
+    call("jp_conv2d_fwd", x, w, None, y, 2, 3, 64, 64, 64, 7, 2, 3, 0, 0, ws, 0, None, None, slot, ctypes.addressof(done), _amax_ws())
+    assert done.value == 0 and _val(slot) == 0.0
+    # ... and nothing of the request reaches a later entry point
     d = torch.empty_like(y)
-    call("jp_act_bwd", y, y, d, y.numel(), 1)
-    assert L.fn["jp_amax_out_done"]() == 0 and _val(slot) == 0.0
+    call("jp_act_bwd", y, y, d, y.numel(), 1, None)
+    assert _val(slot) == 0.0
+
+
+def test_three_source_forward_folds_the_given_magnitudes():
+    """iconv layer cat(skip, up2x(x), disparity): with the three sources' slots given the kernel's scale comes from their maximum
+    (one 64-lane fold launch, no re-read of the sources) and the output equals the self-reduced call's bit for bit."""
+    _scheme2()
+    g = torch.Generator().manual_seed(13)
+    N, H, W = 4, 64, 128                            # (128 workgroups: the P9US2 kernel takes the layer)
+    x0 = torch.randn(N, 64, H, W, generator=g).to(DEV)
+    x1 = (torch.randn(N, 64, H // 2, W // 2, generator=g) * 5.0).to(DEV)          # the largest magnitude sits in the upsampled source
+    x2 = torch.rand(N, 1, H, W, generator=g).to(DEV)
+    w = (torch.randn(128, 129, 3, 3, generator=g) * 0.05).to(DEV)
+    L = lib()
+    ws = torch.empty(int(L.fn["jp_conv2d_ws_floats"](129, 128, 3, 0)), device=DEV)
+
+    def run(am):
+        y = torch.empty(N, 128, H, W, device=DEV)
+        call("jp_conv2d_fwd_src3", x0, 64, 0, x1, 64, 1, x2, 1, 0, w, None, y, N, H, W, 128, 3, 1, 1, 1, 2, ws, 0, None,
+             *am, None, None, _amax_ws())
+        return y
+
+    slots = []
+    for t in (x0, x1, x2):
+        s = _slot()
+        call("jp_amax", t, t.numel(), s)
+        slots.append(s)
+    a, b, c = run((None, None, None)), run(tuple(slots)), run((slots[0], None, slots[2]))
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_batchnorm_and_activation_backward_report_what_they_write():
@@ -143,16 +192,36 @@ def test_batchnorm_and_activation_backward_report_what_they_write():
         assert x.gamax is not None and _val(x.gamax) == float(x.g.abs().max())
         x.add_grad(torch.ones_like(x.t))            # anything added to the gradient drops the reported magnitude
         assert x.gamax is None
-    L = lib()
     dy, yy = torch.randn(2, 32, 40, 40, generator=g).to(DEV), torch.randn(2, 32, 40, 40, generator=g).to(DEV)
     for name, extra in (("jp_act_bwd", None), ("jp_act_bwd_bias", torch.zeros(32, device=DEV))):
         d, slot = torch.empty_like(dy), _slot()
-        L.fn["jp_amax_out"](slot.data_ptr())
         if extra is None:
-            call(name, dy, yy, d, dy.numel(), 2)
+            call(name, dy, yy, d, dy.numel(), 2, slot)
         else:
-            call(name, dy, yy, d, extra, 2, 32, 1600, 2)
-        assert L.fn["jp_amax_out_done"]() == 1 and _val(slot) == float(d.abs().max()), name
+            call(name, dy, yy, d, extra, 2, 32, 1600, 2, slot)
+        assert _val(slot) == float(d.abs().max()), name
+    # one Inf in the tensor a producer writes: every ordinary value still counts (the filter is per element)
+    dy2 = dy.clone()
+    dy2[1, 3, 7, 9] = float("inf")
+    d, slot = torch.empty_like(dy2), _slot()
+    call("jp_act_bwd", dy2, yy, d, dy2.numel(), 2, slot)
+    fin = d[torch.isfinite(d)]
+    assert _val(slot) == float(fin.abs().max())
+    # 5x5 stride-1 max-pool backward (+ addend): the row kernel reports max |dx|
+    xx = torch.randn(2, 32, 64, 64, generator=g).to(DEV)
+    yp, ip = torch.empty_like(xx), torch.empty(2, 32, 64, 64, dtype=torch.uint8, device=DEV)
+    call("jp_maxpool_fwd", xx, yp, ip, 64, 64, 64, 5, 1, 2)
+    gy, add = torch.randn(2, 32, 64, 64, generator=g).to(DEV), torch.randn(2, 32, 64, 64, generator=g).to(DEV)
+    for ad in (None, add):
+        dx, slot = torch.empty_like(xx), _slot()
+        call("jp_maxpool_bwd", gy, ip, dx, ad, 64, 64, 64, 5, 1, 2, slot)
+        assert _val(slot) == float(dx.abs().max())
+    xs = torch.randn(2, 8, 30, 50, generator=g).to(DEV)          # a shape the row kernel does not take: reduction pass behind the kernel
+    ys, is_ = torch.empty(2, 8, 15, 25, device=DEV), torch.empty(2, 8, 15, 25, dtype=torch.uint8, device=DEV)
+    call("jp_maxpool_fwd", xs, ys, is_, 16, 30, 50, 2, 2, 0)
+    dxs, slot = torch.empty_like(xs), _slot()
+    call("jp_maxpool_bwd", torch.randn(2, 8, 15, 25, generator=g).to(DEV), is_, dxs, None, 16, 30, 50, 2, 2, 0, slot)
+    assert _val(slot) == float(dxs.abs().max())
 
 
 def test_conv_chain_uses_reported_magnitudes_and_matches_the_reduced_ones():
@@ -167,11 +236,9 @@ def test_conv_chain_uses_reported_magnitudes_and_matches_the_reduced_ones():
     up = torch.randn(2, 64, 128, 128, generator=g).to(DEV)
 
     def run(reported):
-        saved = ops._amax_out.__init__
+        saved = ops._out_slot
         if not reported:
-            def off(self, dev, on=True):
-                saved(self, dev, False)
-            ops._amax_out.__init__ = off
+            ops._out_slot = lambda dev, on=True: None
         try:
             x = Var(xt.clone(), True)
             v1, v2, vb = (Var(t.clone(), True, torch.zeros_like(t)) for t in (w1, w2, b1))
@@ -186,10 +253,49 @@ def test_conv_chain_uses_reported_magnitudes_and_matches_the_reduced_ones():
             torch.cuda.synchronize()
             return y.t.clone(), x.g.clone(), v1.g.clone(), v2.g.clone(), vb.g.clone()
         finally:
-            ops._amax_out.__init__ = saved
+            ops._out_slot = saved
 
     a, b = run(True), run(False)
     for p, q in zip(a[:4], b[:4]):
         assert torch.equal(p, q)
     # (the bias gradient is a sum that meets in float atomics -- jp_act_bwd_bias -- and differs in its last bits from run to run)
     assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("second", ["add", "view"])
+def test_reported_gradient_magnitude_is_dropped_by_every_accumulation_path(second):
+    """conv -> {BatchNorm, add / view} fan-out.  BatchNorm backward reports max |dx| for the conv output's
+    gradient; the second consumer then accumulates a gradient 2^20 x larger into the same buffer.  A stale (too small) magnitude
+    would overflow fp16 in the conv's dgrad / wgrad (Inf / NaN gradients); the accumulation paths of ops.add and ops_loss.view drop it."""
+    _scheme2()
+    import torch.nn.functional as F
+    from jperceiver_amd import ops_loss
+    g = torch.Generator().manual_seed(6)
+    N, C, H, W = 8, 64, 64, 64
+    xt = torch.randn(N, C, H, W, generator=g)
+    wt = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    up_bn = torch.randn(N, C, H, W, generator=g)
+    up_big = torch.randn(N, C, H, W, generator=g) * 2.0 ** 20
+    x = Var(xt.to(DEV), True)
+    w = Var(wt.to(DEV), True, torch.zeros(C, C, 3, 3, device=DEV))
+    gamma = Var(torch.ones(C, device=DEV), True, torch.zeros(C, device=DEV))
+    beta = Var(torch.zeros(C, device=DEV), True, torch.zeros(C, device=DEV))
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    tape = Tape()
+    with recording(tape):
+        h = ops.conv2d(x, w, None, 1, 1, ops.PAD_ZERO, ops.ACT_NONE)
+        # recorded first = replayed last: the second consumer's backward runs AFTER BatchNorm's and accumulates into h.g
+        z = ops.add(h, Var(torch.zeros_like(h.t), False)) if second == "add" else ops_loss.view(h, (N, C, H * W))
+        y = ops.batchnorm_train(h, gamma, beta, rm, rv)
+    y.g = up_bn.to(DEV)
+    z.g = up_big.to(DEV).view(z.t.shape).clone()
+    tape.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(x.g).all()) and bool(torch.isfinite(w.g).all())
+    xd, wd = xt.double().requires_grad_(True), wt.double().requires_grad_(True)
+    hd = F.conv2d(xd, wd, None, 1, 1)
+    yd = F.batch_norm(hd, None, None, torch.ones(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64), True)
+    (yd * up_bn.double()).sum().backward(retain_graph=True)
+    hd.backward(up_big.double())
+    assert float((x.g.cpu().double() - xd.grad).abs().max() / xd.grad.abs().max()) < 1e-5
+    assert float((w.g.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()) < 1e-5

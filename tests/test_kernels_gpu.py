@@ -759,9 +759,9 @@ def test_act_bwd_bias_one_pass(N, C, H, W, act):
     dy, y = rnd(N, C, H, W, seed=3), rnd(N, C, H, W, seed=4)
     dx = torch.empty_like(dy)
     db = torch.full((C,), 0.25, device=DEV)
-    call("jp_act_bwd_bias", dy, y, dx, db, N, C, H * W, act)
+    call("jp_act_bwd_bias", dy, y, dx, db, N, C, H * W, act, None)
     dx2 = torch.empty_like(dy)
-    call("jp_act_bwd", dy, y, dx2, dy.numel(), act)
+    call("jp_act_bwd", dy, y, dx2, dy.numel(), act, None)
     assert torch.equal(dx, dx2)
     slope = 0.01 if act == 2 else 0.0
     ref = dy.double() * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope)).double()

@@ -154,6 +154,80 @@ def _emit_edges():
     print("JSON" + json.dumps(res))
 
 
+def _emit_outliers():
+    """Where the fp16 two-way split with ONE power-of-two scale per tensor differs from fp32 arithmetic: operand
+    tensors whose largest magnitude sits far above their typical one.  Per output element, against float64:
+        ratio  = |err| / sum_k |a_k| |b_k|                                   (fp32 arithmetic: <= ~K 2^-24 whatever the data)
+        ratioT = |err| / (sum|a||b| + 2^-19 (A sum_k|b_k| + B sum_k|a_k|))    A, B = the operand tensors' largest magnitudes
+    The arithmetic guarantees ratioT <= 2^-19 (an element is carried to 2^-22 relative OR 2^-40 of its tensor's largest, whichever is
+    larger); ratio <= 2^-19 holds while the typical element is within ~2^20 of the largest."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.nn.functional as F
+    from jperceiver_amd import ops
+    from jperceiver_amd.ops import Var, Tape, recording
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    res = {}
+    N, C, H, W, K = 8, 128, 64, 64, 3
+
+    def stats(got, ref, sab, sa_B, sb_A, keep=None):
+        e = (got.double() - ref).abs()
+        if keep is not None:
+            e, sab, sa_B, sb_A, ref = e[keep], sab[keep], sa_B[keep], sb_A[keep], ref[keep]
+        ratio = e / sab.clamp_min(1e-300)
+        ratioT = e / (sab + 2.0 ** -19 * (sa_B + sb_A)).clamp_min(1e-300)
+        return dict(max_ratio=float(ratio.max()), frac_over=float((ratio > 2.0 ** -19).double().mean()),
+                    max_ratioT=float(ratioT.max()), rms=float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))
+
+    def run(name, x, w, gy, keep_fwd=None, keep_wg=None):
+        xv, wv = Var(x.cuda(), True), Var(w.cuda(), True, torch.zeros_like(w).cuda())
+        tape = Tape()
+        with recording(tape):
+            y = ops.conv2d(xv, wv, None, 1, 1, 0, 0)
+        y.g = gy.cuda()
+        tape.backward()
+        xd, wd, gd = x.double(), w.double(), gy.double()
+        A, Bw, G = float(x.abs().max()), float(w.abs().max()), float(gy.abs().max())
+        one_x, one_w, one_g = torch.ones_like(xd), torch.ones_like(wd), torch.ones_like(gd)
+        conv = lambda a, b: F.conv2d(a, b, None, 1, 1)
+        dgr = lambda g_, w_: torch.nn.grad.conv2d_input(xd.shape, w_, g_, 1, 1)
+        wgr = lambda x_, g_: torch.nn.grad.conv2d_weight(x_, wd.shape, g_, 1, 1)
+        res[name + "/fwd"] = stats(y.t.cpu(), conv(xd, wd), conv(xd.abs(), wd.abs()), conv(xd.abs(), one_w) * Bw, conv(one_x, wd.abs()) * A,
+                                   keep_fwd)
+        res[name + "/dgrad"] = stats(xv.g.cpu(), dgr(gd, wd), dgr(gd.abs(), wd.abs()), dgr(gd.abs(), one_w) * Bw, dgr(one_g, wd.abs()) * G)
+        res[name + "/wgrad"] = stats(wv.g.cpu(), wgr(xd, gd), wgr(xd.abs(), gd.abs()), wgr(xd.abs(), one_g) * G, wgr(one_x, gd.abs()) * A,
+                                     keep_wg)
+
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn((C, C, K, K), generator=g) * (9 * C) ** -0.5
+    base = torch.randn((N, C, H, W), generator=g).clamp_min(0)          # ReLU activations: half zeros, median of the rest 0.67
+    gy0 = torch.randn((N, C, H, W), generator=g)
+    for tag, mag in (("1e4", 1e4), ("1e6", 1e6)):
+        x = base.clone()
+        x[3, 17, 30, 40] = mag * 0.67
+        kf = torch.ones((N, C, H, W), dtype=torch.bool)
+        kf[3, :, 29:32, 39:42] = False                                  # outputs whose 3x3 window holds the outlier
+        kw = torch.ones((C, C, K, K), dtype=torch.bool)
+        kw[:, 17] = False                                               # weight gradients of the outlier's input channel
+        run(f"act_outlier_{tag}", x, w, gy0, kf, kw)
+    for sig in (3.0, 4.0):
+        gy = torch.exp(sig * torch.randn((N, C, H, W), generator=g)) * torch.sign(torch.randn((N, C, H, W), generator=g))
+        run(f"grad_lognormal_sigma{sig:.0f}", base + 0.01, w, gy)
+    x = base.clone() + 0.01
+    x[:, 5] *= 2.0 ** -20
+    kw = torch.zeros((C, C, K, K), dtype=torch.bool)
+    kw[:, 5] = True
+    run("channel_2^-20_below/others", x, w, gy0)
+    run("channel_2^-20_below/that_channel", x, w, gy0, None, kw)
+    # a weight tensor with one filter 2^12 above the rest (the per-tensor weight scale costs the other filters bits)
+    w2 = w.clone()
+    w2[9] *= 4096.0
+    kf = torch.ones((N, C, H, W), dtype=torch.bool)
+    kf[:, 9] = False
+    run("filter_2^12_above", base + 0.01, w2, gy0, kf)
+    print("JSON" + json.dumps(res))
+
+
 def _run(env_extra, mode="--emit"):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], capture_output=True, text=True, timeout=1800, env=env,
@@ -211,8 +285,43 @@ def test_split_range_edges_match_documented_behaviour():
     assert split["tiny_2^-120"]["rel_bound"] <= 2.0 ** -7, split["tiny_2^-120"]
 
 
+def test_split_accuracy_where_one_scale_per_tensor_differs_from_fp32():
+    """activation outliers of 10^4 / 10^6 x the median, log-normal gradients (sigma 3 / 4), one channel 2^20 below the
+    rest, one filter 2^12 above the rest -- on the GPU kernels, per output element, next to the exact-fp32 MFMA kernels on the same data
+    (an fp32 accumulation of K = 1152 heavy-tailed terms is itself 3.4e-6 of sum|a||b| off: the element-wise yardstick is the exact
+    kernel's own figure, not a constant).  Measured (profiles/r06_split_outliers.md): the three-product kernels are CLOSER to float64 than
+    the exact-fp32 kernels in 17 of the 21 (case, pass) rows, including both log-normal cases; they are further in exactly the rows the
+    arithmetic predicts, and those are the documented limits asserted here (include/jperceiver_hip.h):
+      * one activation 10^6 x the median: the outputs that do NOT read it carry 1.6 x (forward) / 2.7 x (weight gradient) the rms error
+        of the fp32 accumulation (bound: 3.5 x);
+      * a channel whose activations all sit 2^20 below their tensor's largest: ITS weight gradients are carried to 7e-6 relative rms
+        (fp32: 3e-7; bound 2^-16), 23 x the exact kernel's -- every other output is unaffected.
+    Everywhere: |err| <= max(2 x the exact kernel's worst, 2^-21) x sum|a||b| per output element, and the bound the arithmetic guarantees
+    relative to the operand TENSORS' largest magnitudes (ratioT <= 2^-18)."""
+    split = _run(dict(JP_P9S="1", JP_W9S="1"), "--outliers")
+    exact = _run(dict(JP_P9S="0", JP_W9S="0"), "--outliers")
+    rows = ["| case / pass | max err / sum|a||b| (exact fp32) | tensor-relative | rms vs float64 (exact fp32) |", "|---|---|---|---|"]
+    for k in sorted(split):
+        s, e = split[k], exact[k]
+        rows.append(f"| {k} | {s['max_ratio']:.2e} ({e['max_ratio']:.2e}) | {s['max_ratioT']:.2e} | {s['rms']:.2e} ({e['rms']:.2e}) |")
+    print("\n".join(rows))
+    limits = {"act_outlier_1e6/fwd": ("x", 3.5), "act_outlier_1e6/wgrad": ("x", 3.5),
+              "channel_2^-20_below/that_channel/wgrad": ("abs", 2.0 ** -16)}
+    for k, s in split.items():
+        e = exact[k]
+        assert s["max_ratioT"] <= 2.0 ** -18, (k, s)
+        assert s["max_ratio"] <= max(2.0 * e["max_ratio"], 2.0 ** -21), (k, s, e)
+        kind, lim = limits.get(k, ("x", 1.25))
+        if kind == "x":
+            assert s["rms"] <= lim * e["rms"] + 1e-9, (k, s, e)
+        else:
+            assert s["rms"] <= lim, (k, s)
+
+
 if __name__ == "__main__":
     if "--emit" in sys.argv:
         _emit()
     if "--edges" in sys.argv:
         _emit_edges()
+    if "--outliers" in sys.argv:
+        _emit_outliers()

@@ -33,21 +33,28 @@ GROUPS = [
      "exact-fp32 MFMA kernels, which have none of these edges.",
      ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
     ("Operand scales of the fp16 split kernels (csrc/scale.hip, csrc/igemm_p9s.h:jp_split2h) -- no counterpart in the reference: plumbing of "
-     "the arithmetic above.  A kernel that forms its fp32 products from two fp16 splits per operand reads the operand tensor's largest "
+     "the arithmetic above, and since ABI version 3 entirely in the entry points' own ARGUMENTS (no library-owned device memory, no state "
+     "between calls).  A kernel that forms its fp32 products from two fp16 splits per operand reads the operand tensor's largest "
      "magnitude from device memory.  A magnitude lives in a SLOT of jp_amax_slot_floats() floats (512: 32 words one cache line apart -- "
-     "producers spread their atomics over them, the kernels take the maximum; every `out` / `amax` / `slot` below is one).  The conv entry "
-     "points reduce it themselves (one extra read of the tensor per call) unless the caller registered a hint: jp_amax writes max |x[0..n)| "
-     "(Inf / NaN / |x| >= 2^100 excluded) to *out (jp_amax_into: max(*out, that) -- *out pre-zeroed by the caller, no memset); "
-     "jp_amax_hint(tensor, amax) tells the NEXT conv calls of this thread that `amax` (from jp_amax on this stream or an earlier one it is "
-     "ordered after) holds the largest magnitude of the operand that starts at `tensor`; jp_amax_hint_clear drops the pending hints (at most 8).  "
-     "A hint that is too SMALL overflows fp16 (Inf / NaN outputs); one that is too large only costs precision.  jp_amax_out(slot): the next "
-     "entry point of this thread that fuses the reduction into its kernel folds max |tensor it writes| into *slot (pre-zeroed by the caller) "
-     "-- jp_conv2d_fwd* when a patch kernel runs the layer (y), jp_bn_train_fwd (y), jp_bn_train_bwd (dx), jp_act_bwd / jp_act_bwd_bias (dx); "
-     "jp_amax_out_done() right after that call: 1 = the slot is being written, 0 = the entry point did not take it (request dropped).  "
-     "jp_split_scheme: 2 = this build's patch kernels use the fp16 two-way split (hints are read), 3 = the bf16 three-way split (no operand "
-     "scales; hints are ignored).",
-     ["jp_amax_slot_floats", "jp_amax", "jp_amax_into", "jp_amax_hint", "jp_amax_hint_clear", "jp_amax_out", "jp_amax_out_done",
-      "jp_split_scheme"]),
+     "producers spread their atomics over them, the kernels take the maximum; every `amax_*` / `out` argument is one).  "
+     "INPUT magnitudes -- amax_x / amax_x0..2 (forward, weight gradient), amax_dy (dgrad, weight gradient) of the jp_conv2d_* entry points: "
+     "a slot that holds max |operand| on `stream` (from jp_amax, or written by the producer of the tensor, below), or NULL; for every "
+     "operand passed as NULL the call reduces the tensor itself (one extra read) into `amax_ws`, caller scratch of "
+     "jp_conv2d_amax_ws_floats() floats that need not be initialised and may be reused by the next call on the same stream.  A call with "
+     "a NULL operand magnitude AND amax_ws == NULL is a bad argument, and so is a forward call with more than one source and no amax_ws "
+     "(its kernel reads ONE magnitude, the largest of the sources', folded into the scratch by a 64-lane launch); the -DJP_NS=3 build "
+     "ignores all of them.  A magnitude that is too "
+     "SMALL overflows fp16 (Inf / NaN outputs); one that is too large only costs precision (an upper bound is enough: max-pool and ReLU "
+     "outputs may reuse their input's slot).  "
+     "OUTPUT magnitudes -- a producer folds max |tensor it writes| into the slot with atomic maxima (the slot must hold 0, or an earlier "
+     "maximum to extend): jp_bn_train_fwd amax_y, jp_bn_train_bwd / jp_act_bwd / jp_act_bwd_bias / jp_maxpool_bwd amax_dx (NULL: not "
+     "wanted), and jp_conv2d_fwd* amax_y: folded in by the kernel's epilogue when a patch kernel runs the layer, in which case "
+     "*amax_y_done (host int, may be NULL) is set to 1 before the call returns; 0 = the kernel chosen for this shape does not report "
+     "(use jp_amax on y if the magnitude is needed).  "
+     "jp_amax writes max |x[0..n)| (Inf / NaN / |x| >= 2^100 excluded) to *out (jp_amax_into: max(*out, that) -- *out pre-zeroed by the "
+     "caller, no memset).  jp_split_scheme: 2 = this build's patch kernels use the fp16 two-way split (magnitudes are read), 3 = the "
+     "bf16 three-way split (no operand scales).",
+     ["jp_amax_slot_floats", "jp_conv2d_amax_ws_floats", "jp_amax", "jp_amax_into", "jp_split_scheme"]),
     ("Train-mode BatchNorm2d (+fused residual add / ReLU) — " + R + "resnet.py:21-24,41-45,92; " + R + "layout_model.py:146,152. "
      "ws = jp_bn_ws_doubles(N, C, HW) doubles of caller scratch.  n_updates = number of momentum updates of the running stats (2 for the layout "
      "branch the reference evaluates twice, " + R + "net.py:73-74).  jp_bn_relu_pool_*: the ResNet stem tail bn1 -> relu -> MaxPool2d(3, 2, 1) ("
@@ -119,7 +126,8 @@ def main():
            " *",
            " * Conventions: fp32 NCHW contiguous tensors; raw device pointers; explicit int dims; every call is",
            " * enqueued on `stream` (a hipStream_t passed as void*), never synchronises and never allocates —",
-           " * the caller owns all buffers including scratch.  Return 0 on success, <0 for a bad argument, >0 =",
+           " * the caller owns all buffers including scratch; no entry point keeps state for a later call (the only",
+           " * thread-local data are the error string and the opt-in pack recorder / profiler).  Return 0 on success, <0 for a bad argument, >0 =",
            " * hipError_t; jp_last_error_string() describes the last failure on the calling thread.",
            " * `gout` arguments are device pointers to the upstream scalar gradient (NULL = 1.0).",
            " */",
