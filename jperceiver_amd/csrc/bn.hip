@@ -318,7 +318,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ y, uint8_t* __restrict__ idx, int C, int H, int W,
                                                           int OH, int OW, double count, float momentum, float eps, int n_updates,
-                                                          int S) {
+                                                          int S, unsigned* __restrict__ amax) {
     constexpr int PW = (SP_TW - 1) * 2 + 3, PH = (SP_TH - 1) * 2 + 3;
     __shared__ float tile[PW * PH];
     __shared__ double tot[2];
@@ -378,15 +378,17 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restric
         }
     }
     const int ox = ox0 + tx;
-    if (ox >= OW) return;
+    float mx = 0.f;                      // largest pooled value this thread wrote (-> amax_y: the first residual block's operand scale)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oy = oy0 + q * 4 + j;
-        if (oy < OH) {
+        if (ox < OW && oy < OH) {
             y[(size_t)nc * OH * OW + oy * OW + ox] = best[j];
             idx[(size_t)nc * OH * OW + oy * OW + ox] = (uint8_t)bi[j];
+            mx = fmaxf(mx, jp_fmag(best[j]));
         }
     }
+    jp_wave_amax_commit(mx, amax);
 }
 
 // backward reduction over the POOLED gradient: sum(g), sum(g * xhat) at the argmax positions whose relu is open
@@ -570,7 +572,8 @@ extern "C" int jp_bn_train_bwd(const float* dy, const float* x, const float* y, 
 // as jp_bn_train_fwd.  ws = jp_bn_ws_doubles(N, C, H * W) doubles.
 extern "C" int jp_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, float* pooled, uint8_t* idx,
                                    float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* ws,
-                                   int N, int C, int H, int W, float momentum, float eps, int n_updates, void* stream) {
+                                   int N, int C, int H, int W, float momentum, float eps, int n_updates, float* amax_y,
+                                   void* stream) {
     JP_CHECK_ARG(x && gamma && beta && pooled && idx && save_mean && save_invstd && ws, "bn_relu_pool_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && C > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0, "bn_relu_pool_fwd: H and W must be multiples of 4");
     hipStream_t st = (hipStream_t)stream;
@@ -580,7 +583,7 @@ extern "C" int jp_bn_relu_pool_fwd(const float* x, const float* gamma, const flo
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
     hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(jp_cdiv(OW, SP_TW), jp_cdiv(OH, SP_TH), N * C), dim3(TPB), 0, st, x, ws, save_mean,
                        save_invstd, running_mean, running_var, gamma, beta, pooled, idx, C, H, W, OH, OW, (double)N * HW, momentum,
-                       eps, n_updates, N * CH);
+                       eps, n_updates, N * CH, reinterpret_cast<unsigned*>(amax_y));
     JP_LAUNCH_CHECK();
 }
 

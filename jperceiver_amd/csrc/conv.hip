@@ -28,7 +28,9 @@
 #include "igemm_w9s.h"
 #include "igemm_w9s2.h"
 #include "igemm_p9us2.h"
-#include "igemm_p1l.h"
+#if JP_NS == 3
+#include "igemm_p1l.h"      // the persistent 1x1 kernel exists in the six-product build only (opt-in there, JP_P1L=1)
+#endif
 #include "scale.h"
 constexpr double JP_NPROD = JP_NS == 2 ? 3.0 : 6.0;     // matrix-pipe products per fp32 product of the P9S-family kernels
 #include "igemm_p9sd.h"
@@ -789,6 +791,7 @@ struct DgradEpi {  // dx[img][ci][pix] (= or +=) acc
     typedef size_t St;
     float* dx;
     int Cin, HW, accumulate;
+    unsigned* amax = nullptr;           // != nullptr: the patch kernels report max |dx as stored| here (the entry point's amax_dx)
     __device__ __forceinline__ St col(int p) const {
         int img = p / HW;
         return (size_t)img * Cin * HW + (p - img * HW);
@@ -801,6 +804,18 @@ struct DgradEpi {  // dx[img][ci][pix] (= or +=) acc
         float4* q = reinterpret_cast<float4*>(dx + base + (size_t)m * HW);
         if (accumulate) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *q = v;
+    }
+    __device__ __forceinline__ float put_get(St base, int m, float v) const {       // put, returning the stored value
+        float* q = dx + base + (size_t)m * HW;
+        const float r = accumulate ? (*q + v) : v;
+        *q = r;
+        return r;
+    }
+    __device__ __forceinline__ float put4_get(St base, int m, float4 v) const {     // put4, returning the largest stored magnitude
+        float4* q = reinterpret_cast<float4*>(dx + base + (size_t)m * HW);
+        if (accumulate) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *q = v;
+        return fmaxf(fmaxf(jp_fmag(v.x), jp_fmag(v.y)), fmaxf(jp_fmag(v.z), jp_fmag(v.w)));
     }
 };
 
@@ -1761,17 +1776,24 @@ struct DgradBorderEpi {  // dx[img][ci][y][x] += acc for the border pixel b
 // border pass through scratch: the K loop is split into slices that store part[slice][ci][b] (coalesced along the border pixels),
 // then ONE small pass folds the slices into dx in a fixed order -- more workgroups on a launch that has only a few dozen tiles,
 // the scattered read-modify-write done once, no atomics
+// amax != nullptr: max |final value| of the pixels this pass touches goes to the slot the main pass reported into -- every element of dx
+// is then covered by one of the two (an upper bound: the main pass's value of a border pixel is in there as well)
 __global__ void border_add_kernel(const float* __restrict__ part, float* __restrict__ dx, int Cin, int Nb, int H, int W,
-                                  int slices) {
+                                  int slices, unsigned* __restrict__ amax) {
     const long total = (long)Cin * Nb;
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / Nb), b = (int)(i - (long)m * Nb);
         const InPixSt px = border_pix(b, Nb, H, W);
         if (!px.valid) continue;
         float s = 0.f;
         for (int k = 0; k < slices; ++k) s += part[(size_t)k * total + i];
-        dx[((size_t)px.img * Cin + m) * H * W + px.y * W + px.x] += s;
+        float* q = dx + ((size_t)px.img * Cin + m) * H * W + px.y * W + px.x;
+        const float r = *q + s;
+        *q = r;
+        mx = fmaxf(mx, jp_fmag(r));
     }
+    jp_wave_amax_commit(mx, amax);
 }
 
 template <int KH>
@@ -2316,19 +2338,20 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * H * W, st) : nullptr;
     if constexpr (JP_NS == 2 && jp_has_amax<E>::value) e.amax = jp_take_amax_out(st);       // (every kernel below reports it)
+#if JP_NS == 3
     if constexpr (TAPS == 1) {
         const long ntiles = (long)N * (H / 4) * (W / 32), xb = (long)N * red * H * W * 4;
         if (bmt == 256 && mt_off == 0 && p1l_enabled() && rows % 256 == 0 && red % 128 == 0 && H % 4 == 0 && W % 32 == 0 && xb < (1L << 31) &&
             ntiles >= 8L * jp_num_cus()) {     // (4 tiles per workgroup, the @128^2 layers: no gain over the patch kernel, profiles/r05_p1l_conv_bench.log)
             const int G = jp_num_cus(), tpw = jp_cdiv(ntiles, G);
             jp_prof_before(p1l_tag<E>(), JP_NPROD * 2.0 * rows * (double)N * H * W * red, st);
-            if constexpr (JP_NS == 3)
-                hipLaunchKernelGGL((jp_conv1x1_p1l_kernel<E>), dim3(jp_cdiv(ntiles, tpw), rows / 256, 1), dim3(512), 0, st, wq, x, e, rows, red, NST,
+            hipLaunchKernelGGL((jp_conv1x1_p1l_kernel<E>), dim3(jp_cdiv(ntiles, tpw), rows / 256, 1), dim3(512), 0, st, wq, x, e, rows, red, NST,
                                    H, W, (int)ntiles, tpw, (int)xb);
             jp_prof_after(st);
             return;
         }
     }
+#endif
     if constexpr (TAPS == 9) {
         // wide tiles (8 rows x 32 columns per workgroup, NJ = 4): only where they keep every CU busy (3x3 layers only)
         const int mode = p9_tile();
@@ -2452,7 +2475,7 @@ static bool w9s_enabled() {
     static const bool on = [] { const char* e = getenv("JP_W9S"); return !(e && e[0] == '0'); }();
     return on;
 }
-struct W9Plan { int splits, tps, ntiles, slices, narrow, split_mfma, ncb1; long need; };
+struct W9Plan { int splits, tps, ntiles, slices, narrow, split_mfma, ncb1, tr; long need; };
 // W9S with 256 output x 32 input channels per workgroup (igemm_w9s.h NCB = 1) for layers whose output channels fill 256-row tiles;
 // JP_W9S_NCB=2 keeps the 128 x 64 tiles of round 3
 static inline bool w9s_ncb1(int Cout, int narrow) {
@@ -2460,13 +2483,17 @@ static inline bool w9s_ncb1(int Cout, int narrow) {
     return on && !narrow && Cout % 256 == 0;
 }
 static inline bool w9_plan(int N, int Cm, int H, int W, int Cout, int KH, int stride, int pad, long ws_floats, W9Plan* p) {
-    if (!w9_enabled() || KH != 3 || stride != 1 || pad != 1 || W % 32 || H % W9_TR || Cm < 64 || Cm % 64 || Cout < 48 ||
+    if (!w9_enabled() || KH != 3 || stride != 1 || pad != 1 || W % 32 || Cm < 64 || Cm % 64 || Cout < 48 ||
         (long)N * Cout * H * W * 4 >= (1L << 31))
         return false;
     const int narrow = Cout <= 64;                    // KG = 2: two K groups per workgroup, two slices per split
     p->split_mfma = w9s_enabled();
     p->ncb1 = p->split_mfma && w9s_ncb1(Cout, narrow);
-    const int ntiles = N * (H / (p->split_mfma ? (narrow ? W9S_TRN : (p->ncb1 ? w9s_tr1() : W9S_TR)) : W9_TR)) * (W / 32), kg = narrow ? 2 : 1;
+    // pixel-tile height of the kernel that will run; the 256 x 32 variant falls back from 4-row to 2-row tiles on maps whose height is
+    // not a multiple of 4 (round 6: the 10 x 32 and 20 x 64 maps of the 1024 x 320 shape used to drop to the exact-fp32 engine here)
+    p->tr = !p->split_mfma ? W9_TR : (narrow ? W9S_TRN : (p->ncb1 ? ((w9s_tr1() == 4 && H % 4 == 0) ? 4 : 2) : W9S_TR));
+    if (H % p->tr) return false;
+    const int ntiles = N * (H / p->tr) * (W / 32), kg = narrow ? 2 : 1;
     const long out_tiles = p->ncb1 ? (long)(Cm / 32) * (Cout / 256) : (long)(Cm / 64) * jp_cdiv(Cout, narrow ? 64 : 128);
     const long per = (long)Cout * 9 * Cm;
     static const long wgs = [] { const char* e = getenv("JP_W9_WGS"); return e ? atol(e) : 256L; }();
@@ -2546,7 +2573,7 @@ static void launch_w9(const float* dy, const float* x, float* ws, int N, int Cx,
                                p.ntiles, p.tps, dyb, xb, gam, xam);
         } else if (p.ncb1) {
             dim3 grid(Cm / 32, Cout / 256, p.splits);
-            if (w9s_tr1() == 4) {
+            if (p.tr == 4) {
                 jp_prof_before(w9s_tag<4, REFLECT, 1, 1>(), JP_NPROD * 2.0 * Cout * 9.0 * Cm * (double)N * H * W, st);
                 hipLaunchKernelGGL((jp_wgrad_w9s_kernel<4, REFLECT, 1, 1>), grid, dim3(512), 0, st, dy, x, ws, Cout, Cx, Cm, H, W,
                                    p.ntiles, p.tps, dyb, xb, gam, xam);
@@ -3052,9 +3079,10 @@ static void border_pass(const PackA& a, const float* dy, float* dx, int C, int C
         launch_auto(a, bb, es, C, Nb, Kp, nsl, wkps, st);
         const long total = (long)C * Nb;
         hipLaunchKernelGGL(border_add_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, split_ws, dx, C, Nb, H,
-                           W, nsl);
+                           W, nsl, (st.ax && st.ax->out_taken) ? st.ax->out : nullptr);
         return;
     }
+    if (st.ax) st.ax->out_taken = false;       // (the read-modify-write epilogue below does not report: the caller reduces dx itself)
     DgradBorderEpi be{dx, C, H, W, Nb, 0};
     const int bsp = border_splits(btiles, Kp / KC);
     const int bkps = jp_cdiv(jp_cdiv(Kp, bsp), KC) * KC;
@@ -3064,7 +3092,9 @@ static void border_pass(const PackA& a, const float* dy, float* dx, int C, int C
 
 extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
                                int KH, int stride, int pad, int pad_mode, int accumulate, float* ws, int ws_state,
-                               float* split_ws, const float* amax_dy, float* amax_ws, void* stream) {
+                               float* split_ws, const float* amax_dy, float* amax_dx, int* amax_dx_done, float* amax_ws,
+                               void* stream) {
+    if (amax_dx_done) *amax_dx_done = 0;
     JP_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && !(KH == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2)),
                  "conv2d_dgrad: reflect mode supports 3x3 stride 1 pad 1 only");
@@ -3075,6 +3105,10 @@ extern "C" int jp_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     JpAmaxCtx ax;
     ax.know(dy, amax_dy);
     ax.ws = amax_ws;
+    // amax_dx: folded in by the patch kernels' epilogue (+ the border fold of reflection layers); a layer with a short row tail is
+    // finished by a second launch that does not report, so the slot is not offered there
+    if (!(Cin > 128 && Cin % 128 <= 16 && Cin % 128 != 0)) ax.out = reinterpret_cast<unsigned*>(amax_dx);
+    const JpAmaxDone done_flag{amax_dx_done, &ax};
     const JpCall st((hipStream_t)stream, &ax);
     if (jp_c16_ok(Cin, Cout, KH, stride, pad, pad_mode, H, W)) {
         jp_c16_dgrad(dy, w, dx, 0, N, Cin, Cout, H, W, accumulate, st);
@@ -3252,7 +3286,9 @@ extern "C" long jp_conv2d_dgrad_src3_split_floats(int c0, int up0, int c1, int u
 extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
                                     int c1, int up1, int acc1, float* dx2, int c2, int up2, int acc2, int N, int H, int W,
                                     int Cout, int KH, int stride, int pad, int pad_mode, float* ws, int ws_state,
-                                    float* split_ws, const float* amax_dy, float* amax_ws, void* stream) {
+                                    float* split_ws, const float* amax_dy, float* amax_dx0, int* amax_dx0_done, float* amax_ws,
+                                    void* stream) {
+    if (amax_dx0_done) *amax_dx0_done = 0;
     // split_ws: optional scratch of jp_conv2d_dgrad_src3_split_floats floats for the border passes (NULL: read-modify-write epilogue)
     JP_CHECK_ARG(dy && w, "conv2d_dgrad_src3: null pointer");
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
@@ -3281,6 +3317,9 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
         const int C = cs[sidx];
         if (!C) continue;
         float* dx = dxs[sidx];
+        // amax_dx0: max |dx0| out of the first source's passes (main patch kernel + border fold), if it is a full-resolution one
+        ax.out = (sidx == 0 && !us[0]) ? reinterpret_cast<unsigned*>(amax_dx0) : nullptr;
+        ax.out_taken = false;
         if (dx && !us[sidx]) {
             PackA a{ws + (size_t)coff * Cp, Cin, Kp, Cp, 9};
             if (C <= 4 && (long)C * Cout * 9 * 4 <= 48 * 1024) {
@@ -3311,6 +3350,7 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
                 }
             }
             border_pass(a, dy, dx, C, Cp, Kp, Cout, N, H, W, split_ws, st);
+            if (sidx == 0 && amax_dx0_done) *amax_dx0_done = ax.out_taken ? 1 : 0;
         } else if (dx) {
             const int h2 = H / 2, w2 = W / 2, KpU = 16 * Cp;
             const long tot = 16L * C * Cp, np2 = (long)N * h2 * w2;

@@ -143,9 +143,7 @@ __device__ __forceinline__ jp_f32x16 jp_mfma_bf16_sw(jp_u32x4 a, jp_u32x4 b, jp_
 }
 
 constexpr int P9S_AHEAD = 2;          // steps of slack behind every M tile's weight stream in the pack: the deepest prefetch of any kernel
-#ifndef P9S_AH3
-#define P9S_AH3 2                     // steps of weight prefetch of the 3x3 kernels in the three-product build (measured: tools/ubench/p9s_bench.hip)
-#endif
+constexpr int P9S_AH3 = 2;            // steps of weight prefetch of the 3x3 kernels in the three-product build (1 vs 2: < 1 %, profiles/r05_fp16x2_lookahead_ab.log; the switch is gone)
 
 // WM x WN waves; wave (wm, wn) owns channels [64 wm, +64) of the M tile and pixel rows [NJ wn, +NJ) of the tile.
 // TAPS = 9 (3x3, one-pixel halo) or 1 (1x1).  KGS = 16-channel groups per stage.
@@ -497,9 +495,7 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
 #endif
 }
 
-#ifndef P9S_OCC1
-#define P9S_OCC1 1         // 1: the 8-wave 1x1 kernels with <= 128 registers (two workgroups per CU) in the three-product build
-#endif
+constexpr bool P9S_OCC1 = true;       // the 8-wave 1x1 kernels with <= 128 registers (two workgroups per CU) in the three-product build (0.467 -> 0.385 ms alone, step unchanged: settled, the switch is gone)
 template <int WM, int WN, int NJ, bool REFLECT, bool REV, class Epi, int TAPS, int KGS>
 __global__ __launch_bounds__(64 * WM * WN, (P9S_OCC1 && JP_NS == 2 && TAPS == 1 && WM * WN == 8) ? 4 : (NJ <= 2 ? 2 : 1)) void jp_igemm_p9s_kernel(
     const unsigned* __restrict__ wp, const float* __restrict__ x, Epi epi, int M, int C, int NST, int H, int W, int mt_off,

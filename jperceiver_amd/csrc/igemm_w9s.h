@@ -31,9 +31,7 @@ typedef short jp_s16x8 __attribute__((ext_vector_type(8)));
 #ifndef W9S_DB
 #define W9S_DB 1
 #endif
-#ifndef W9S_LA
-#define W9S_LA 2           // taps of look-ahead of the transpose reads in the three-product build (1: as the six-product stream)
-#endif
+constexpr int W9S_LA = 2;  // taps of look-ahead of the transpose reads in the three-product build (1: as the six-product stream; < 1 % either way, the switch is gone)
 // NCB = 32-channel INPUT blocks per workgroup: 2 (128 output x 64 input channels, rounds 3) or 1 (256 output x 32 input channels,
 // round 4).  The kernel is VALU-issue-sensitive (timing probes, profiles/r04_w9s_probes.log: dropping the 44-VALU dY split per K
 // group is worth 8 %, dropping the patch staging 12.6 %) and the patch staging -- address arithmetic + split of every staged X

@@ -63,33 +63,44 @@ __global__ void pose_fwd_kernel(const float* __restrict__ aa, const float* __res
         }
 }
 
-// dP (B,3,4) as doubles accumulated by the warp backward -> d axisangle, d translation
+// dP (B,3,4) as doubles accumulated by the warp backward -> d axisangle, d translation.
+// Evaluated in DOUBLE (round 6): one thread per image, so it costs nothing, and the float version was the weakest link of the pose
+// gradient -- for the small rotations of a pose network (|axisangle| ~ 1e-3) the chain through th = |v|, a = v / th, 1 - cos th
+// cancels catastrophically in fp32 (1 - cos(3e-3) = 4.5e-6 carries ~1 % of float rounding, da * inv and dth * v / th nearly cancel):
+// tools/debug/two_step_referee.py measured the pose networks' gradients 8-10 % from the float64 oracle after one Adam step where the
+// fp32 CPU oracle sat at 0.4 %.  The forward keeps the reference's fp32 formulas (net.py:704-756).
 __global__ void pose_bwd_kernel(const double* __restrict__ dP, const float* __restrict__ aa,
                                 const float* __restrict__ tr, const float* __restrict__ K, float* __restrict__ daa,
                                 float* __restrict__ dtr, int B, int invert, int accumulate) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float* Kb = K + 16 * b;
-    float dM[12];  // rows 0..2 of K[:3,:]^T dP  (row 3 of M is constant)
+    double dM[12];  // rows 0..2 of K[:3,:]^T dP  (row 3 of M is constant)
     for (int k = 0; k < 3; ++k)
         for (int j = 0; j < 4; ++j) {
-            float s = 0.f;
-            for (int i = 0; i < 3; ++i) s += Kb[4 * i + k] * (float)dP[12 * b + 4 * i + j];
+            double s = 0.0;
+            for (int i = 0; i < 3; ++i) s += (double)Kb[4 * i + k] * dP[12 * b + 4 * i + j];
             dM[4 * k + j] = s;
         }
-    float v[3] = {aa[3 * b], aa[3 * b + 1], aa[3 * b + 2]};
-    float t[3] = {tr[3 * b], tr[3 * b + 1], tr[3 * b + 2]};
-    float R[9], G[9], dt[3];
-    rodrigues(v, R);
+    const double v[3] = {aa[3 * b], aa[3 * b + 1], aa[3 * b + 2]};
+    const double t[3] = {tr[3 * b], tr[3 * b + 1], tr[3 * b + 2]};
+    const double th = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double inv = 1.0 / (th + 1e-7);
+    const double a[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+    const double ca = cos(th), sa = sin(th), C = 1.0 - ca;
+    const double R[9] = {a[0] * a[0] * C + ca,        a[0] * a[1] * C - a[2] * sa, a[2] * a[0] * C + a[1] * sa,
+                         a[0] * a[1] * C + a[2] * sa, a[1] * a[1] * C + ca,        a[1] * a[2] * C - a[0] * sa,
+                         a[2] * a[0] * C - a[1] * sa, a[1] * a[2] * C + a[0] * sa, a[2] * a[2] * C + ca};
+    double G[9], dt[3];
     if (!invert) {
         for (int i = 0; i < 3; ++i) {
             for (int j = 0; j < 3; ++j) G[3 * i + j] = dM[4 * i + j];
             dt[i] = dM[4 * i + 3];
         }
     } else {
-        const float g3[3] = {dM[3], dM[7], dM[11]};
+        const double g3[3] = {dM[3], dM[7], dM[11]};
         for (int j = 0; j < 3; ++j) {
-            float s = 0.f;
+            double s = 0.0;
             for (int i = 0; i < 3; ++i) {
                 G[3 * j + i] = dM[4 * i + j] - g3[i] * t[j];
                 s += R[3 * j + i] * g3[i];
@@ -97,27 +108,23 @@ __global__ void pose_bwd_kernel(const double* __restrict__ dP, const float* __re
             dt[j] = -s;
         }
     }
-    const float th = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const float inv = 1.f / (th + 1e-7f);
-    const float a[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
-    const float ca = cosf(th), sa = sinf(th), C = 1.f - ca;
-    float aGa = 0.f;
+    double aGa = 0.0;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) aGa += a[i] * G[3 * i + j] * a[j];
-    const float dca = G[0] + G[4] + G[8] - aGa;
-    const float dsa = -a[2] * G[1] + a[1] * G[2] + a[2] * G[3] - a[0] * G[5] - a[1] * G[6] + a[0] * G[7];
-    float da[3] = {sa * (-G[5] + G[7]), sa * (G[2] - G[6]), sa * (-G[1] + G[3])};
+    const double dca = G[0] + G[4] + G[8] - aGa;
+    const double dsa = -a[2] * G[1] + a[1] * G[2] + a[2] * G[3] - a[0] * G[5] - a[1] * G[6] + a[0] * G[7];
+    double da[3] = {sa * (-G[5] + G[7]), sa * (G[2] - G[6]), sa * (-G[1] + G[3])};
     for (int i = 0; i < 3; ++i) {
-        float s = 0.f;
+        double s = 0.0;
         for (int j = 0; j < 3; ++j) s += (G[3 * i + j] + G[3 * j + i]) * a[j];
         da[i] += C * s;
     }
-    float dth = -sa * dca + ca * dsa;
+    double dth = -sa * dca + ca * dsa;
     dth -= (da[0] * v[0] + da[1] * v[1] + da[2] * v[2]) * inv * inv;
     for (int i = 0; i < 3; ++i) {
-        float g = da[i] * inv + (th > 0.f ? dth * v[i] / th : 0.f);
+        const float g = (float)(da[i] * inv + (th > 0.0 ? dth * v[i] / th : 0.0));
         daa[3 * b + i] = accumulate ? daa[3 * b + i] + g : g;
-        dtr[3 * b + i] = accumulate ? dtr[3 * b + i] + dt[i] : dt[i];
+        dtr[3 * b + i] = accumulate ? dtr[3 * b + i] + (float)dt[i] : (float)dt[i];
     }
 }
 

@@ -599,7 +599,9 @@ __global__ __launch_bounds__(TPB) void axpby_kernel(const float* __restrict__ a,
 // chain of pairwise adds.  Left-to-right order = the reference's accumulation order (x + top1 + top2 + ...).
 __global__ __launch_bounds__(TPB) void sum_n_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
                                                     const float* __restrict__ a2, const float* __restrict__ a3,
-                                                    const float* __restrict__ a4, float* __restrict__ out, long n) {
+                                                    const float* __restrict__ a4, float* __restrict__ out, long n,
+                                                    unsigned* __restrict__ amax) {
+    float mx = 0.f;                      // largest |out| this thread wrote (-> amax_out: the operand scale of the convolution that reads it)
     ew_loop(n, al16(a0, a1, a2, a3, a4, out),
             [&](long i) {
                 float4 r = JP_F4(a0)[i];
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(TPB) void sum_n_kernel(const float* __restrict__ a0
                 if (a3) { const float4 c = JP_F4(a3)[i]; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
                 if (a4) { const float4 c = JP_F4(a4)[i]; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
                 JP_F4W(out)[i] = r;
+                mx = fmaxf(fmaxf(mx, fmaxf(jp_fmag(r.x), jp_fmag(r.y))), fmaxf(jp_fmag(r.z), jp_fmag(r.w)));
             },
             [&](long i) {
                 float r = a0[i] + a1[i];
@@ -616,7 +619,9 @@ __global__ __launch_bounds__(TPB) void sum_n_kernel(const float* __restrict__ a0
                 if (a3) r += a3[i];
                 if (a4) r += a4[i];
                 out[i] = r;
+                mx = fmaxf(mx, jp_fmag(r));
             });
+    jp_block_amax_commit(mx, amax);
 }
 
 __global__ __launch_bounds__(TPB) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -1148,11 +1153,13 @@ extern "C" int jp_copy_channels(const float* src, float* dst, int N, int C, int 
     JP_LAUNCH_CHECK();
 }
 
+// amax_out: optional magnitude slot (see the header) that receives max |out|
 extern "C" int jp_sum_n(const float* a0, const float* a1, const float* a2, const float* a3, const float* a4, float* out,
-                        long n, void* stream) {
+                        long n, float* amax_out, void* stream) {
     JP_CHECK_ARG(a0 && a1 && out && n > 0 && !(a3 && !a2) && !(a4 && !a3), "sum_n: bad args");
     JP_ST;
-    hipLaunchKernelGGL(sum_n_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, a0, a1, a2, a3, a4, out, n);
+    hipLaunchKernelGGL(sum_n_kernel, dim3(blocks_for((n + 3) / 4)), dim3(TPB), 0, st, a0, a1, a2, a3, a4, out, n,
+                       reinterpret_cast<unsigned*>(amax_out));
     JP_LAUNCH_CHECK();
 }
 

@@ -116,15 +116,19 @@ class CRPBlock(nn.Module):
                 top = ops.maxpool(top, 5, 1, 2, bwd_addend=(lambda: G[0]) if train else None)
                 top = getattr(self, "{}_{}".format(i + 1, "pointwise"))._fwd(top)
                 tops.append(top)
-        terms, acc = [x.t] + [t.t for t in tops], None
+        terms, acc, acc_am = [x.t] + [t.t for t in tops], None, None
         while len(terms) > 1:                      # up to 5 terms per launch (n_stages = 4 -> exactly one)
             chunk, terms = terms[:5], terms[5:]
             acc = torch.empty_like(x.t)
-            ops.call("jp_sum_n", *(chunk + [None] * (5 - len(chunk))), acc, acc.numel())
+            acc_am = ops._out_slot(acc.device, len(terms) == 0)      # the last launch reports max |sum|: the merge convolution's operand scale
+            ops.call("jp_sum_n", *(chunk + [None] * (5 - len(chunk))), acc, acc.numel(), acc_am)
             terms = [acc] + terms
         if not train:
-            return Var(acc if acc is not None else x.t, False)
+            r = Var(acc if acc is not None else x.t, False)
+            r.amax = acc_am if acc is not None else x.amax
+            return r
         out = Var(acc, True)
+        out.amax = acc_am
         last = top
 
         def bwd():

@@ -228,7 +228,7 @@ class PackRegistry:
         if e is None or e.ptr != ptr or e.ws.numel() != nfloats or e.param is not w.p:
             e = _PackEntry()
             e.ws, e.jobs, e.ptr, e.epoch, e.ver = _new((nfloats,), w.t), None, ptr, -1, -1
-            e._param = weakref.ref(w.p, lambda _r, key=key, reg=weakref.ref(self): PackRegistry._drop(reg, key, _r))
+            e._param = weakref.ref(w.p, lambda _r, key=key, reg=weakref.ref(self), drop=PackRegistry._drop: drop(reg, key, _r))
             self.entries[key] = e
             self.table = None
         return e
@@ -581,9 +581,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 g, acc = srcs[0][0].grad_buf()
                 nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
                 ws_s = _new((nsd,), dy) if nsd else None
+                dx_slot, dx_done = _out_slot(dy.device, big), _ct.c_int(0)
                 _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
-                           (dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc), (ws_s, *dg_am))
+                           (dy, w.t, g, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, acc),
+                           (ws_s, dg_am[0], dx_slot, _ct.addressof(dx_done), dg_am[1]))
                 del ws_s
+                if dx_done.value:         # max |dx| out of the dgrad epilogue (+ border fold): the scale of the next convolution backward
+                    srcs[0][0].gamax = dx_slot
             elif int(_jplib().fn["jp_conv2d_dgrad_src3_ok"](s3[1], s3[2], s3[4], s3[5], s3[7], s3[8], N, H, W, Cout, KH,
                                                            stride, pad, pad_mode)):
                 # per-source dgrad inside the library: straight into each source's gradient buffer, the upsampled
@@ -599,9 +603,13 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 nsd = int(_jplib().fn["jp_conv2d_dgrad_src3_split_floats"](*[v for i in range(3) for v in (s3[3 * i + 1], s3[3 * i + 2])],
                                                                           N, H, W))
                 ws_s = _new((nsd,), dy) if nsd else None
+                dx_slot, dx_done = _out_slot(dy.device, big and rgs[0]), _ct.c_int(0)
                 _conv_call("jp_conv2d_dgrad_src3", w, "dgrad3", sig + rgs, nwd,
-                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode), (ws_s, *dg_am))
+                           (dy, w.t, *ga, N, H, W, Cout, KH, stride, pad, pad_mode),
+                           (ws_s, dg_am[0], dx_slot, _ct.addressof(dx_done), dg_am[1]))
                 del ws_s
+                if dx_done.value:         # (the first source's gradient as STORED -- also when the call accumulated into it)
+                    srcs[0][0].gamax = dx_slot
             else:   # gradient w.r.t. the virtual concat, then routed to the sources
                 dcat = _new((N, Cin, H, W), dy)
                 # (split-K scratch as in the single-source call: small-grid layers then fold their K slices in a fixed order
@@ -609,7 +617,7 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 nsd = int(_jplib().fn["jp_conv2d_dgrad_split_floats"](N, Cin, H, W, Cout, KH, stride, pad))
                 ws_s = _new((nsd,), dy) if nsd else None
                 _conv_call("jp_conv2d_dgrad", w, "dgrad", sig, nwd,
-                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (ws_s, *dg_am))
+                           (dy, w.t, dcat, N, Cin, H, W, Cout, KH, stride, pad, pad_mode, 0), (ws_s, dg_am[0], None, None, dg_am[1]))
                 del ws_s
                 c0 = 0
                 for v, u in srcs:
@@ -686,12 +694,14 @@ def bn_relu_maxpool_train(x: Var, gamma: Var, beta: Var, running_mean, running_v
     idx = _new((N, C, H // 2, W // 2), x.t, torch.uint8)
     mean, invstd = _new((groups, C), x.t), _new((groups, C), x.t)
     nbw = int(_jplib().fn["jp_bn_ws_doubles"](Ng, C, H * W))
+    y_am = _out_slot(y.device, C >= 32)       # max of the pooled map out of the kernel: the first residual block's operand scale
     for g in range(groups):
         sl = slice(g * Ng, (g + 1) * Ng)
         ws = _new((nbw,), x.t, torch.float64)
         call("jp_bn_relu_pool_fwd", x.t[sl], gamma.t, beta.t, y[sl], idx[sl], running_mean, running_var, mean[g], invstd[g], ws,
-             Ng, C, H, W, momentum, eps, n_updates)
+             Ng, C, H, W, momentum, eps, n_updates, y_am)
     out = Var(y, x.rg or gamma.rg)
+    out.amax = y_am
 
     def bwd():
         if out.g is None:

@@ -27,7 +27,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, 0, None, None, None, None, None, None)
     assert rc == -1 and "null" in L.last_error()
     rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, 0, None,
-                                 None, None, None)
+                                 None, None, None, None, None)
     assert rc == -1
     if L.fn["jp_split_scheme"]() == 2:
         # ABI 3: an operand magnitude that is neither passed nor reducible (amax_ws == NULL) is a bad argument, not a hidden allocation

@@ -299,3 +299,40 @@ def test_reported_gradient_magnitude_is_dropped_by_every_accumulation_path(secon
     hd.backward(up_big.double())
     assert float((x.g.cpu().double() - xd.grad).abs().max() / xd.grad.abs().max()) < 1e-5
     assert float((w.g.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("pm", [ops.PAD_ZERO, ops.PAD_REFLECT])
+def test_dgrad_reports_the_gradient_it_writes(pm):
+    """jp_conv2d_dgrad amax_dx: max |dx| out of the patch kernel's epilogue; for reflection-padded layers the border fold, which
+    changes the border pixels afterwards, folds its final values into the same slot (an upper bound of max |dx|, exact when the
+    largest element is not a border pixel the fold lowered)."""
+    _scheme2()
+    g = torch.Generator().manual_seed(8)
+    x = Var(torch.randn(8, 128, 64, 64, generator=g).to(DEV), True)
+    w = Var((torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(DEV), False)
+    tape = Tape()
+    with recording(tape):
+        y = ops.conv2d(x, w, None, 1, 1, pm, ops.ACT_NONE)
+    y.g = torch.randn(8, 128, 64, 64, generator=g).to(DEV)
+    tape.backward()
+    torch.cuda.synchronize()
+    assert x.gamax is not None, "the dgrad patch kernel did not report"
+    got, ref = _val(x.gamax), float(x.g.abs().max())
+    assert got >= ref and got <= ref * 1.5, (got, ref)
+    if pm == ops.PAD_ZERO:
+        assert got == ref
+
+
+def test_sum_and_stem_pool_report_what_they_write():
+    g = torch.Generator().manual_seed(9)
+    a = [torch.randn(2, 32, 40, 40, generator=g).to(DEV) for _ in range(5)]
+    out, slot = torch.empty_like(a[0]), _slot()
+    call("jp_sum_n", *a, out, out.numel(), slot)
+    assert torch.equal(out, a[0] + a[1] + a[2] + a[3] + a[4]) and _val(slot) == float(out.abs().max())
+    x = Var((torch.randn(4, 64, 64, 96, generator=g) * 3.0).to(DEV), True)
+    gamma, beta = Var(torch.rand(64, generator=g).to(DEV) + 0.5, True, torch.zeros(64, device=DEV)), Var(
+        torch.randn(64, generator=g).to(DEV), True, torch.zeros(64, device=DEV))
+    with recording(Tape()):
+        y = ops.bn_relu_maxpool_train(x, gamma, beta, torch.zeros(64, device=DEV), torch.ones(64, device=DEV))
+    if ops.split_scheme() == 2:
+        assert y.amax is not None and _val(y.amax) == float(y.t.abs().max())

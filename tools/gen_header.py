@@ -47,10 +47,12 @@ GROUPS = [
      "SMALL overflows fp16 (Inf / NaN outputs); one that is too large only costs precision (an upper bound is enough: max-pool and ReLU "
      "outputs may reuse their input's slot).  "
      "OUTPUT magnitudes -- a producer folds max |tensor it writes| into the slot with atomic maxima (the slot must hold 0, or an earlier "
-     "maximum to extend): jp_bn_train_fwd amax_y, jp_bn_train_bwd / jp_act_bwd / jp_act_bwd_bias / jp_maxpool_bwd amax_dx (NULL: not "
-     "wanted), and jp_conv2d_fwd* amax_y: folded in by the kernel's epilogue when a patch kernel runs the layer, in which case "
-     "*amax_y_done (host int, may be NULL) is set to 1 before the call returns; 0 = the kernel chosen for this shape does not report "
-     "(use jp_amax on y if the magnitude is needed).  "
+     "maximum to extend): jp_bn_train_fwd / jp_bn_relu_pool_fwd amax_y, jp_sum_n amax_out, jp_bn_train_bwd / jp_act_bwd / jp_act_bwd_bias / "
+     "jp_maxpool_bwd amax_dx (NULL: not wanted), and the convolutions -- jp_conv2d_fwd* amax_y, jp_conv2d_dgrad amax_dx, "
+     "jp_conv2d_dgrad_src3 amax_dx0 (the first source's gradient): folded in by the kernel's epilogue (and, for the backward of "
+     "reflection-padded layers, by the border fold) when a patch kernel runs the layer, in which case *amax_y_done / *amax_dx_done "
+     "(host int, may be NULL) is set to 1 before the call returns; 0 = the kernel chosen for this shape does not report "
+     "(use jp_amax on the tensor if the magnitude is needed).  "
      "jp_amax writes max |x[0..n)| (Inf / NaN / |x| >= 2^100 excluded) to *out (jp_amax_into: max(*out, that) -- *out pre-zeroed by the "
      "caller, no memset).  jp_split_scheme: 2 = this build's patch kernels use the fp16 two-way split (magnitudes are read), 3 = the "
      "bf16 three-way split (no operand scales).",
