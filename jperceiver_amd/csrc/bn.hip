@@ -283,7 +283,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
 
 // generic per-channel sum over (N, HW): out[c] (+)= sum  — conv bias gradients
 __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          int C, int HW, int CH, int chunk) {
+                                                          int C, int HW, int CH, int chunk, float* __restrict__ part) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
     const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
@@ -298,7 +298,18 @@ __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restric
     }
     s += fs;
     s = jp_block_sum_d(s, sm);
-    if (threadIdx.x == 0) atomicAdd(&out[c], (float)s);
+    if (threadIdx.x == 0) {
+        if (part) part[(size_t)c * gridDim.y + blockIdx.y] = (float)s;      // fixed-order fold below: bit-reproducible
+        else atomicAdd(&out[c], (float)s);
+    }
+}
+// out[c] += part[c][0] + part[c][1] + ... in that order (one thread per channel)
+__global__ void channel_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(size_t)c * S + i];
+    out[c] += s;
 }
 
 
@@ -614,13 +625,21 @@ extern "C" int jp_bn_relu_pool_bwd(const float* dpool, const uint8_t* idx, const
     JP_LAUNCH_CHECK();
 }
 
-extern "C" int jp_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
+// ws: optional scratch of jp_channel_sum_ws_floats(N, C, HW) floats -- the per-workgroup partial sums are then folded in a fixed order
+// (bit-reproducible); NULL: they meet in float atomics (run-dependent last bits)
+extern "C" long jp_channel_sum_ws_floats(int N, int C, int HW) {
+    int CH, chunk;
+    chunking(N, C, HW, &CH, &chunk);
+    return (long)C * N * CH;
+}
+extern "C" int jp_channel_sum(const float* x, float* out, int N, int C, int HW, int accumulate, float* ws, void* stream) {
     JP_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "channel_sum: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) JP_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, st));
     int CH, chunk;
     chunking(N, C, HW, &CH, &chunk);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, out, C, HW, CH, chunk);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, out, C, HW, CH, chunk, ws);
+    if (ws) hipLaunchKernelGGL(channel_fold_kernel, dim3(jp_cdiv(C, 64)), dim3(64), 0, st, ws, out, C, N * CH);
     JP_LAUNCH_CHECK();
 }
 

@@ -516,8 +516,11 @@ __global__ __launch_bounds__(TPB) void up_head_D_kernel(const float* __restrict_
     for (int q = 0; q < 16; ++q) D[((size_t)img * 16 + q) * hw + p] = d[q];
 }
 constexpr int UPD_CB = 8;
+// part != nullptr: the workgroup's 16 (class, slot) sums per channel go to part[(img * bands + band)][c][16] and
+// up_head_wgrad_fold_kernel adds them into the 9 taps in a fixed order (bit-reproducible); nullptr: float atomics on dw
 __global__ __launch_bounds__(TPB) void up_head_wgrad_D_kernel(const float* __restrict__ x, const float* __restrict__ D,
-                                                              float* __restrict__ dw, int C, int hw, int band) {
+                                                              float* __restrict__ dw, int C, int hw, int band,
+                                                              float* __restrict__ part) {
     __shared__ float red[4][UPD_CB * 16];
     const int c0 = blockIdx.x * UPD_CB, img = blockIdx.z;
     const float* xp = x + ((size_t)img * C + c0) * hw;
@@ -548,13 +551,32 @@ __global__ __launch_bounds__(TPB) void up_head_wgrad_D_kernel(const float* __res
         const int k = threadIdx.x >> 4, q = threadIdx.x & 15;
         if (c0 + k < C) {
             const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            int y0, y1, x0, x1;
-            up_tap_range(q >> 3, (q >> 1) & 1, y0, y1);
-            up_tap_range((q >> 2) & 1, q & 1, x0, x1);
-            for (int ty = y0; ty <= y1; ++ty)
-                for (int tx = x0; tx <= x1; ++tx) atomicAdd(dw + (size_t)(c0 + k) * 9 + ty * 3 + tx, s);
+            if (part) {
+                part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c0 + k) * 16 + q] = s;
+            } else {
+                int y0, y1, x0, x1;
+                up_tap_range(q >> 3, (q >> 1) & 1, y0, y1);
+                up_tap_range((q >> 2) & 1, q & 1, x0, x1);
+                for (int ty = y0; ty <= y1; ++ty)
+                    for (int tx = x0; tx <= x1; ++tx) atomicAdd(dw + (size_t)(c0 + k) * 9 + ty * 3 + tx, s);
+            }
         }
     }
+}
+// dw[c][tap] += sum over the (class, slot) sums q that reach the tap, over the workgroups in index order
+__global__ void up_head_wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int nblk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 9) return;
+    const int c = i / 9, t = i - c * 9, ty = t / 3, tx = t - ty * 3;
+    float s = 0.f;
+    for (int q = 0; q < 16; ++q) {
+        int y0, y1, x0, x1;
+        up_tap_range(q >> 3, (q >> 1) & 1, y0, y1);
+        up_tap_range((q >> 2) & 1, q & 1, x0, x1);
+        if (ty < y0 || ty > y1 || tx < x0 || tx > x1) continue;
+        for (int b = 0; b < nblk; ++b) s += part[((size_t)b * C + c) * 16 + q];
+    }
+    dw[i] += s;
 }
 
 }  // namespace
@@ -634,6 +656,12 @@ int jp_up_head_dgrad(const float* dy, const float* w, float* dx, int N, int C, i
                        h, wd, accumulate);
     return 0;
 }
+long jp_up_head_wgrad_ws_floats(int N, int C, int h, int wd) {
+    const int hw = h * wd;
+    const int bands = std::max(1, std::min(hw / (TPB * 16), 16));
+    const int band = jp_cdiv(jp_cdiv(hw, bands), TPB) * TPB;
+    return 16L * N * hw + 16L * C * jp_cdiv(hw, band) * N;
+}
 int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, int h, int wd, hipStream_t st, float* ws,
                      long ws_floats) {
     const int hw = h * wd;
@@ -641,8 +669,11 @@ int jp_up_head_wgrad(const float* x, const float* dy, float* dw, int N, int C, i
         hipLaunchKernelGGL(up_head_D_kernel, dim3(jp_cdiv(hw, TPB), N), dim3(TPB), 0, st, dy, ws, h, wd);
         const int bands = std::max(1, std::min(hw / (TPB * 16), 16));
         const int band = jp_cdiv(jp_cdiv(hw, bands), TPB) * TPB;
-        hipLaunchKernelGGL(up_head_wgrad_D_kernel, dim3(jp_cdiv(C, UPD_CB), jp_cdiv(hw, band), N), dim3(TPB), 0, st, x, ws, dw, C, hw,
-                           band);
+        const int nb = jp_cdiv(hw, band);
+        // room behind the D planes for the workgroups' partial sums -> fixed-order fold (jp_up_head_wgrad_ws_floats asks for it)
+        float* part = ws_floats >= 16L * N * hw + 16L * C * nb * N ? ws + 16L * N * hw : nullptr;
+        hipLaunchKernelGGL(up_head_wgrad_D_kernel, dim3(jp_cdiv(C, UPD_CB), nb, N), dim3(TPB), 0, st, x, ws, dw, C, hw, band, part);
+        if (part) hipLaunchKernelGGL(up_head_wgrad_fold_kernel, dim3(jp_cdiv(C * 9, 256)), dim3(256), 0, st, part, dw, C, nb * N);
         return 0;
     }
     const int bands = std::max(1, std::min(hw / (TPB * 16), 16));     // (64 bands of 4 iterations measured slower: 361 vs 278 us)

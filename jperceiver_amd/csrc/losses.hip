@@ -238,24 +238,39 @@ __global__ __launch_bounds__(TPB) void scale_bwd_kernel(const float* __restrict_
             bil_window(xs, sx, ws, FW, tx0, tx1);
             ty0 = max(ty0, y_lo); ty1 = min(ty1, y_hi - 1);
             tx0 = max(tx0, x_lo); tx1 = min(tx1, x_hi - 1);
+            // shrink both windows to the label rows / columns that really read this source pixel (bil_src decides, so forward and
+            // backward agree); between the first and the last match every candidate matches (the taps move monotonically)
+            auto hits = [](int o, float scale, int in, int r) {
+                int i0, i1;
+                float w1;
+                bil_src(o, scale, in, i0, i1, w1);
+                return i0 == r || i1 == r;
+            };
+            while (ty0 <= ty1 && !hits(ty0, sy, hs, ys)) ++ty0;
+            while (ty1 >= ty0 && !hits(ty1, sy, hs, ys)) --ty1;
+            while (tx0 <= tx1 && !hits(tx0, sx, ws, xs)) ++tx0;
+            while (tx1 >= tx0 && !hits(tx1, sx, ws, xs)) --tx1;
             for (int y = ty0; y <= ty1; ++y) {
                 int y0, y1;
                 float wy;
                 bil_src(y, sy, hs, y0, y1, wy);
+                if (y0 != ys && y1 != ys) continue;
                 // weight of source row ys in target row y (y0 == y1 at the last row: both taps land on it)
                 const float wrow = (y0 == ys ? 1.f - wy : 0.f) + (y1 == ys ? wy : 0.f);
-                if (y0 != ys && y1 != ys) continue;
+                const float* lrow = lb + (size_t)y * FW;
+                const float* d0 = d + y0 * ws;
+                const float* d1 = d + y1 * ws;
                 for (int x = tx0; x <= tx1; ++x) {
+                    const float gt = lrow[x];
+                    if (!(gt > 0.f)) continue;
                     int x0, x1;
                     float wx;
                     bil_src(x, sx, ws, x0, x1, wx);
                     if (x0 != xs && x1 != xs) continue;
-                    const float gt = lb[(size_t)y * FW + x];
-                    if (!(gt > 0.f)) continue;
-                    const float a = 1.f / (min_disp + rng * d[y0 * ws + x0]);
-                    const float bq = 1.f / (min_disp + rng * d[y0 * ws + x1]);
-                    const float c = 1.f / (min_disp + rng * d[y1 * ws + x0]);
-                    const float e = 1.f / (min_disp + rng * d[y1 * ws + x1]);
+                    const float a = 1.f / (min_disp + rng * d0[x0]);
+                    const float bq = 1.f / (min_disp + rng * d0[x1]);
+                    const float c = 1.f / (min_disp + rng * d1[x0]);
+                    const float e = 1.f / (min_disp + rng * d1[x1]);
                     const float pr = (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * c + wx * e);
                     if (!(pr >= 1e-3f && pr <= 80.f)) continue;            // clamp passes no gradient outside
                     const float wcol = (x0 == xs ? 1.f - wx : 0.f) + (x1 == xs ? wx : 0.f);

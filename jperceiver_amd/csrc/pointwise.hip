@@ -685,7 +685,7 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(const float* __restrict__ 
 // grid (C, N * CH): block = one chunk of one (n, c) plane; fp32 short runs -> double, one float atomic per block (as channel_sum).
 __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
                                                            float* __restrict__ dbias, int C, int HW, int CH, int chunk, int act,
-                                                           unsigned* __restrict__ amax) {
+                                                           unsigned* __restrict__ amax, float* __restrict__ part) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
     const int n = blockIdx.y / CH, ck = blockIdx.y - n * CH;
@@ -718,7 +718,18 @@ __global__ __launch_bounds__(TPB) void act_bwd_bias_kernel(const float* __restri
     jp_block_amax_commit(mx, amax);
     s += fs;
     s = jp_block_sum_d(s, sm);
-    if (threadIdx.x == 0) atomicAdd(&dbias[c], (float)s);
+    if (threadIdx.x == 0) {
+        if (part) part[(size_t)c * gridDim.y + blockIdx.y] = (float)s;      // fixed-order fold below: bit-reproducible
+        else atomicAdd(&dbias[c], (float)s);
+    }
+}
+// dbias[c] += part[c][0] + part[c][1] + ... in that order (one thread per channel)
+__global__ void bias_fold_kernel(const float* __restrict__ part, float* __restrict__ dbias, int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(size_t)c * S + i];
+    dbias[c] += s;
 }
 
 // out[n][c][hw] = a[n][c][hw] * s[n][0][hw]   (CrossViewTransformer.py:68) and its two adjoints
@@ -1198,19 +1209,32 @@ extern "C" int jp_act_bwd(const float* dy, const float* y, float* dx, long n, in
     JP_LAUNCH_CHECK();
 }
 
-// dx = dy * act'(y) and dbias[c] += sum over (n, hw) of dx, one pass (dbias is accumulated into: zero it for a fresh gradient)
-extern "C" int jp_act_bwd_bias(const float* dy, const float* y, float* dx, float* dbias, int N, int C, int HW, int act,
-                               float* amax_dx, void* stream) {
-    JP_CHECK_ARG(dy && y && dx && dbias && N > 0 && C > 0 && HW > 0 && C <= 65535, "act_bwd_bias: bad args");
-    JP_ST;
+// dx = dy * act'(y) and dbias[c] += sum over (n, hw) of dx, one pass (dbias is accumulated into: zero it for a fresh gradient).
+// bias_ws: optional scratch of jp_act_bwd_bias_ws_floats(N, C, HW) floats -- the per-workgroup partial sums are then folded in a fixed
+// order (bit-reproducible bias gradients); NULL: they meet in float atomics (run-dependent last bits)
+static void act_bias_chunks(int N, int C, int HW, int* CH, int* chunk) {
     int ch = std::max(1, 2048 / std::max(1, N * C));
     ch = std::min(ch, std::max(1, HW / 2048));
-    int chunk = (HW + ch - 1) / ch;
-    chunk = (chunk + 3) & ~3;                       // chunks start on 16-byte boundaries when HW allows vector accesses
-    const int CH = (HW + chunk - 1) / chunk;
+    int ck = (HW + ch - 1) / ch;
+    ck = (ck + 3) & ~3;                             // chunks start on 16-byte boundaries when HW allows vector accesses
+    *chunk = ck;
+    *CH = (HW + ck - 1) / ck;
+}
+extern "C" long jp_act_bwd_bias_ws_floats(int N, int C, int HW) {
+    int CH, chunk;
+    act_bias_chunks(N, C, HW, &CH, &chunk);
+    return (long)C * N * CH;
+}
+extern "C" int jp_act_bwd_bias(const float* dy, const float* y, float* dx, float* dbias, int N, int C, int HW, int act,
+                               float* amax_dx, float* bias_ws, void* stream) {
+    JP_CHECK_ARG(dy && y && dx && dbias && N > 0 && C > 0 && HW > 0 && C <= 65535, "act_bwd_bias: bad args");
+    JP_ST;
+    int CH, chunk;
+    act_bias_chunks(N, C, HW, &CH, &chunk);
     JP_CHECK_ARG((long)N * CH <= 65535, "act_bwd_bias: too many chunks");
     hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(C, N * CH), dim3(TPB), 0, st, dy, y, dx, dbias, C, HW, CH, chunk, act,
-                       reinterpret_cast<unsigned*>(amax_dx));
+                       reinterpret_cast<unsigned*>(amax_dx), bias_ws);
+    if (bias_ws) hipLaunchKernelGGL(bias_fold_kernel, dim3(jp_cdiv(C, 64)), dim3(64), 0, st, bias_ws, dbias, C, N * CH);
     JP_LAUNCH_CHECK();
 }
 

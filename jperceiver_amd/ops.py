@@ -496,7 +496,8 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
             ao = _out_slot(dy.device, big)
             if b is not None and b.rg and Cout <= 65535:
                 # activation backward and bias gradient in one pass (the bias gradient is a sum over the tensor this pass writes)
-                call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act, ao)
+                nbw = int(_jplib().fn["jp_act_bwd_bias_ws_floats"](N, Cout, OH * OW))
+                call("jp_act_bwd_bias", dy, y, d2, b.g, N, Cout, OH * OW, act, ao, _new((nbw,), dy))    # (scratch: fixed-order fold)
                 bias_done = True
             else:
                 call("jp_act_bwd", dy, y, d2, dy.numel(), act, ao)
@@ -509,7 +510,8 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
 
         def param_grads():
             if b is not None and b.rg and not bias_done:
-                call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1)
+                ncw = int(_jplib().fn["jp_channel_sum_ws_floats"](N, Cout, OH * OW))
+                call("jp_channel_sum", dy, b.g, N, Cout, OH * OW, 1, _new((ncw,), dy))
             if w.rg:
                 wg_am = (*x_am, dy_am, _amax_ws(dy.device, dy_am, *x_am[:len(srcs)]))
                 nms = 0
@@ -519,7 +521,9 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
                 up_head = len(srcs) == 1 and srcs[0][1] and int(_jplib().fn["jp_conv2d_up_head_ok"](
                     s3[1], s3[2], 0, 0, Cout, KH, stride, pad, pad_mode, H, W))
                 if up_head:     # disparity head on an upsampled source: upsample-aware direct kernel, nothing materialised
-                    nup = 4 * N * H * W                     # 16 gathered dY sums per half-resolution pixel
+                    # 16 gathered dY sums per half-resolution pixel + the workgroups' partial sums (folded in a fixed order)
+                    nup = int(_jplib().fn["jp_conv2d_wgrad_src3_ws_floats"](s3[1], s3[2], 0, 0, 0, 0, N, H, W, Cout, KH, stride, pad,
+                                                                             pad_mode))
                     ws_w = _new((nup,), dy)
                     call("jp_conv2d_wgrad_src3", *s3, dy, w.g, N, H, W, Cout, KH, stride, pad, pad_mode, 1, ws_w, nup, *wg_am)
                     del ws_w

@@ -198,7 +198,7 @@ def test_batchnorm_and_activation_backward_report_what_they_write():
         if extra is None:
             call(name, dy, yy, d, dy.numel(), 2, slot)
         else:
-            call(name, dy, yy, d, extra, 2, 32, 1600, 2, slot)
+            call(name, dy, yy, d, extra, 2, 32, 1600, 2, slot, None)
         assert _val(slot) == float(d.abs().max()), name
     # one Inf in the tensor a producer writes: every ordinary value still counts (the filter is per element)
     dy2 = dy.clone()
@@ -256,10 +256,8 @@ def test_conv_chain_uses_reported_magnitudes_and_matches_the_reduced_ones():
             ops._out_slot = saved
 
     a, b = run(True), run(False)
-    for p, q in zip(a[:4], b[:4]):
+    for p, q in zip(a, b):          # (round 6: the bias gradient's partial sums are folded in a fixed order too)
         assert torch.equal(p, q)
-    # (the bias gradient is a sum that meets in float atomics -- jp_act_bwd_bias -- and differs in its last bits from run to run)
-    assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("second", ["add", "view"])

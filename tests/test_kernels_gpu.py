@@ -10,6 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from jperceiver_amd import ops, ops_loss                                        # noqa: E402
+from jperceiver_amd import _lib                                                # noqa: E402
 from jperceiver_amd._lib import call                                           # noqa: E402
 from jperceiver_amd.ops import Var, Tape, recording                            # noqa: E402
 from oracle import jp_oracle as J                                              # noqa: E402
@@ -759,7 +760,24 @@ def test_act_bwd_bias_one_pass(N, C, H, W, act):
     dy, y = rnd(N, C, H, W, seed=3), rnd(N, C, H, W, seed=4)
     dx = torch.empty_like(dy)
     db = torch.full((C,), 0.25, device=DEV)
-    call("jp_act_bwd_bias", dy, y, dx, db, N, C, H * W, act, None)
+    call("jp_act_bwd_bias", dy, y, dx, db, N, C, H * W, act, None, None)
+    # with scratch the partial sums are folded in a fixed order: the same bits on every run, and the sum of the atomics path
+    nws = int(_lib.lib().fn["jp_act_bwd_bias_ws_floats"](N, C, H * W))
+    dbs = []
+    for _ in range(2):
+        dbw = torch.full((C,), 0.25, device=DEV)
+        call("jp_act_bwd_bias", dy, y, torch.empty_like(dy), dbw, N, C, H * W, act, None, torch.empty(nws, device=DEV))
+        dbs.append(dbw)
+    assert torch.equal(dbs[0], dbs[1])
+    close(dbs[0], db, rtol=1e-5, atol=1e-5, msg="dbias with scratch vs atomics")
+    nwc = int(_lib.lib().fn["jp_channel_sum_ws_floats"](N, C, H * W))
+    cs = []
+    for _ in range(2):
+        o = torch.zeros(C, device=DEV)
+        call("jp_channel_sum", dy, o, N, C, H * W, 0, torch.empty(nwc, device=DEV))
+        cs.append(o)
+    assert torch.equal(cs[0], cs[1])
+    close(cs[0], dy.double().sum(dim=(0, 2, 3)).float(), rtol=1e-5, atol=1e-5, msg="channel_sum with scratch")
     dx2 = torch.empty_like(dy)
     call("jp_act_bwd", dy, y, dx2, dy.numel(), act, None)
     assert torch.equal(dx, dx2)

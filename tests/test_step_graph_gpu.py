@@ -57,10 +57,10 @@ def _copy_state(src, dst):
 def test_captured_step_equals_eager_step(ty):
     """Step by step from IDENTICAL state (the eager runner's parameters, Adam moments, BatchNorm buffers and RNG position are
     copied over before every step): 2 eager warm-up iterations, the capture, then 5 replays, each against the eager step on the
-    same batch.  Forward quantities agree to fp32 rounding; one clip+Adam step moves a weight by at most ~lr, so parameters
-    agree within 2.2 lr everywhere (a sign flip of a ~0 gradient under the few atomically-folded sums) and bit for bit on all
-    but a sliver of the elements; Adam's step counter / bias corrections, the halved lr from step 5 on, the BatchNorm counters
-    and the device RNG position follow the eager run exactly."""
+    same batch.  Round 6: BIT FOR BIT -- every loss term, the gradient arena and the parameters after clip + Adam.  (Until round 5
+    a few sums met in float atomics and the two issue orders differed in their last bits; tests/test_step_repro_gpu.py has the list
+    of what was made order-independent.)  Adam's step counter / bias corrections, the halved lr from step 5 on, the BatchNorm
+    counters and the device RNG position follow the eager run exactly."""
     E, split = _runner(ty, False)
     G, _ = _runner(ty, True)
     batches = [syn.make_batch(B, HW, HW, FR, HW // 4, (129, 154) if split == "argo" else (94, 311), split, seed=80 + i)
@@ -83,14 +83,14 @@ def test_captured_step_equals_eager_step(ty):
         for k in le:
             d = abs(le[k] - lg[k]) / max(1.0, abs(le[k]))
             worst_l = max(worst_l, d)
-            assert d <= 2e-5, (i, k, le[k], lg[k])
+            assert le[k] == lg[k], (i, k, le[k], lg[k])          # round 6: no run-dependent sum is left on the step path
         pe, pg = E.optimizer.arena.params, G.optimizer.arena.params
         n = E.optimizer.arena.live_numel
+        assert torch.equal(E.optimizer.arena.grads[:n], G.optimizer.arena.grads[:n]), (i, "gradient arena")
         d = (pe[:n] - pg[:n]).abs()
         worst_p = max(worst_p, float(d.max()))
-        frac = max(frac, float((d > 1e-7).float().mean()))
-        assert float(d.max()) <= 2.2 * lr, (i, float(d.max()))
-        assert float((d > 1e-7).float().mean()) < 0.02, (i, float((d > 1e-7).float().mean()))
+        frac = max(frac, float((d > 0).float().mean()))
+        assert torch.equal(pe[:n], pg[:n]), (i, float(d.max()), float((d > 0).float().mean()))
         assert E.optimizer.arena.step_count == G.optimizer.arena.step_count == i + 1
         for (na, ba), (nb, bb) in zip(E.model.named_buffers(), G.model.named_buffers()):
             if ba.dtype.is_floating_point:

@@ -1,0 +1,50 @@
+"""The training step is bit-reproducible run to run: two models built from the same state take the same step on
+the same batch -- every loss term, every one of the 466 parameter gradients and the parameters after clip + Adam are bit-identical.
+
+Until round 6, 153-191 of the 466 gradient tensors differed in their last bits between runs (<= 1.2e-6 relative): a few sums merged
+their partials with float atomics -- the scale loss's bilinear scatter, the split-K slices of small-map stride-2 dgrads that got no
+scratch, bias gradients, the slot-table / disparity-head weight gradients.  tools/debug/first_divergence.py (checksums of every
+kernel call's arguments, two runs side by side) named them; they now fold their partial sums in a fixed order through caller scratch
+or gather instead of scatter.  What is still accumulated with atomics is accumulated in DOUBLE (loss sums, the warp's dP, the
+smoothness normaliser) and read back through an fp32 rounding that those last bits do not reach.
+Reference loop: mono/apis/trainer.py:30-56, mono/core/utils/dist_utils.py:54-60."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from jperceiver_amd import ops, synthetic as syn                                # noqa: E402
+from jperceiver_amd.model import MONO                                          # noqa: E402
+from jperceiver_amd.apis import batch_processor, build_optimizer, Runner       # noqa: E402
+from jperceiver_amd.core import DistOptimizerHook                              # noqa: E402
+from oracle import jp_oracle as J                                              # noqa: E402
+
+
+def _one_run(opt, batch):
+    model = MONO.module_dict["Baseline"](opt)
+    model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
+    model = model.cuda().train()
+    optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+    runner = Runner(model, batch_processor, optim, DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)))
+    ops.manual_seed(7)          # Dropout masks / automask noise come from the device generator: same seed, same draws
+    out = runner.train_iter({k: v.clone() for k, v in batch.items()})
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    params = optim.arena.params[:optim.arena.live_numel].clone()
+    return dict(out["log_vars"]), grads, params
+
+
+@pytest.mark.parametrize("ty,HW,B", [("static", 256, 2), ("Argo_both", 256, 2), ("static", 512, 1)])
+def test_same_step_twice_is_bit_identical(ty, HW, B):
+    FR = [0, -1, 1]
+    split = "argo" if ty.startswith("Argo") else "odometry"
+    opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type=ty, split=split,
+                        loss_weightS=20, loss2_weightS=20)
+    batch = syn.make_batch(B, HW, HW, FR, HW // 4, (129, 154) if split == "argo" else (94, 311), split, seed=41)
+    runs = [_one_run(opt, batch) for _ in range(3)]
+    l0, g0, p0 = runs[0]
+    for l, g, p in runs[1:]:
+        assert l == l0, {k: (l0[k], l[k]) for k in l0 if l0[k] != l[k]}
+        bad = [n for n in g0 if not torch.equal(g0[n], g[n])]
+        assert not bad, f"{len(bad)} of {len(g0)} gradient tensors differ between two runs of the same step: {bad[:10]}"
+        assert torch.equal(p0, p), "parameters after clip + Adam differ between two runs of the same step"

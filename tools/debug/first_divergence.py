@@ -1,0 +1,66 @@
+"""Which kernel call is the first whose OUTPUT differs between two runs of the same training step?  Every tensor argument of every
+C-ABI call is checksummed (integer sum of its bytes: order-independent, exact) right after the call, on the stream it was issued on; two
+runs from identical state are compared call by call.   python tools/debug/first_divergence.py [HW=256] [B=2] [type=static]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from jperceiver_amd import ops, ops_loss, runtime as rt, synthetic as syn, _lib
+from jperceiver_amd.model import MONO, net as netmod, modules as mods
+from jperceiver_amd.apis import batch_processor, build_optimizer, Runner
+from jperceiver_amd.core import DistOptimizerHook
+from oracle import jp_oracle as J
+HW = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+TY = sys.argv[3] if len(sys.argv) > 3 else "static"
+FR = [0, -1, 1]
+split = "argo" if TY.startswith("Argo") else "odometry"
+opt = J.default_opt(frame_ids=FR, imgs_per_gpu=B, height=HW, width=HW, occ_map_size=HW // 4, type=TY, split=split, loss_weightS=20, loss2_weightS=20)
+batch = syn.make_batch(B, HW, HW, FR, HW // 4, (129, 154) if split == "argo" else (94, 311), split, seed=41)
+orig = _lib.call
+logs = []
+
+
+def run():
+    rec = []
+
+    def spy(name, *a):
+        orig(name, *a)
+        sums, names = [], [an for _, an in _lib.lib().protos[name][1]]
+        for t, an in zip(a, names):
+            # (scratch arguments hold uninitialised slack: not results)
+            # (float64 arguments are sums accumulated with double atomics: their last bits vary, what is derived from them in fp32 does not)
+            if isinstance(t, torch.Tensor) and t.numel() > 0 and t.dtype != torch.float64 and an not in ("ws", "split_ws", "amax_ws", "part", "bias_ws"):
+                sums.append((an, t.reshape(-1).view(torch.uint8).sum(dtype=torch.int64)))
+        rec.append((name, tuple(tuple(t.shape) for t in a if isinstance(t, torch.Tensor)), sums))
+    for m in (ops, ops_loss, netmod, rt, mods):
+        if hasattr(m, "call"):
+            m.call = spy
+    try:
+        model = MONO.module_dict["Baseline"](opt)
+        model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0))
+        model = model.cuda().train()
+        optim = build_optimizer(model, dict(type="Adam", lr=1e-4, weight_decay=0))
+        runner = Runner(model, batch_processor, optim, DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)))
+        ops.manual_seed(7)
+        runner.train_iter({k: v.clone() for k, v in batch.items()})
+        torch.cuda.synchronize()
+    finally:
+        for m in (ops, ops_loss, netmod, rt, mods):
+            if hasattr(m, "call"):
+                m.call = orig
+    return [(n, sh, [(an, int(x)) for an, x in s]) for n, sh, s in rec]
+
+
+a, b = run(), run()
+print(f"{len(a)} / {len(b)} calls")
+shown = 0
+for i, (x, y) in enumerate(zip(a, b)):
+    if x[0] != y[0] or x[1] != y[1]:
+        print(f"call {i}: different call sequence: {x[0]} {x[1]} vs {y[0]} {y[1]}")
+        break
+    if x[2] != y[2]:
+        which = [u[0] for u, v in zip(x[2], y[2]) if u != v]
+        print(f"call {i}: {x[0]} argument(s) {which} differ; shapes {x[1]}")
+        shown += 1
+        if shown >= 12:
+            break

@@ -43,5 +43,8 @@ groups = collections.Counter(".".join(n.split(".")[:2]) for n in bad)
 for g, c in groups.most_common():
     worst = max(v for n, v in bad.items() if n.startswith(g))
     print(f"   {g:40s} {c:4d} tensors, worst relative difference {worst:.2e}")
-for n in list(bad)[:0]:
-    print("  ", n, bad[n])
+if len(sys.argv) > 5:        # which tensors of one group are bit-equal / differ (localises where the run-dependence enters)
+    grp = sys.argv[5]
+    for n in grads[0]:
+        if n.startswith(grp):
+            print(f"   {'DIFF ' + format(bad[n], '.1e') if n in bad else 'equal        '}  {n}")

@@ -31,7 +31,7 @@ GROUPS = [
      "weight gradient (JP_P7S, W9S2) and a -DJP_NS=3 build use 6 bf16 products of exact 3-way bf16 splits (csrc/igemm_p9s.h:jp_split3: error "
      "<= the fp32 FMA chain's for 2^-109 <= |x| <= 3.3895e38; Inf -> NaN).  JP_P9S=0 JP_W9S=0 JP_P9US=0 JP_P9SD=0 JP_P9S2=0 selects the "
      "exact-fp32 MFMA kernels, which have none of these edges.",
-     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
+     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
     ("Operand scales of the fp16 split kernels (csrc/scale.hip, csrc/igemm_p9s.h:jp_split2h) -- no counterpart in the reference: plumbing of "
      "the arithmetic above, and since ABI version 3 entirely in the entry points' own ARGUMENTS (no library-owned device memory, no state "
      "between calls).  A kernel that forms its fp32 products from two fp16 splits per operand reads the operand tensor's largest "
@@ -68,7 +68,7 @@ GROUPS = [
      "nearest upsample " + R + "layers.py:110; torch.cat; Dropout multiply " + R + "depth_decoder.py:52-53; F.interpolate bilinear "
      + R + "net.py:196,632,692 and area " + R + "net.py:762.",
      ["jp_maxpool_fwd", "jp_maxpool_bwd", "jp_upsample2x_fwd", "jp_upsample2x_bwd", "jp_copy_channels", "jp_axpby", "jp_sum_n", "jp_mul",
-      "jp_affine", "jp_act_fwd", "jp_act_bwd", "jp_act_bwd_bias", "jp_mul_bcast_c", "jp_mul_bcast_c_bwd_s", "jp_bilinear_fwd", "jp_bilinear_bwd",
+      "jp_affine", "jp_act_fwd", "jp_act_bwd", "jp_act_bwd_bias_ws_floats", "jp_act_bwd_bias", "jp_mul_bcast_c", "jp_mul_bcast_c_bwd_s", "jp_bilinear_fwd", "jp_bilinear_bwd",
       "jp_area_downsample", "jp_fill", "jp_warp_perspective", "jp_softmax_c2", "jp_disp_to_depth",
       "jp_scale_label_assemble", "jp_fill_convex_poly"]),
     ("Small dense algebra of the BEV branch — CVP MLP " + R + "CycledViewProjection.py:33-38,54-67; CCT attention "
