@@ -1796,6 +1796,19 @@ __global__ void border_add_kernel(const float* __restrict__ part, float* __restr
     jp_wave_amax_commit(mx, amax);
 }
 
+// the same fold for the edge pass of an upsampled segment (boundary pixels of the half-resolution map, edge_pix)
+__global__ void edge_add_kernel(const float* __restrict__ part, float* __restrict__ dx, int C, int Nb, int h, int w, int slices) {
+    const long total = (long)C * Nb;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / Nb), b = (int)(i - (long)m * Nb);
+        const InPixSt px = edge_pix(b, Nb, h, w);
+        if (!px.valid) continue;
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += part[(size_t)k * total + i];
+        dx[((size_t)px.img * C + m) * h * w + px.y * w + px.x] += s;
+    }
+}
+
 template <int KH>
 struct WgradBT {  // B[k=pixel][n=(tap,ci)], any source layout (per-element decode)
     static constexpr bool ALONG_K = true;
@@ -2690,9 +2703,10 @@ inline bool seg_aligned(int c0, int c1, int c2) {   // every segment end except 
 int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
                       const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int act, int reflect,
                       hipStream_t st, int accumulate = 0);
-int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
-                        int up2, const float* dy, float* dw, int N, int H, int W, int Cout, int reflect,
-                        hipStream_t st);
+long jp_conv_small_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int single_full_res);
+int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
+                        const float* dy, float* dw, int N, int H, int W, int Cout, int reflect, hipStream_t st, float* ws,
+                        long ws_floats);
 // conv_c16.hip: direct kernels for the 16 / 32-channel 3x3 layers of the BEV decoder
 bool jp_c16_ok(int Cin, int Cout, int KH, int stride, int pad, int pad_mode, int H, int W);
 int jp_c16_fwd(const float* x, int up, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int H, int W, int act,
@@ -3077,7 +3091,7 @@ static void border_pass(const PackA& a, const float* dy, float* dx, int C, int C
     static const bool via_ws = [] { const char* e_ = getenv("JP_BORDER_WS"); return !(e_ && e_[0] == '0'); }();
     const int chunks = Kp / KC;
     const int wsl = (int)std::max<long>(1, std::min<long>(std::min<long>(4, chunks / 9), jp_cdiv(512, btiles)));
-    if (via_ws && split_ws && wsl > 1 && C > 4) {      // (a one-row launch -- the disparity channel -- gains nothing from slices)
+    if (via_ws && split_ws && wsl > 1) {      // (also the one-row launches -- the disparity channel: its slices met in float atomics until round 6)
         const int wkps = jp_cdiv(jp_cdiv(Kp, wsl), KC) * KC, nsl = jp_cdiv(Kp, wkps);
         WgradEpiWS es{split_ws, C, Nb};
         launch_auto(a, bb, es, C, Nb, Kp, nsl, wkps, st);
@@ -3284,7 +3298,9 @@ extern "C" int jp_conv2d_dgrad_src3_ok(int c0, int up0, int c1, int up1, int c2,
 // scratch for jp_conv2d_dgrad_src3's `split_ws`: <= 4 K slices of the widest full-resolution segment's border pass
 extern "C" long jp_conv2d_dgrad_src3_split_floats(int c0, int up0, int c1, int up1, int c2, int up2, int N, int H, int W) {
     const int cm = std::max(std::max(up0 ? 0 : c0, up1 ? 0 : c1), up2 ? 0 : c2);
-    return 4L * cm * N * (2L * H + 2L * W);
+    const int cu = std::max(std::max(up0 ? c0 : 0, up1 ? c1 : 0), up2 ? c2 : 0);
+    // <= 4 slices of a full-resolution segment's border pass, <= 8 slices of the upsampled segment's edge pass (N * (H + W) pixels)
+    return std::max(4L * cm * N * (2L * H + 2L * W), 8L * cu * N * ((long)H + W));
 }
 
 extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0, int c0, int up0, int acc0, float* dx1,
@@ -3383,6 +3399,17 @@ extern "C" int jp_conv2d_dgrad_src3(const float* dy, const float* w, float* dx0,
             const int bsp = (int)std::max<long>(border_splits(btiles, KpU / KC), std::min<long>(4, jp_cdiv(256, btiles)));
             const int bkps = jp_cdiv(jp_cdiv(KpU, bsp), KC) * KC;
             be.split = jp_cdiv(KpU, bkps) > 1;
+            if (be.split && split_ws) {
+                // K slices to scratch, then one fixed-order fold into dx (round 6: the slices met in float atomics -- run-dependent last
+                // bits in the gradient of the upsampled segment, which the whole coarser decoder level inherits)
+                const int nsl = std::min(jp_cdiv(KpU, bkps), 8);
+                const int wkps = jp_cdiv(jp_cdiv(KpU, nsl), KC) * KC, ns2 = jp_cdiv(KpU, wkps);
+                WgradEpiWS es{split_ws, C, Nb};
+                launch_auto(a, bb, es, C, Nb, KpU, ns2, wkps, st);
+                const long total = (long)C * Nb;
+                hipLaunchKernelGGL(edge_add_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, split_ws, dx, C,
+                                   Nb, h2, w2, ns2);
+            } else
             launch_auto(a, bb, be, C, Nb, KpU, jp_cdiv(KpU, bkps), bkps, st);
         }
         coff += C;
@@ -3410,7 +3437,8 @@ static int wgrad_impl(const float* x0, int c0, int up0, const float* x1, int c1,
         JP_LAUNCH_CHECK();
     }
     if (whole && small_head(Cin, Cout, KH, stride, pad)) {
-        jp_conv_small_wgrad(x0, c0, up0, x1, c1, up1, x2, c2, up2, dy, dw, N, H, W, Cout, pad_mode == JP_PAD_REFLECT, st);
+        jp_conv_small_wgrad(x0, c0, up0, x1, c1, up1, x2, c2, up2, dy, dw, N, H, W, Cout, pad_mode == JP_PAD_REFLECT, st, ws,
+                            ws ? ws_floats : 0);
         JP_LAUNCH_CHECK();
     }
     WgradA a{dy, Cout, (int)npix, OH * OW};
@@ -3735,6 +3763,8 @@ extern "C" long jp_conv2d_wgrad_src3_ws_floats(int c0, int up0, int c1, int up1,
     if (c1 == 0 && c2 == 0 && jp_c16_ok(c0, Cout, KH, stride, pad, pad_mode, H, W)) return jp_c16_wgrad_ws_floats(N, c0, Cout, H, W);
     // disparity head on an upsampled source: the gathered dY sums + the workgroups' partial sums (fixed-order fold)
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) return jp_up_head_wgrad_ws_floats(N, c0, H / 2, W / 2);
+    if (small_head(c0 + c1 + c2, Cout, KH, stride, pad))
+        return jp_conv_small_wgrad_ws_floats(N, c0 + c1 + c2, H, W, Cout, c1 == 0 && c2 == 0 && !up0);
     if (!wgrad_segments_ok(c0, up0, c1, up1, c2, up2, N, H, W, Cout, KH, stride, pad, pad_mode)) return 0;
     const int cs[3] = {c0, c1, c2}, us[3] = {up0, up1, up2};
     const long cap = 48L << 20;
@@ -3768,6 +3798,7 @@ extern "C" long jp_conv2d_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long npix = (long)N * OH * OW, cap = 32L << 20;
     if (jp_c16_ok(Cin, Cout, KH, stride, pad, 0, H, W)) return jp_c16_wgrad_ws_floats(N, Cin, Cout, H, W);
+    if (small_head(Cin, Cout, KH, stride, pad)) return jp_conv_small_wgrad_ws_floats(N, Cin, H, W, Cout, 1);
     W7Plan w7;
     if (w7_plan(N, Cin, H, W, Cout, KH, stride, pad, cap, &w7)) return w7.need;
     W1Plan w1;

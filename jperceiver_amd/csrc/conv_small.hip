@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TPB) void conv_small_fwd_kernel(Src3s src, const fl
 template <int CO>
 __global__ __launch_bounds__(TPB) void conv_small_wgrad_kernel(Src3s src, const float* __restrict__ dy,
                                                                float* __restrict__ dw, int Cin, int chunk,
-                                                               int reflect) {
+                                                               int reflect, float* __restrict__ part) {
     __shared__ float red[4][CO * 9];
     const int ci = blockIdx.y, img = blockIdx.z;
     const int HW = src.H * src.W;
@@ -126,7 +126,9 @@ __global__ __launch_bounds__(TPB) void conv_small_wgrad_kernel(Src3s src, const 
         const int i = threadIdx.x;
         const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
         const int c = i / 9, t = i - c * 9;
-        atomicAdd(dw + ((size_t)c * Cin + ci) * 9 + t, s);
+        // part: [workgroup (img, x-block)][ci][CO * 9] partial sums, folded in a fixed order by conv_small_wgrad_fold_kernel
+        if (part) part[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * Cin + ci) * (CO * 9) + i] = s;
+        else atomicAdd(dw + ((size_t)c * Cin + ci) * 9 + t, s);
     }
 }
 
@@ -137,7 +139,7 @@ template <int CO>
 __global__ __launch_bounds__(TPB) void conv_small_wgrad_tiled_kernel(const float* __restrict__ x,
                                                                      const float* __restrict__ dy,
                                                                      float* __restrict__ dw, int Cin, int H, int W,
-                                                                     int reflect) {
+                                                                     int reflect, float* __restrict__ part) {
     constexpr int TW = 64, TH = 16, PW = TW + 2, PH = TH + 2, BAND = 64;
     __shared__ float tile[PH * PW];
     __shared__ float red[4][CO * 9];
@@ -205,8 +207,20 @@ __global__ __launch_bounds__(TPB) void conv_small_wgrad_tiled_kernel(const float
         const int i = threadIdx.x;
         const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
         const int c = i / 9, t = i - c * 9;
-        atomicAdd(dw + ((size_t)c * Cin + ci) * 9 + t, s);
+        // part: [workgroup (img, x-block)][ci][CO * 9] partial sums, folded in a fixed order by conv_small_wgrad_fold_kernel
+        if (part) part[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * Cin + ci) * (CO * 9) + i] = s;
+        else atomicAdd(dw + ((size_t)c * Cin + ci) * 9 + t, s);
     }
+}
+
+// dw[c][ci][t] += sum over the workgroups (in index order) of part[wg][ci][c * 9 + t]
+__global__ void conv_small_wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cin, int CO, int nwg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * CO * 9) return;
+    const int ci = i / (CO * 9), r = i - ci * (CO * 9), c = r / 9, t = r - c * 9;
+    float s = 0.f;
+    for (int b = 0; b < nwg; ++b) s += part[((size_t)b * Cin + ci) * (CO * 9) + r];
+    dw[((size_t)c * Cin + ci) * 9 + t] += s;
 }
 
 Src3s make_src(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2, int up2,
@@ -600,14 +614,34 @@ int jp_conv_small_fwd(const float* x0, int c0, int up0, const float* x1, int c1,
     return 0;
 }
 
+static void small_wgrad_grid(int Cin, int N, int H, int W, bool tiled, dim3* grid, int* chunk) {
+    if (tiled) { *grid = dim3(jp_cdiv(H, 64), Cin, N); *chunk = 0; return; }
+    // chunks so that ~2k blocks stream the input, >= 4k pixels each
+    int chunks = std::max(1, 2048 / std::max(1, Cin * N));
+    chunks = std::min(chunks, std::max(1, H * W / 4096));
+    *chunk = jp_cdiv(jp_cdiv(H * W, chunks), TPB) * TPB;
+    *grid = dim3(jp_cdiv(H * W, *chunk), Cin, N);
+}
+// scratch with which the workgroups' partial sums are folded in a fixed order (bit-reproducible) instead of meeting in float atomics
+long jp_conv_small_wgrad_ws_floats(int N, int Cin, int H, int W, int Cout, int single_full_res) {
+    dim3 g;
+    int chunk;
+    small_wgrad_grid(Cin, N, H, W, single_full_res && H >= 2 && W >= 2, &g, &chunk);
+    return (long)g.x * g.z * Cin * std::min(std::max(Cout, 1), 4) * 9;
+}
 int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c1, int up1, const float* x2, int c2,
                         int up2, const float* dy, float* dw, int N, int H, int W, int Cout, int reflect,
-                        hipStream_t st) {
+                        hipStream_t st, float* ws, long ws_floats) {
     const int Cin = c0 + c1 + c2;
     const Src3s src = make_src(x0, c0, up0, x1, c1, up1, x2, c2, up2, H, W);
-    if (src.nseg == 1 && src.s[0].sh == 0 && H >= 2 && W >= 2) {   // single full-resolution source: LDS-tiled kernel
-        const dim3 gt(jp_cdiv(H, 64), Cin, N);
-#define JP_GT(CO) hipLaunchKernelGGL((conv_small_wgrad_tiled_kernel<CO>), gt, dim3(TPB), 0, st, src.s[0].p, dy, dw, Cin, H, W, reflect)
+    const bool tiled = src.nseg == 1 && src.s[0].sh == 0 && H >= 2 && W >= 2;   // single full-resolution source: LDS-tiled kernel
+    const int CO = Cout <= 3 ? std::max(Cout, 1) : 4;
+    dim3 grid;
+    int chunk;
+    small_wgrad_grid(Cin, N, H, W, tiled, &grid, &chunk);
+    float* part = (ws && ws_floats >= (long)grid.x * grid.z * Cin * CO * 9) ? ws : nullptr;
+    if (tiled) {
+#define JP_GT(COv) hipLaunchKernelGGL((conv_small_wgrad_tiled_kernel<COv>), grid, dim3(TPB), 0, st, src.s[0].p, dy, dw, Cin, H, W, reflect, part)
         switch (Cout) {
             case 1: JP_GT(1); break;
             case 2: JP_GT(2); break;
@@ -615,21 +649,18 @@ int jp_conv_small_wgrad(const float* x0, int c0, int up0, const float* x1, int c
             default: JP_GT(4); break;
         }
 #undef JP_GT
-        return 0;
-    }
-    // chunks so that ~2k blocks stream the input, >= 4k pixels each
-    int chunks = std::max(1, 2048 / std::max(1, Cin * N));
-    chunks = std::min(chunks, std::max(1, H * W / 4096));
-    const int chunk = jp_cdiv(jp_cdiv(H * W, chunks), TPB) * TPB;
-    const dim3 grid(jp_cdiv(H * W, chunk), Cin, N);
-#define JP_GO(CO) hipLaunchKernelGGL((conv_small_wgrad_kernel<CO>), grid, dim3(TPB), 0, st, src, dy, dw, Cin, chunk, reflect)
-    switch (Cout) {
-        case 1: JP_GO(1); break;
-        case 2: JP_GO(2); break;
-        case 3: JP_GO(3); break;
-        default: JP_GO(4); break;
-    }
+    } else {
+#define JP_GO(COv) hipLaunchKernelGGL((conv_small_wgrad_kernel<COv>), grid, dim3(TPB), 0, st, src, dy, dw, Cin, chunk, reflect, part)
+        switch (Cout) {
+            case 1: JP_GO(1); break;
+            case 2: JP_GO(2); break;
+            case 3: JP_GO(3); break;
+            default: JP_GO(4); break;
+        }
 #undef JP_GO
+    }
+    if (part) hipLaunchKernelGGL(conv_small_wgrad_fold_kernel, dim3(jp_cdiv(Cin * CO * 9, 256)), dim3(256), 0, st, part, dw, Cin, CO,
+                                 (int)(grid.x * grid.z));
     return 0;
 }
 
