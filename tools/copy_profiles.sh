@@ -15,3 +15,5 @@ cp $S/smoke.log $D/${R}_smoke.log
 cp $S/bench_under_rocprof.log $D/${R}_bench_under_rocprof.log
 cp $S/bench_other_configs.jsonl $D/${R}_bench_other_configs.jsonl
 ls -la $D | grep ${R}_
+for f in kernel_stats_320x1024.md critical_path_traced.txt stream_milestones.md copybuffer_count.md amax_log.txt step_repro.log; do [ -f $S/$f ] && cp $S/$f $D/${R}_$f; done
+ls -la $D | grep ${R}_

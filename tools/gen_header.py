@@ -24,7 +24,12 @@ GROUPS = [
      "Measured against float64 on layer data the rms error is 0.62-1.00 x the exact-fp32 MFMA kernels' (profiles/r05_fp16x2_accuracy_vs_f64.md; "
      "tests/test_split_accuracy_gpu.py holds it to 1.25 x and every output to 2^-19 sum|a||b|; tools/split_study.py: the split error is 3-4 x "
      "below the fp32 accumulation's own rounding).  It is an error relative to the tensor's largest magnitude, not to each element: outputs "
-     "that depend only on values > 2^29 below their tensor's largest lose relative precision.  RANGE EDGES "
+     "that depend only on values > 2^29 below their tensor's largest lose relative precision.  MEASURED LIMITS on the GPU kernels "
+     "(tests/test_split_accuracy_gpu.py::test_split_accuracy_where_one_scale_per_tensor_differs_from_fp32, profiles/r06_split_outliers.md; "
+     "8 x 128 -> 128 3x3 @64^2 next to the exact-fp32 kernels): one activation 10^6 x the median costs the outputs that do NOT read it 1.6 x "
+     "(forward) / 2.7 x (weight gradient) the rms error of the fp32 accumulation; a channel whose data all sits 2^20 below its tensor's "
+     "largest has ITS weight gradients carried to 7e-6 relative rms (fp32: 3e-7); log-normal gradients (sigma 3 / 4), 10^4 outliers, a "
+     "filter 2^12 above the rest: no further from float64 than the exact-fp32 kernels.  RANGE EDGES "
      "(test_split_range_edges_match_documented_behaviour): Inf / NaN inputs and finite ones with |x| >= 2^100 take no part in the scale and "
      "make exactly the outputs that read them NaN (an fp32 convolution yields +-Inf for an Inf input); everything else is bit-identical to "
      "the run without them.  Tensors of tiny values are lifted by their scale (2^-120 inputs: full accuracy).  The 7x7 stem and the stride-2 "
