@@ -394,16 +394,21 @@ def secondary_figure(dev, B, log, steps=6, warmup=2):
     try:
         frames = [0, -1, 1]
         optd = make_opt(B, 320, 1024, frames, layout_branch=False)
+        # 921 launches of ~28 us per step: on a box with a slow host this workload is launch-bound (258 vs 304 images/s measured on
+        # two boxes of the pool with the same tree), so -- like the one-image configs -- both issue modes are timed in the warm-up
+        # and the faster one is kept (the captured hipGraph replays the same kernels, bit for bit: tests/test_step_graph_gpu.py)
         runner, batch = build_runner(optd, dev, 1, 0, dict(B=B, height=320, width=1024, frame_ids=frames, occ=256,
-                                                           full_hw=(375, 1242), split="odometry", seed=1))
-        dt, out, _ = timed_steps(runner, batch, steps, warmup, 1, dev, lambda m: None)
+                                                           full_hw=(375, 1242), split="odometry", seed=1), step_graph=True)
+        calib = {}
+        dt, out, _ = timed_steps(runner, batch, steps, max(warmup, 3), 1, dev, lambda m: None, calibrate=calib)
         ms = dt / steps * 1e3
         res = {"workload": f"SECONDARY (not the headline): 1024(W)x320(H), frames {frames}, {B} images/GPU, "
                            "depth + pose + CGT warp + photometric/SSIM/automask + smoothness + scale losses, backward, "
                            "clip + Adam; BEV-layout branch disabled (the reference's CVP/CCT need square inputs)",
                "parity": "tests/test_subpath_320x1024_gpu.py (reference-generated fixture at 320x1024 + oracle on this workload)",
                "value": round(B * steps / dt, 3), "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps,
-               "warmup": warmup, "loss": float(out["log_vars"]["loss"])}
+               "warmup": max(warmup, 3), "loss": float(out["log_vars"]["loss"]), "step_graph": bool(runner.step_graph),
+               "step_graph_calibration": calib}
         log(f"secondary figure: {res['value']} images/s ({res['ms_per_step']} ms/step) at 1024x320 without the layout branch")
         return res
     except Exception as e:     # the headline must not depend on the secondary figure

@@ -47,6 +47,22 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// Statistics that arrive as partial sums from the producing convolution's epilogue (igemm_p9s.h; conv_stats[(c * 2 + {0, 1}) * parts + p],
+// fp32 sums over <= 128 pixels each): one workgroup per channel folds parts [p0, p0 + np) in double, in a fixed order, into the layout
+// bn_apply reads with S = 1.  Replaces bn_stats_kernel's pass over the tensor (round 6).
+__global__ __launch_bounds__(TPB) void bn_stats_fold_kernel(const float* __restrict__ conv_stats, double* __restrict__ sums, int parts,
+                                                            int p0, int np) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const float* a = conv_stats + ((size_t)c * 2 + 0) * parts + p0;
+    const float* b = conv_stats + ((size_t)c * 2 + 1) * parts + p0;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < np; i += TPB) { s += (double)a[i]; q += (double)b[i]; }
+    s = jp_block_sum_d(s, sm);
+    q = jp_block_sum_d(q, sm);
+    if (threadIdx.x == 0) { sums[2 * c] = s; sums[2 * c + 1] = q; }
+}
+
 // One wave of every apply workgroup folds its channel's partial sums (fixed order -> every workgroup of a channel gets
 // the same bits): mean / invstd, and -- by image 0's first workgroup only -- the saved statistics for backward and the
 // running-stat momentum update (applied n_updates times: the reference evaluates the layout branch twice per iteration,
@@ -545,17 +561,25 @@ extern "C" long jp_bn_ws_doubles(int N, int C, int HW) {
 extern "C" int jp_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                                float* y, float* running_mean, float* running_var, float* save_mean,
                                float* save_invstd, double* ws, int N, int C, int HW, float momentum, float eps,
-                               int relu, int n_updates, float* amax_y, void* stream) {
-    // amax_y: optional magnitude slot (jp_amax_slot_floats floats, see the header); the apply kernel folds max |y| into it
+                               int relu, int n_updates, float* amax_y, const float* conv_stats, int conv_parts, void* stream) {
+    // amax_y: optional magnitude slot (jp_amax_slot_floats floats, see the header); the apply kernel folds max |y| into it.
+    // conv_stats / conv_parts: the partial sums the producing convolution left (jp_conv2d_fwd* bn_stats, *bn_stats_parts > 0) -- the
+    // statistics are then folded from them instead of read off x (NULL / 0: the statistics pass over x runs)
     JP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn_train_fwd: bad dims");
     hipStream_t st = (hipStream_t)stream;
     int CH, chunk;
     chunking(N, C, HW, &CH, &chunk);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
+    int S = N * CH;
+    if (conv_stats && conv_parts > 0) {
+        hipLaunchKernelGGL(bn_stats_fold_kernel, dim3(C), dim3(TPB), 0, st, conv_stats, ws, conv_parts, 0, conv_parts);
+        S = 1;          // one folded (sum, sum of squares) pair per channel
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N * CH), dim3(TPB), 0, st, x, ws, C, HW, CH, chunk);
+    }
     const int gx = std::min(jp_cdiv(HW, 4 * TPB), 64);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, ws, save_mean, save_invstd, running_mean,
-                       running_var, gamma, beta, residual, y, C, HW, relu, (double)N * HW, momentum, eps, n_updates, N * CH,
+                       running_var, gamma, beta, residual, y, C, HW, relu, (double)N * HW, momentum, eps, n_updates, S,
                        reinterpret_cast<unsigned*>(amax_y));
     JP_LAUNCH_CHECK();
 }

@@ -625,6 +625,7 @@ struct FwdEpi {  // y[img][co][pix] = act(acc + bias[co])
     const float* bias;
     int Cout, OHW, act;
     unsigned* amax = nullptr;           // != nullptr: the patch kernels report max |y| here (the entry point's amax_y)
+    float* stats = nullptr;             // != nullptr: BatchNorm statistics partials of y (the entry point's bn_stats), igemm_p9s.h epilogue
     __device__ __forceinline__ St col(int p) const {
         int img = p / OHW;
         return (size_t)img * Cout * OHW + (p - img * OHW);
@@ -2351,6 +2352,19 @@ void launch_p9s(const float* wp, const float* x, E e, int rows, int red, int N, 
     const unsigned* wq = reinterpret_cast<const unsigned*>(wp);
     const float* xam = JP_NS == 2 ? jp_amax_of(x, (long)N * red * H * W, st) : nullptr;
     if constexpr (JP_NS == 2 && jp_has_amax<E>::value) e.amax = jp_take_amax_out(st);       // (every kernel below reports it)
+    if constexpr (jp_has_stats<E>::value) {
+        // BatchNorm statistics in the epilogue: the 4-wave 3x3 kernels only (transposed accumulators: a lane owns one channel, the
+        // sums over its pixels are plain register adds + one cross-half shuffle); partials per channel = pixel tiles x pixel-row waves
+        e.stats = nullptr;
+        if (TAPS == 9 && bmt != 256 && mt_off == 0 && st.ax && st.ax->stats) {
+            const int mode = p9_tile();
+            long tiles;
+            if (bmt == 64) tiles = (mode >= 3 && H % 16 == 0 && (long)N * (H / 16) * (W / 32) >= 256) ? (long)N * (H / 16) * (W / 32) : (long)N * (H / 8) * (W / 32);
+            else tiles = (mode >= 2 && H % 8 == 0 && (long)N * (H / 8) * (W / 32) * jp_cdiv(rows, bmt) >= 256) ? (long)N * (H / 8) * (W / 32) : (long)N * (H / 4) * (W / 32);
+            e.stats = st.ax->stats;
+            st.ax->stats_parts = (int)(tiles * (bmt == 64 ? 4 : 2));
+        }
+    }
 #if JP_NS == 3
     if constexpr (TAPS == 1) {
         const long ntiles = (long)N * (H / 4) * (W / 32), xb = (long)N * red * H * W * 4;
@@ -2760,6 +2774,10 @@ static bool p9sm_wanted(int rows, int red, int N, int H, int W, int KH, int stri
            (long)jp_cdiv(rows, sm->bmt) * N * jp_cdiv(H, sm->tr) * jp_cdiv(W, 32) < 192;
 }
 
+// floats of `bn_stats` scratch for a forward call with OH x OW output maps: 2 sums x Cout x (at most one partial per 2 x 32 output pixels)
+extern "C" long jp_conv2d_fwd_bn_stats_floats(int N, int OH, int OW, int Cout) {
+    return 2L * Cout * N * jp_cdiv(OH, 2) * jp_cdiv(OW, 32);
+}
 extern "C" long jp_conv2d_ws_floats(int Cin, int Cout, int KH, int which) {
     // + 256 rows of slack: the A gather of the last M tile reads (never uses) up to 255 rows past the last tap
     // forward: up to 16 weight planes per channel (parity-class path of fused-upsample segments), 3 padded segments
@@ -2778,10 +2796,16 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
                                   const float* x2, int c2, int up2, const float* w, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int KH, int stride, int pad, int pad_mode, int act,
                                   float* ws, int ws_state, float* split_ws, const float* amax_x0, const float* amax_x1,
-                                  const float* amax_x2, float* amax_y, int* amax_y_done, float* amax_ws, void* stream) {
+                                  const float* amax_x2, float* amax_y, int* amax_y_done, float* amax_ws, float* bn_stats,
+                                  int* bn_stats_parts, void* stream) {
     // ws_state: 0 = pack the weights into ws now; 1 = ws already holds this layer's pack (refreshed by jp_pack_replay)
     // amax_*: operand magnitudes of the fp16 split kernels, see the header (all may be NULL when amax_ws is given)
+    // bn_stats: optional scratch of jp_conv2d_fwd_bn_stats_floats floats for a convolution that feeds a train-mode BatchNorm (no bias, no
+    // activation): the 4-wave 3x3 patch kernels leave per-channel partial sums of y and y^2 there and *bn_stats_parts (host int) = the
+    // partials per channel, to be handed to jp_bn_train_fwd instead of its own pass over y; 0 = the kernel that ran does not (BatchNorm
+    // then reads y itself, as before)
     if (amax_y_done) *amax_y_done = 0;
+    if (bn_stats_parts) *bn_stats_parts = 0;
     JP_CHECK_ARG(x0 && w && y, "conv2d_fwd: null pointer");
     JP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && c0 > 0 && stride >= 1, "conv2d_fwd: bad dims");
     JP_CHECK_ARG(!(pad_mode == JP_PAD_REFLECT && (pad >= H || pad >= W)), "conv2d_fwd: reflect pad >= size");
@@ -2798,7 +2822,8 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
     ax.know(x2, amax_x2);
     ax.ws = amax_ws;
     ax.out = reinterpret_cast<unsigned*>(amax_y);
-    const JpAmaxDone done_flag{amax_y_done, &ax};
+    if (bn_stats && bn_stats_parts && !bias && act == JP_ACT_NONE) ax.stats = bn_stats;
+    const JpAmaxDone done_flag{amax_y_done, &ax, bn_stats_parts};
     const JpCall st((hipStream_t)stream, &ax);
     FwdEpi e{y, bias, Cout, OH * OW, act};
     if (up_head(c0, up0, c1, c2, Cout, KH, stride, pad, pad_mode, H, W)) {
@@ -3041,9 +3066,10 @@ extern "C" int jp_conv2d_fwd_src3(const float* x0, int c0, int up0, const float*
 extern "C" int jp_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
                              int W, int Cout, int KH, int stride, int pad, int pad_mode, int act, float* ws,
                              int ws_state, float* split_ws, const float* amax_x, float* amax_y, int* amax_y_done, float* amax_ws,
-                             void* stream) {
+                             float* bn_stats, int* bn_stats_parts, void* stream) {
     return jp_conv2d_fwd_src3(x, Cin, 0, nullptr, 0, 0, nullptr, 0, 0, w, bias, y, N, H, W, Cout, KH, stride, pad,
-                              pad_mode, act, ws, ws_state, split_ws, amax_x, nullptr, nullptr, amax_y, amax_y_done, amax_ws, stream);
+                              pad_mode, act, ws, ws_state, split_ws, amax_x, nullptr, nullptr, amax_y, amax_y_done, amax_ws, bn_stats,
+                              bn_stats_parts, stream);
 }
 
 // same for jp_conv2d_dgrad's `split_ws`

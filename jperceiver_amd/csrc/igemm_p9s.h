@@ -127,6 +127,11 @@ template <class E, class = void>
 struct jp_has_amax : std::false_type {};
 template <class E>
 struct jp_has_amax<E, std::void_t<decltype(&E::put_get)>> : std::true_type {};
+// Epilogues with a `stats` member (FwdEpi): BatchNorm statistics of the stored tile (sum, sum of squares per channel) as partials
+template <class E, class = void>
+struct jp_has_stats : std::false_type {};
+template <class E>
+struct jp_has_stats<E, std::void_t<decltype(std::declval<E&>().stats)>> : std::true_type {};
 template <bool SWAP>
 __device__ __forceinline__ jp_f32x16 jp_mfma_bf16_sw(jp_u32x4 a, jp_u32x4 b, jp_f32x16 c) {
 #if JP_NS == 2
@@ -448,6 +453,30 @@ __device__ __forceinline__ void jp_igemm_p9s_body(
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= osc;
+    }
+    if constexpr (VEC && jp_has_stats<Epi>::value) {
+        // BatchNorm statistics of what this wave is about to store (convolutions that feed a train-mode BatchNorm: no bias, no
+        // activation, so the stored value IS the accumulator): lane l31 owns channel m, its 16 * NJ registers are that channel's
+        // pixels of this half (lhi) of the tile.  stats[(m * 2 + {0, 1}) * parts + part], part = pixel tile * WN + pixel-row wave:
+        // every (channel, part) is written exactly once -- no atomics, folded in a fixed order by bn.hip's bn_stats_fold_kernel.
+        if (epi.stats) {
+            const size_t parts = (size_t)gridDim.x * WN, part = (size_t)nt * WN + wn;     // (nt: this workgroup's pixel tile after the XCD remap)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 = fmaf(v, v, s2); }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const int m = m0 + wm * 64 + i * 32 + l31;
+                if (lhi == 0 && m < M) {
+                    epi.stats[((size_t)m * 2 + 0) * parts + part] = s1;
+                    epi.stats[((size_t)m * 2 + 1) * parts + part] = s2;
+                }
+            }
+        }
     }
     float omx = 0.f;                     // largest |stored value| of this lane (epilogues that report it)
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

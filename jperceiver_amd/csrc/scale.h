@@ -17,6 +17,8 @@ struct JpAmaxCtx {
     int ws_used = 0;
     unsigned* out = nullptr;        // the caller's amax_y: taken by the launcher whose kernel folds it into its epilogue
     bool out_taken = false;
+    float* stats = nullptr;         // the caller's bn_stats scratch (forward): per-(pixel tile, wave) partial sums of y and y^2 per channel,
+    int stats_parts = 0;            // written by the 4-wave 3x3 patch kernels' epilogue; > 0 once a launcher took it (= partials per channel)
     void know(const float* tensor, const float* slot) {
         if (tensor && slot && nh < MAXH) { t[nh] = tensor; a[nh] = slot; ++nh; }
     }
@@ -39,7 +41,11 @@ struct JpCall {
 struct JpAmaxDone {
     int* flag;
     const JpAmaxCtx* c;
-    ~JpAmaxDone() { if (flag) *flag = c->out_taken ? 1 : 0; }
+    int* parts = nullptr;           // forward entry points: *parts = partial sums per channel the epilogue left in bn_stats (0: none)
+    ~JpAmaxDone() {
+        if (flag) *flag = c->out_taken ? 1 : 0;
+        if (parts) *parts = c->stats_parts;
+    }
 };
 
 // Device pointer to a slot holding max |x[0 .. n)|, valid for kernels launched on the call's stream after this: the slot the caller

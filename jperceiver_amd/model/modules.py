@@ -20,6 +20,7 @@ from ..ops import Var, param as P, ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID, P
 
 
 _STEM_FUSE = os.environ.get("JP_STEM_FUSE", "1") != "0"      # bn1 -> relu -> maxpool of the ResNet stems in one pass each way
+_BN_STATS_FUSE = os.environ.get("JP_BN_STATS_FUSE", "1") != "0"   # BatchNorm statistics out of the producing convolution's epilogue (round 6)
 
 
 def _t(v):
@@ -53,11 +54,13 @@ def bn_apply(bn: BatchNorm2d, x: Var, residual=None, relu=False, n_updates=1, gr
     return ops.batchnorm_eval(x, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, residual, relu, bn.eps)
 
 
-def conv_apply(conv: nn.Conv2d, x, stride=None, pad=None, pad_mode=PAD_ZERO, act=ACT_NONE, srcs=None) -> Var:
+def conv_apply(conv: nn.Conv2d, x, stride=None, pad=None, pad_mode=PAD_ZERO, act=ACT_NONE, srcs=None, bn_stats=False) -> Var:
+    """`bn_stats`: the output goes straight into a train-mode BatchNorm (resnet.py:29-45): the convolution's epilogue leaves the
+    statistics' partial sums for it where the kernel that runs the layer can (ops.conv2d)."""
     stride = conv.stride[0] if stride is None else stride
     pad = conv.padding[0] if pad is None else pad
     return ops.conv2d(x, P(conv.weight), P(conv.bias) if conv.bias is not None else None, stride, pad, pad_mode, act,
-                      srcs)
+                      srcs, bn_stats=bn_stats)
 
 
 # ------------------------------------------------------------------------------------------- layers.py
@@ -217,8 +220,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def _fwd(self, x, n_updates=1, groups=1):
-        out = bn_apply(self.bn1, conv_apply(self.conv1, x), relu=True, n_updates=n_updates, groups=groups)
-        out = conv_apply(self.conv2, out)
+        tr = self.bn1.training and _BN_STATS_FUSE
+        out = bn_apply(self.bn1, conv_apply(self.conv1, x, bn_stats=tr), relu=True, n_updates=n_updates, groups=groups)
+        out = conv_apply(self.conv2, out, bn_stats=tr)
         res = x
         if self.downsample is not None:
             res = bn_apply(self.downsample[1], conv_apply(self.downsample[0], x), n_updates=n_updates, groups=groups)

@@ -21,7 +21,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 class Var:
     """A device tensor plus its (lazily allocated) gradient buffer.  `p`: the nn.Parameter a weight Var was made from
     (ops.param) -- conv weights of parameters get persistent packed copies (PackRegistry), raw tensors do not."""
-    __slots__ = ("t", "g", "rg", "p", "amax", "gamax")
+    __slots__ = ("t", "g", "rg", "p", "amax", "gamax", "bnst")
 
     def __init__(self, t: torch.Tensor, rg: bool = False, g: torch.Tensor | None = None, p=None):
         self.t, self.rg, self.g, self.p = t, rg, g, p
@@ -30,6 +30,8 @@ class Var:
         # what ONE producer wrote (dropped as soon as anything is accumulated into g)
         self.amax = None
         self.gamax = None
+        # (scratch, parts): BatchNorm statistics partials the producing convolution's epilogue left (conv2d(..., bn_stats=True))
+        self.bnst = None
 
     def grad_buf(self):
         """-> (buffer, accumulate flag) for kernels that can either write or add."""
@@ -442,7 +444,7 @@ def _new(shape, like: torch.Tensor, dtype=None):
 
 
 # ------------------------------------------------------------------------------------------- conv
-def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, srcs=None) -> Var:
+def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, srcs=None, bn_stats=False) -> Var:
     """nn.Conv2d (+ReflectionPad2d, +bias, +activation epilogue).  `srcs` = [(Var, upsampled?)...] (<=3)
     feeds the conv with the channel-concat of the sources, half-resolution ones being read through a
     fused nearest-2x upsample (depth_decoder.py:68,76-77) — nothing is materialised."""
@@ -477,13 +479,21 @@ def conv2d(x, w: Var, b: Var | None, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT
     x_am = [(_amax_of(srcs[i][0]) if (big and i < len(srcs)) else None) for i in range(3)]
     y_slot = _out_slot(y.device, big)
     y_done = _ct.c_int(0)
+    # bn_stats: this convolution feeds a train-mode BatchNorm -- the 4-wave 3x3 patch kernels leave per-channel partial sums of y and
+    # y^2 in `st_ws` (their epilogue), and BatchNorm folds those instead of reading y once more
+    st_ws, st_parts = None, _ct.c_int(0)
+    if bn_stats and big and KH == 3 and stride == 1 and bt is None and act == ACT_NONE and len(srcs) == 1:
+        st_ws = _new((int(_jplib().fn["jp_conv2d_fwd_bn_stats_floats"](N, OH, OW, Cout)),), w.t)
     _conv_call("jp_conv2d_fwd_src3", w, "fwd", sig, nwf,
                (*s3, w.t, bt, y, N, H, W, Cout, KH, stride, pad, pad_mode, act),
                (ws_s, *x_am, y_slot, _ct.addressof(y_done),
-                _amax_ws(y.device, *(x_am[:len(srcs)] if len(srcs) == 1 else (None,)))))     # (several sources: their slots are folded into the scratch)
+                _amax_ws(y.device, *(x_am[:len(srcs)] if len(srcs) == 1 else (None,))),      # (several sources: their slots are folded into the scratch)
+                st_ws, _ct.addressof(st_parts)))
     del ws_s
     out = Var(y, any(v.rg for v, _ in srcs) or w.rg)
     out.amax = y_slot if y_done.value else None   # max|y| from the kernel's epilogue when a patch kernel ran the layer: the next convolution's scale
+    if st_parts.value > 0:
+        out.bnst = (st_ws, st_parts.value)
 
     def bwd():
         if out.g is None:
@@ -653,11 +663,14 @@ def batchnorm_train(x: Var, gamma: Var, beta: Var, running_mean, running_var, re
     invstd = _new((groups, C), x.t)
     nbw = int(_jplib().fn["jp_bn_ws_doubles"](Ng, C, H * W))
     y_am = _out_slot(y.device, C >= 32)       # max|y| out of the apply kernel: the next convolution's operand scale
+    # statistics partials from the producing convolution's epilogue (one group only: a partial never straddles two images, but the
+    # kernels deal their pixel tiles out in an order of their own)
+    st_ws, st_parts = x.bnst if (x.bnst is not None and groups == 1) else (None, 0)
     for g in range(groups):
         sl = slice(g * Ng, (g + 1) * Ng)
         ws = _new((nbw,), x.t, torch.float64)
         call("jp_bn_train_fwd", x.t[sl], gamma.t, beta.t, residual.t[sl] if residual is not None else None, y[sl], running_mean,
-             running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates, y_am)
+             running_var, mean[g], invstd[g], ws, Ng, C, H * W, momentum, eps, int(relu), n_updates, y_am, st_ws, st_parts)
     out = Var(y, x.rg or gamma.rg or (residual is not None and residual.rg))
     out.amax = y_am
 

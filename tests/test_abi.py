@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_bad_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
-    rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, 0, None, None, None, None, None, None)
+    rc = L.fn["jp_conv2d_fwd"](None, None, None, None, 1, 1, 4, 4, 1, 3, 1, 1, 0, 0, None, 0, None, None, None, None, None, None, None, None)
     assert rc == -1 and "null" in L.last_error()
     rc = L.fn["jp_conv2d_dgrad"](ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 1, 4, 4, 1, 5, 1, 1, 1, 0, None, 0, None,
                                  None, None, None, None, None)
@@ -33,7 +33,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
         # ABI 3: an operand magnitude that is neither passed nor reducible (amax_ws == NULL) is a bad argument, not a hidden allocation
         done = ctypes.c_int(7)
         rc = L.fn["jp_conv2d_fwd"](ctypes.c_void_p(8), ctypes.c_void_p(8), None, ctypes.c_void_p(8), 1, 64, 32, 32, 64, 3, 1, 1, 0, 0, None, 0,
-                                   None, None, None, ctypes.addressof(done), None, None)
+                                   None, None, None, ctypes.addressof(done), None, None, None, None)
         assert rc == -1 and "amax_ws" in L.last_error() and done.value == 0
 
 

@@ -80,7 +80,7 @@ def _conv_direct(x, w, hint=None, want_out=False, amax_ws=True):
     out_slot = _slot() if want_out else None
     done = ctypes.c_int(-1)
     call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, KH, 1, KH // 2, 0, 0, ws, 0, sp, hint, out_slot, ctypes.addressof(done),
-         _amax_ws() if amax_ws else None)
+         _amax_ws() if amax_ws else None, None, None)
     return y, out_slot, done.value
 
 
@@ -139,7 +139,7 @@ def test_amax_out_is_left_alone_by_kernels_that_cannot_report():
     ws = torch.empty(int(L.fn["jp_conv2d_ws_floats"](3, 64, 7, 0)), device=DEV)
     slot = _slot()
     done = ctypes.c_int(-1)
-    call("jp_conv2d_fwd", x, w, None, y, 2, 3, 64, 64, 64, 7, 2, 3, 0, 0, ws, 0, None, None, slot, ctypes.addressof(done), _amax_ws())
+    call("jp_conv2d_fwd", x, w, None, y, 2, 3, 64, 64, 64, 7, 2, 3, 0, 0, ws, 0, None, None, slot, ctypes.addressof(done), _amax_ws(), None, None)
     assert done.value == 0 and _val(slot) == 0.0
     # ... and nothing of the request reaches a later entry point
     d = torch.empty_like(y)
@@ -163,7 +163,7 @@ def test_three_source_forward_folds_the_given_magnitudes():
     def run(am):
         y = torch.empty(N, 128, H, W, device=DEV)
         call("jp_conv2d_fwd_src3", x0, 64, 0, x1, 64, 1, x2, 1, 0, w, None, y, N, H, W, 128, 3, 1, 1, 1, 2, ws, 0, None,
-             *am, None, None, _amax_ws())
+             *am, None, None, _amax_ws(), None, None)
         return y
 
     slots = []

@@ -868,3 +868,38 @@ print("RESULT", h, err, "|".join(names))
     assert "p1l" not in out["0"][2]
     assert out["0"][0] == out["1"][0], "the persistent 1x1 kernel's results differ from the patch kernel's"
     assert out["1"][1] < 2e-5
+
+
+@pytest.mark.parametrize("N,C,H,W,expect", [(8, 64, 128, 128, True),      # ResNet layer1 shape class: 64-row 4-wave tiles (wide)
+                                            (8, 128, 64, 64, True),       # layer2: 128-row 4-wave tiles
+                                            (8, 64, 64, 96, True),        # regular (not wide) 64-row tiles
+                                            (8, 512, 32, 32, True),       # layer4: four 128-row M tiles per pixel tile (XCD-remapped ids)
+                                            (8, 256, 64, 128, False)])    # 256-row 8-wave tiles: no statistics epilogue -> the pass over y
+def test_batchnorm_statistics_from_the_conv_epilogue(N, C, H, W, expect):
+    """Round 6 (VERDICT r03-r05 "BatchNorm folded into the convolutions", resnet.py:29-45): a 3x3 convolution that feeds a train-mode
+    BatchNorm leaves per-channel partial sums of y and y^2 in its epilogue (jp_conv2d_fwd* bn_stats) and jp_bn_train_fwd folds them
+    instead of reading y for the statistics.  Same normalised output, saved statistics and running statistics as the two-pass form
+    (fp32 partial sums in another order: 1e-6), and as float64 on the CPU."""
+    x = Var(rnd(N, C, H, W, seed=11) * 1.7 + 0.2, True)
+    w = Var(rnd(C, C, 3, 3, seed=12) * (9 * C) ** -0.5, True, torch.zeros(C, C, 3, 3, device=DEV))
+    gamma, beta = rnd(C, seed=13) * 0.2 + 1.0, rnd(C, seed=14) * 0.1
+    outs = []
+    for fused in (True, False):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        with recording(Tape()):
+            y = ops.conv2d(x, w, None, 1, 1, ops.PAD_ZERO, ops.ACT_NONE, bn_stats=fused)
+            if fused:
+                assert (y.bnst is not None) == (expect and ops.split_scheme() in (2, 3)), (y.bnst is not None, expect)
+            else:
+                assert y.bnst is None
+            z = ops.batchnorm_train(y, Var(gamma.clone(), True, torch.zeros(C, device=DEV)), Var(beta.clone(), True, torch.zeros(C, device=DEV)),
+                                    rm, rv, relu=True)
+        outs.append((y.t.clone(), z.t.clone(), rm.clone(), rv.clone()))
+    (y1, z1, rm1, rv1), (y0, z0, rm0, rv0) = outs
+    assert torch.equal(y1, y0)                                  # the convolution's output does not depend on the extra epilogue work
+    close(z1, z0, rtol=2e-5, atol=2e-5, msg="normalised output, fused statistics vs the pass over y")
+    close(rm1, rm0, rtol=1e-5, atol=1e-6, msg="running mean")
+    close(rv1, rv0, rtol=1e-5, atol=1e-6, msg="running var")
+    yd = y0.double().cpu()
+    ref = F.relu(F.batch_norm(yd, None, None, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5))
+    close(z1, ref.float(), rtol=1e-4, atol=1e-4, msg="vs float64 batch norm")

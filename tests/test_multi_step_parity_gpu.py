@@ -112,8 +112,8 @@ def test_second_step_matches_oracle(name):
             force["cm_argmax_" + tag] = out["cm_argmax_" + tag].cpu()
         for p in P.values():
             p.grad = None
-        P0 = {n: p.detach().clone() for n, p in P.items()} if step == 2 else None      # (the state step 2 starts from)
-        B0 = {n: b.clone() for n, b in Bf.items()} if step == 2 else None
+        P0 = {n: p.detach().clone() for n, p in P.items()}        # (the state this step starts from: float64 referee, step-2 checks)
+        B0 = {n: b.clone() for n, b in Bf.items()}
         o2, L2 = J.forward(P, Bf, opt, inp, True, masks, noise, label, force)
         tot2 = J.total_loss(L2)
         tot2.backward()
@@ -136,8 +136,9 @@ def test_second_step_matches_oracle(name):
         # pose networks and the coarse decoder levels (the device 1-7 %), and in the total the two fp32 evaluations land 0.4 % and 5 %
         # from float64 by luck of the draw (same picture with the exact -DJP_NS=3 library, and a model built fresh from this state
         # reproduces the continuing model's gradients: tools/debug/second_step_fresh.py -- it is the function, not state).  So:
-        #  (a) total gradient: every parameter within 15 % of its norm and the median parameter within 2.5 % of the fp32 oracle
-        #      (a pack, scale header or counter that did not follow the weights moves EVERY gradient by more than that);
+        #  (a) total gradient: every parameter within 15 % of its norm around the fp32 oracle -- or, failing that, within 20 % of the
+        #      float64 oracle -- and the median parameter within 2.5 % of the fp32 oracle (a pack, scale header or counter that did not
+        #      follow the weights moves EVERY gradient by more than that);
         bad, errs = [], []
         for n, p in named.items():
             r = P[n].grad if n in P else None
@@ -150,7 +151,20 @@ def test_second_step_matches_oracle(name):
                 errs.append(err / (rn + 1e-30))
             if err > 0.15 * rn + 2e-5 * abs(float(tot2)):
                 bad.append((n, err, rn))
-        assert not bad, f"{name} step {step}: gradients more than 15 % off the oracle's: {bad[:8]}"
+        if bad:
+            # The fp32 CPU oracle is itself a draw: on some hosts of the pool its pose-network gradients at B = 8, 1024^2 land 88 % from the
+            # device's while both sit ~2 % from float64 on others (the photometric terms' cancellation, thread-count dependent summation
+            # order).  Referee as in the one-step tests: what misses the band around the fp32 oracle must be within 20 % of FLOAT64.
+            g64 = _f64_grads(c, opt, P0, B0, inp, masks, noise, label, force)
+            worse = []
+            for n, err, rn in bad:
+                r64 = g64[n]
+                eh = float((named[n].grad.detach().cpu().double() - r64).norm() / (r64.norm() + 1e-30))
+                ec = float((P[n].grad.double() - r64).norm() / (r64.norm() + 1e-30))
+                print(f"referee {name} step {step} {n}: hip {eh:.4f} fp32-oracle {ec:.4f}")
+                if eh > 0.2:
+                    worse.append((n, eh, ec))
+            assert not worse, f"{name} step {step}: gradients more than 20 % off the float64 oracle (name, hip, cpu32): {worse[:8]}"
         errs.sort()
         assert errs[len(errs) // 2] <= 2.5e-2, (name, step, errs[len(errs) // 2])     # measured: 0.3 % (512^2) .. 1.4 % (B = 8, 1024^2, step 2)
         if step == 2:

@@ -17,6 +17,6 @@ for (N, Cin, H, W, Cout) in [(8,256,256,256,256),(8,256,256,256,128),(8,256,256,
         for _ in range(n): fn(1)
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
-    tf = t(lambda st: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, s, p, pm, 2, wsf, st, None, None, None, None, aws))
+    tf = t(lambda st: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, s, p, pm, 2, wsf, st, None, None, None, None, aws, None, None))
     gb = (x.numel()+y.numel())*4/1e9
     print(f"{Cin}->{Cout} @{H}: {tf:.3f} ms {flops/tf/1e9:.1f} TF, min HBM {gb:.2f} GB -> {gb/tf:.2f} TB/s", flush=True)

@@ -29,7 +29,7 @@ def run():
         for t, an in zip(a, names):
             # (scratch arguments hold uninitialised slack: not results)
             # (float64 arguments are sums accumulated with double atomics: their last bits vary, what is derived from them in fp32 does not)
-            if isinstance(t, torch.Tensor) and t.numel() > 0 and t.dtype != torch.float64 and an not in ("ws", "split_ws", "amax_ws", "part", "bias_ws"):
+            if isinstance(t, torch.Tensor) and t.numel() > 0 and t.dtype != torch.float64 and an not in ("ws", "split_ws", "amax_ws", "part", "bias_ws", "bn_stats", "conv_stats"):
                 sums.append((an, t.reshape(-1).view(torch.uint8).sum(dtype=torch.int64)))
         rec.append((name, tuple(tuple(t.shape) for t in a if isinstance(t, torch.Tensor)), sums))
     for m in (ops, ops_loss, netmod, rt, mods):

@@ -22,7 +22,7 @@ def t(f, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 p = K // 2
-for name, f in (("fwd", lambda: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, 1, p, mode, 0, wsf, 0, None, None, None, None, aws)),
+for name, f in (("fwd", lambda: call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, K, 1, p, mode, 0, wsf, 0, None, None, None, None, aws, None, None)),
                 ("dgrad", lambda: call("jp_conv2d_dgrad", dy, w, dx, N, Cin, H, W, Cout, K, 1, p, mode, 0, wsd, 0, None, None, None, None, aws)),
                 ("wgrad", lambda: call("jp_conv2d_wgrad", x, dy, dw, N, Cin, H, W, Cout, K, 1, p, mode, 0, wsw, nws, None, None, aws))):
     ms = t(f)

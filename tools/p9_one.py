@@ -9,8 +9,8 @@ L = lib()
 x = torch.randn(N, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
 y = torch.empty(N, Cout, H, W, device="cuda")
 ws = torch.empty(int(L.fn["jp_conv2d_ws_floats"](Cin, Cout, 3, 0)), device="cuda")
-call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, 3, 1, 1, pm, 2, ws, 0, None, None, None, None, aws)
+call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, 3, 1, 1, pm, 2, ws, 0, None, None, None, None, aws, None, None)
 for _ in range(reps):
-    call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, 3, 1, 1, pm, 2, ws, 1, None, None, None, None, aws)
+    call("jp_conv2d_fwd", x, w, None, y, N, Cin, H, W, Cout, 3, 1, 1, pm, 2, ws, 1, None, None, None, None, aws, None, None)
 torch.cuda.synchronize()
 print("done")
