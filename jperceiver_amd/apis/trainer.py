@@ -242,6 +242,7 @@ class CapturedStep:
         self.base_dev = torch.zeros(1, device=dev, dtype=torch.int64)
         bns = self._bn_modules()
         saved = (arena.step_count, ops._EPOCH[0], [b._pending for b in bns])
+        n_partials0 = getattr(arena, "_n_partials", 0)     # host-side counter of the norm partials: the capture must not move it
         import gc
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -274,6 +275,9 @@ class CapturedStep:
         self.rng_calls = cap.calls
         self.bn_delta = [(b, b._pending - p0) for b, p0 in zip(bns, saved[2])]
         # the capture executed nothing: take the host-side counters back
+        if hasattr(arena, "_n_partials"):
+            # (graph B bakes the partials' layout of THIS capture in; an eager step must find the counter where it left it)
+            arena._n_partials = n_partials0
         arena.step_count, ops._EPOCH[0] = saved[0], saved[1]
         for b, p0 in zip(bns, saved[2]):
             b._pending = p0
@@ -316,6 +320,8 @@ class CapturedStep:
         if self._h2d_done is None:
             self._h2d_done = torch.cuda.Event()
         self._h2d_done.record()
+        # ORDER IS PART OF THE CONTRACT: graph B was captured into graph A's memory pool (its temporaries reuse A's), so it may only ever
+        # be replayed after A and the exchange of the same iteration -- never alone, never twice
         self.graph.replay()
         if self.world > 1:
             self._exchange()
