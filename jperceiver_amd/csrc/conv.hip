@@ -3869,16 +3869,23 @@ extern "C" int jp_pack_record_end(void) {
 }
 
 // jobs: DEVICE copy of `njobs` records whose `begin` fields hold the exclusive prefix sum of `total`; total_elems = the sum.
-extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, void* stream) {
+// 1 if a recorded job of this mode is re-packed by the LDS-staged split-pack kernel (its elements are skipped by the generic kernel):
+// a caller that puts those jobs BEHIND the others in the table can tell jp_pack_replay where the generic kernel's range ends
+extern "C" int jp_pack_mode_is_split(int mode) { return (mode == PACK_SPLIT || mode == PACK_SPLITSEG) ? 1 : 0; }
+// generic_elems: elements (begin of the first split-pack job) the generic kernel has to walk when the split-pack jobs are the tail of
+// the table; <= 0 or >= total_elems: the whole range (round 6: the generic kernel spent most of its 0.36 ms at the head of every step
+// deciding, four elements at a time, that a range belongs to the other kernel)
+extern "C" int jp_pack_replay(const void* jobs, int njobs, long total_elems, long generic_elems, void* stream) {
     JP_CHECK_ARG(jobs && njobs > 0 && total_elems > 0, "pack_replay: bad args");
+    const long gen = (generic_elems > 0 && generic_elems < total_elems) ? generic_elems : total_elems;
     if (JP_PACK_HDR)    // headers (weight scales) of the fp16 split packs first: the pack kernels below read them
     {
         hipLaunchKernelGGL(pack_scale_zero_kernel, dim3((njobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
         hipLaunchKernelGGL(pack_scale_reduce_kernel, dim3(PSL, njobs), dim3(256), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
         hipLaunchKernelGGL(pack_scale_finish_kernel, dim3((njobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const JpPackJob*)jobs, njobs);
     }
-    hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((total_elems + 4095) / 4096, 16384)), dim3(256), 0,
-                       (hipStream_t)stream, (const JpPackJob*)jobs, njobs, total_elems);
+    hipLaunchKernelGGL(pack_replay_kernel, dim3((int)std::min<long>((gen + 4095) / 4096, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, (const JpPackJob*)jobs, njobs, gen);
     // the split-bf16 packs of the table: LDS-staged, grid-stride over their work items (a block without an item returns)
     // (its job-prefix table lives in LDS: 2048 jobs per launch -- a model has a few hundred; longer tables go in slices)
     for (int off = 0; off < njobs; off += 2048)

@@ -264,6 +264,15 @@ class Baseline(nn.Module):
                 pose_out[("translation", 0, f)] = tr.t.view(B, 1, 1, 3)
 
         if side is not None:
+            # The side stream reads the batch in its BACKWARD too (K in the pose gradient, the layout labels in the layout losses'
+            # backward, the image in the layout encoder's first weight gradient), and the caller may drop the batch as soon as the
+            # forward returns: the tape's closures then hold the last references, each released the moment its node has been
+            # ENQUEUED -- while the side stream may still be tens of milliseconds away from running it.  Without this the caching
+            # allocator hands such a block to the next main-stream scratch and K is overwritten before the pose backward reads it
+            # (tests/probe_pose_branch.py: pose gradients 0.4 x / ~0 x their value in runs whose batch was a temporary).
+            for t in inputs.values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
             side.wait_stream(main)                      # inputs (and last step's parameter update) are visible
             with torch.cuda.stream(side), ops.recording(pose_tape):
                 pose_branch()
@@ -333,6 +342,9 @@ class Baseline(nn.Module):
             # AFTER the depth decoder's backward, i.e. well after the side stream was started) adds them to the real ones.
             F_s = F if _LAYOUT_ENC_SIDE else Var(F.t, True)          # F itself lives on the side stream in that mode
             f4_s = Var(feats[-1].t, True)
+            feats[-1].t.record_stream(side)                          # (main-stream tensors the heads' forward AND backward read there)
+            if F_s is not F:
+                F.t.record_stream(side)
             f4_main = feats[-1]
 
             heads_done = torch.cuda.Event()

@@ -254,11 +254,16 @@ class PackRegistry:
             jobs = np.concatenate([e.jobs for e in live]) if live else None
             if jobs is None or len(jobs) == 0:
                 return False
+            # the split packs (re-packed by their own LDS-staged kernel) go to the tail of the table: the generic kernel then walks
+            # only the range in front of them (jp_pack_replay generic_elems)
+            is_split = _jplib().fn["jp_pack_mode_is_split"]
+            tail = np.array([bool(is_split(int(m))) for m in jobs["mode"]])
+            jobs = np.concatenate([jobs[~tail], jobs[tail]])
             # jp_pack_replay walks the concatenated range in groups of 4 elements: every job begins on a multiple of 4
             padded = (jobs["total"] + 3) // 4 * 4
             jobs["begin"] = np.concatenate([[0], np.cumsum(padded)[:-1]])
             dev = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
-            self.table = (dev, len(jobs), int(padded.sum()), live)
+            self.table = (dev, len(jobs), int(padded.sum()), live, int(padded[:int((~tail).sum())].sum()))
         return True
 
     def refresh_all(self):
@@ -280,8 +285,8 @@ class PackRegistry:
             return
         if not self.ensure_table():
             return
-        dev, n, total, live = self.table
-        call("jp_pack_replay", dev, n, total)
+        dev, n, total, live, generic = self.table
+        call("jp_pack_replay", dev, n, total, generic)
         for e in live:
             p = e.param
             if p is not None:

@@ -152,9 +152,10 @@ def test_second_step_matches_oracle(name):
             if err > 0.15 * rn + 2e-5 * abs(float(tot2)):
                 bad.append((n, err, rn))
         if bad:
-            # The fp32 CPU oracle is itself a draw: on some hosts of the pool its pose-network gradients at B = 8, 1024^2 land 88 % from the
-            # device's while both sit ~2 % from float64 on others (the photometric terms' cancellation, thread-count dependent summation
-            # order).  Referee as in the one-step tests: what misses the band around the fp32 oracle must be within 20 % of FLOAT64.
+            # Referee as in the one-step tests: what misses the band around the fp32 oracle must be within 20 % of FLOAT64 (the
+            # photometric terms cancel, so either fp32 evaluation may land a few percent out).  History: the "pose networks 88-100 %
+            # off on some boxes" this branch once reported was NOT the oracle's noise but a real lifetime bug of the temporary batch
+            # on the side stream (DESIGN section 1 "Streams", tests/test_batch_lifetime_gpu.py); since the fix the branch is not taken.
             g64 = _f64_grads(c, opt, P0, B0, inp, masks, noise, label, force)
             worse = []
             for n, err, rn in bad:

@@ -15,7 +15,8 @@ GROUPS = [
      + R + "depth_decoder.py:68,76-77).  pad_mode 0=zero 1=reflect; act 0=none 1=relu 2=leaky_relu(0.01) 3=sigmoid.  ws / ws_state: caller scratch for the packed weights "
      "(jp_conv2d_ws_floats) and whether it already holds this layer's pack (1) or must be packed by this call (0); packs recorded with "
      "jp_pack_record_begin/end can be refreshed for the whole model by one jp_pack_replay launch per step (job table in device memory; every job's `begin` is the running sum of the totals rounded up to a multiple of 4, "
-     "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements).  "
+     "total_elems the rounded grand total: the replay kernel works on groups of 4 consecutive elements; generic_elems: where the jobs of the "
+     "LDS-staged split-pack kernel -- jp_pack_mode_is_split(job.mode) -- begin when the caller put them at the tail of the table, 0 = not sorted).  "
      "bn_stats / bn_stats_parts (forward): optional scratch of jp_conv2d_fwd_bn_stats_floats floats for a convolution that feeds a train-mode "
      "BatchNorm (" + R + "resnet.py:29-45; no bias, no activation): the 4-wave 3x3 patch kernels leave per-channel partial sums of y and y^2 "
      "there and *bn_stats_parts (host int) = the partials per channel, to be handed to jp_bn_train_fwd (conv_stats / conv_parts) in place of "
@@ -40,7 +41,7 @@ GROUPS = [
      "weight gradient (JP_P7S, W9S2) and a -DJP_NS=3 build use 6 bf16 products of exact 3-way bf16 splits (csrc/igemm_p9s.h:jp_split3: error "
      "<= the fp32 FMA chain's for 2^-109 <= |x| <= 3.3895e38; Inf -> NaN).  JP_P9S=0 JP_W9S=0 JP_P9US=0 JP_P9SD=0 JP_P9S2=0 selects the "
      "exact-fp32 MFMA kernels, which have none of these edges.",
-     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_bn_stats_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_replay"]),
+     ["jp_conv2d_fwd", "jp_conv2d_fwd_src3", "jp_conv2d_dgrad", "jp_conv2d_dgrad_src3", "jp_conv2d_dgrad_src3_split_floats", "jp_conv2d_dgrad_src3_ok", "jp_conv2d_up_head_ok", "jp_conv2d_wgrad", "jp_conv2d_wgrad_src3", "jp_conv2d_ws_floats", "jp_conv2d_fwd_bn_stats_floats", "jp_conv2d_fwd_split_floats", "jp_conv2d_dgrad_split_floats", "jp_conv2d_wgrad_ws_floats", "jp_conv2d_wgrad_src3_ws_floats", "jp_channel_sum_ws_floats", "jp_channel_sum", "jp_pack_job_bytes", "jp_pack_record_begin", "jp_pack_record_end", "jp_pack_mode_is_split", "jp_pack_replay"]),
     ("Operand scales of the fp16 split kernels (csrc/scale.hip, csrc/igemm_p9s.h:jp_split2h) -- no counterpart in the reference: plumbing of "
      "the arithmetic above, and since ABI version 3 entirely in the entry points' own ARGUMENTS (no library-owned device memory, no state "
      "between calls).  A kernel that forms its fp32 products from two fp16 splits per operand reads the operand tensor's largest "
