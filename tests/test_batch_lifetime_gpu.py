@@ -18,11 +18,11 @@ from jperceiver_amd.apis.trainer import change_input_variable                  #
 import bench                                                                   # noqa: E402
 
 
-@pytest.mark.parametrize("B,HW", [(8, 1024), (2, 512)])
-def test_temporary_batch_gives_the_held_batch_gradients(B, HW):
-    cfg = bench.CONFIGS[1]
+@pytest.mark.parametrize("ci,B,HW", [(1, 8, 1024), (1, 2, 512), (4, 2, 512)])      # configs[1] (static) and configs[4] (Argo_both: both heads' labels)
+def test_temporary_batch_gives_the_held_batch_gradients(ci, B, HW):
+    cfg = bench.CONFIGS[ci]
     FR = cfg["frames"]
-    opt = bench.make_opt(B, HW, HW, FR, cfg["type"], cfg["split"], loss_sum=cfg["loss_sum"])
+    opt = bench.make_opt(B, HW, HW, FR, cfg["type"], cfg["split"], loss_sum=cfg["loss_sum"], **cfg.get("extra", {}))
     model = MONO.module_dict["Baseline"](opt)
     model.load_state_dict(syn.synth_state_dict(model.state_dict(), seed=0), strict=True)
     model = model.cuda().train()
