@@ -49,8 +49,8 @@ __global__ __launch_bounds__(TPB) void sum_doubles_kernel(const double* __restri
 __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const double* __restrict__ normsq, float grad_scale,
-                                                   float max_norm, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2, const float* __restrict__ state) {
+                                                   float max_norm, float lr, float b1, float b2, float omb1, float omb2,
+                                                   float eps, float bc1, float bc2, const float* __restrict__ state) {
     if (state) { lr = state[0]; bc1 = state[1]; bc2 = state[2]; }      // captured step: this step's scalars live in device memory
     float coef = grad_scale;
     if (normsq && max_norm > 0.f) {
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const 
 #define JP_ADAM1(P, G, M, V)                                   \
     {                                                          \
         const float gs_ = (G) * coef;                          \
-        (M) = b1 * (M) + (1.f - b1) * gs_;                     \
-        (V) = b2 * (V) + (1.f - b2) * gs_ * gs_;                \
+        (M) = b1 * (M) + omb1 * gs_;                           \
+        (V) = b2 * (V) + omb2 * gs_ * gs_;                      \
         (P) -= step * (M) / (sqrtf(V) * isb2 + eps);           \
     }
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long)gridDim.x * TPB) {
@@ -150,7 +150,8 @@ extern "C" int jp_adam_clip_step(float* p, const float* g, float* m, float* v, l
     // bias corrections in double on the host, as torch.optim.Adam does with python floats
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, p, g, m, v, n, normsq, grad_scale, max_norm,
-                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)bc1, (float)bc2, (const float*)nullptr);
+                       (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)bc1,
+                       (float)bc2, (const float*)nullptr);
     JP_LAUNCH_CHECK();
 }
 
@@ -165,7 +166,7 @@ extern "C" int jp_adam_clip_step_dev(float* p, const float* g, float* m, float* 
     JP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_clip_step_dev: arenas must be 16-B aligned");
     JP_ST;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(TPB), 0, st, p, g, m, v, n, normsq, grad_scale, max_norm,
-                       0.f, (float)beta1, (float)beta2, (float)eps, 1.f, 1.f, state);
+                       0.f, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.f, 1.f, state);
     JP_LAUNCH_CHECK();
 }
 

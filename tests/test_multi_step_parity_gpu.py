@@ -131,13 +131,13 @@ def test_second_step_matches_oracle(name):
             if k in o2 and o2[k] is not None and k in out:
                 a, b = out[k].cpu(), o2[k].detach()
                 assert float((a - b).abs().max() / b.abs().max()) < 1e-3, (name, step, k)
-        # ---- gradients.  Measured at this state (tools/debug/step2_terms.py, profiles/r06_step2_terms.log): after one Adam step the
-        # photometric terms' gradients are ill-conditioned in fp32 -- per term the fp32 CPU oracle itself sits 1-5 % from float64 on the
-        # pose networks and the coarse decoder levels (the device 1-7 %), and in the total the two fp32 evaluations land 0.4 % and 5 %
-        # from float64 by luck of the draw (same picture with the exact -DJP_NS=3 library, and a model built fresh from this state
-        # reproduces the continuing model's gradients: tools/debug/second_step_fresh.py -- it is the function, not state).  So:
+        # ---- gradients.  The photometric terms' gradients are ill-conditioned (sums over 10^6 signed per-pixel terms whose sample
+        # positions move with every weight): a 1e-6 relative difference in the PARAMETERS moves them by several percent, and per term
+        # the two fp32 evaluations sit 1-5 % from float64 (tools/debug/step2_terms.py).  Both sides therefore evaluate step 2 at the
+        # device's parameters (synchronised below, after the Adam check), and step 2 is then as close as step 1 (measured medians
+        # 0.1-0.5 %).  So:
         #  (a) total gradient: every parameter within 15 % of its norm around the fp32 oracle -- or, failing that, within 20 % of the
-        #      float64 oracle -- and the median parameter within 2.5 % of the fp32 oracle (a pack, scale header or counter that did not
+        #      float64 oracle -- and the median parameter within 1 % of the fp32 oracle (a pack, scale header or counter that did not
         #      follow the weights moves EVERY gradient by more than that);
         bad, errs = [], []
         for n, p in named.items():
@@ -167,7 +167,9 @@ def test_second_step_matches_oracle(name):
                     worse.append((n, eh, ec))
             assert not worse, f"{name} step {step}: gradients more than 20 % off the float64 oracle (name, hip, cpu32): {worse[:8]}"
         errs.sort()
-        assert errs[len(errs) // 2] <= 2.5e-2, (name, step, errs[len(errs) // 2])     # measured: 0.3 % (512^2) .. 1.4 % (B = 8, 1024^2, step 2)
+        print(f"{name} step {step}: gradient distance to the fp32 oracle per parameter: median {errs[len(errs) // 2]:.3e}, max {errs[-1]:.3e}; "
+              f"outside the band: {len(bad)}")
+        assert errs[len(errs) // 2] <= 1e-2, (name, step, errs[len(errs) // 2])     # measured: 0.10-0.23 % (512^2), 0.45-0.50 % (B = 8, 1024^2), steps 1 and 2 alike
         if step == 2:
             #  (b) every term EXCEPT the photometric ones (scale, smoothness, layout / cycle losses: well-conditioned, and their
             #      backward runs through the same decoder / encoder / head kernels): element-wise, 2 % of each parameter's gradient
@@ -219,6 +221,15 @@ def test_second_step_matches_oracle(name):
         worst = max(float((p.detach().cpu() - P[n].detach()).abs().max()) for n, p in named.items() if n in P)
         assert worst <= 1e-6 * step, f"{name}: parameters after step {step} differ from the oracle trajectory by {worst}"
         assert optim.arena.step_count == step == adam["t"]
+        # Both trajectories continue from the DEVICE's parameters.  The two Adam updates agree to an ulp or two (asserted above), but the
+        # photometric terms amplify a 1e-6 relative parameter difference into several percent of gradient: measured with
+        # tools/debug/step2_forward_referee.py, the device's step-2 forward sits 2e-7 from the float64 forward AT ITS OWN parameters
+        # and 2e-6 from the float64 forward at the oracle's, and the round's first "step-2 gradients 5-13 % from float64" were that
+        # difference, not the kernels (profiles/r06_step2_forward_referee.log).
+        with torch.no_grad():
+            for n, p in named.items():
+                if n in P:
+                    P[n].copy_(p.detach().cpu())
         # BatchNorm buffers walk with the oracle's (running statistics after `step` momentum updates, counters)
         sd = model.state_dict()
         for n, b in Bf.items():

@@ -54,3 +54,8 @@ for step in (1, 2):
     T._feed_device_grads(model, P)
     J.adam_step(P, adam, lr=1e-4, max_norm=35.0)
     optim.step()
+    if os.environ.get("SYNC_PARAMS", "1") != "0":     # continue from the DEVICE's parameters (an ulp of difference moves the photometric gradients by percent)
+        with torch.no_grad():
+            for n, p in named.items():
+                if n in P:
+                    P[n].copy_(p.detach().cpu())
