@@ -167,12 +167,23 @@ def build_runner(optd, dev, world, rank, batch_kw, step_graph=False):
     return runner, batch
 
 
-def timed_steps(runner, batch, steps, warmup, world, dev, log, calibrate=None):
+PREWARM = 0 if os.environ.get("JP_PMC_CALIB") else int(os.environ.get("JP_BENCH_PREWARM", "30"))     # (counter passes: every launch is replayed)
+
+
+def timed_steps(runner, batch, steps, warmup, world, dev, log, calibrate=None, prewarm=0):
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Pre-warm (reported as `prewarm_steps`): a process that is the FIRST on a cold box needs a few seconds of load before the step
+    # time settles (measured: 63.9 ms for 20 steps after 5 warm-up steps as the first process on a box, 62.7 after 40, 62.4 / 62.3 for
+    # the next processes after 5 -- profiles/r06_bench_repeat_head.log).  These untimed steps come BEFORE the W warm-up steps the
+    # caller asked for; the timed region is unchanged.  A fixed count: every rank must issue the same number of exchanges.
+    for _ in range(prewarm):
+        runner.train_iter(batch)
+    if prewarm:
+        torch.cuda.synchronize()
     for i in range(warmup):
         t_w = time.perf_counter()
         runner.train_iter(batch)
@@ -306,7 +317,7 @@ def main():
     if use_graph and args.warmup < 3:
         log("note: the captured step needs 2 eager iterations + the capture itself: --warmup < 3 puts them inside the timed region")
     calib = {} if (use_graph and args.graph == "auto") else None
-    dt, out, multi = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log, calibrate=calib)
+    dt, out, multi = timed_steps(runner, batch, args.steps, args.warmup, world, dev, log, calibrate=calib, prewarm=PREWARM)
     use_graph = bool(runner.step_graph)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
@@ -342,6 +353,7 @@ def main():
         line = {
             "metric": f"train images/sec (full train step, synthetic {len(frames)}-frame batches)", "value": round(value, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "prewarm_steps": PREWARM,       # untimed steps before the W warm-up steps (cold-box settling, see timed_steps)
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": ARITHMETIC[_scheme()],

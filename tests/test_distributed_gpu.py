@@ -128,7 +128,7 @@ def test_bench_two_rank_code_path_on_one_gpu():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, JP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, JP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JP_BENCH_PREWARM="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "1", "--hw", "256", "--no-cpu-baseline", "--no-secondary"]
@@ -270,7 +270,7 @@ def test_bench_self_launch_two_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(JP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(JP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JP_BENCH_PREWARM="2")      # (the pre-warm loop on two ranks)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "2",
            "--batch", "1", "--hw", "256", "--no-cpu-baseline", "--no-secondary", "--no-roofline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -292,7 +292,7 @@ def test_bench_two_gpus_rccl():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", JP_BENCH_PREWARM="0")
     env.pop("JP_DIST_BACKEND", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "1",
            "--no-cpu-baseline", "--no-secondary", "--no-roofline"]

@@ -6,9 +6,10 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $ROOT
+export JP_BENCH_PREWARM=0      # the profiled / short bench runs below count on steps + warmup iterations exactly; the headline line pre-warms
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
-JP_BENCH_TABLE=$OUT/bench_families.json timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+JP_BENCH_PREWARM=30 JP_BENCH_TABLE=$OUT/bench_families.json timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 # the other BASELINE.json configs on one GPU (config 0 / 4 = one image per GPU: with and without the captured step)
 : > $OUT/bench_other_configs.jsonl
 for c in 0 4; do for g in off on; do timeout 300 python bench.py --config $c --graph $g --steps 20 --warmup 4 --no-cpu-baseline --no-secondary --no-roofline >> $OUT/bench_other_configs.jsonl 2>> $OUT/bench_other.err; done; done
